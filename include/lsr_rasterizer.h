@@ -1,0 +1,155 @@
+/*
+ * lsr_rasterizer.h — C ABI of the MI355X-native latentSplat rasterizer ("lsr").
+ *
+ * This is the drop-in boundary for the ONE hot path named by BASELINE.json:north_star: the
+ * Gaussian-splat rasterizer behind `diff_gaussian_rasterization.GaussianRasterizer`.
+ *
+ * What it replaces in the reference (all paths relative to /root/reference):
+ *   - the pybind entry points `_C.rasterize_gaussians` / `_C.rasterize_gaussians_backward` of the
+ *     external package `git+https://github.com/Chrixtar/latent-gaussian-rasterization`
+ *     (requirements.txt:33), which the reference reaches through
+ *     `GaussianRasterizer(settings)(means3D=..., means2D=..., shs=..., colors_precomp=...,
+ *     features=..., opacities=..., cov3D_precomp=...)` at
+ *     src/model/decoder/cuda_splatting.py:132-158 (perspective) and :257-283 (orthographic).
+ *   - lsr_forward_prepare + lsr_forward_render  <->  `_C.rasterize_gaussians`
+ *     (forward of the autograd Function called at cuda_splatting.py:150-158);
+ *   - lsr_backward                              <->  `_C.rasterize_gaussians_backward`
+ *     (reached from `self.manual_backward(...)`, src/model/model_wrapper.py:440).
+ *
+ * Differences from the per-view reference call, by design (MI355X-first):
+ *   - one call renders `num_views` views; every per-Gaussian input carries a per-view element
+ *     stride, and stride 0 means "one scene shared by all views" (removes the v-fold `repeat`
+ *     at src/model/decoder/decoder_splatting_cuda.py:71-87);
+ *   - camera parameters live in a device-side view table, so no host<->device sync is needed to
+ *     fetch tan(fov) (removes the `.item()` at cuda_splatting.py:135-136);
+ *   - scratch memory is provided by the caller (two-phase: query size, then run), so the library
+ *     is allocator-agnostic; with PyTorch it comes from the caching allocator.
+ *
+ * Plain C: pointers and sizes only, no torch / HIP types in the signatures.  All data pointers
+ * are DEVICE pointers unless the name ends in `_host`.  All functions return 0 on success or a
+ * negative LSR_E* code; nothing here throws.  The library never allocates device memory.
+ */
+#ifndef LSR_RASTERIZER_H
+#define LSR_RASTERIZER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSR_ABI_VERSION 1
+#define LSR_TILE 16            /* tile edge in pixels (16x16 = the published algorithm's tile) */
+#define LSR_MAX_FEAT_CHANNELS 32
+#define LSR_MAX_SH_DEGREE 4
+
+/* Per-view camera record, LSR_VIEW_FLOATS consecutive floats:
+ *   [0..15]  viewmatrix  — memory of `settings.viewmatrix` (row-major tensor holding the
+ *                          transposed world->view matrix, cuda_splatting.py:116,139)
+ *   [16..31] projmatrix  — memory of `settings.projmatrix` (transposed world->clip, :117,140)
+ *   [32..34] campos      — `settings.campos` (:142)
+ *   [35]     tanfovx, [36] tanfovy   (:135-136)
+ *   [37..39] bg          — `settings.bg` (3 entries; feature background is 0) (:137)          */
+#define LSR_VIEW_FLOATS 40
+
+enum { LSR_COLOR_NONE = 0, LSR_COLOR_SH = 1, LSR_COLOR_PRECOMP = 2 };
+
+enum {
+    LSR_OK = 0,
+    LSR_EINVAL = -1,     /* bad dimensions / argument combination */
+    LSR_ENULL = -2,      /* required pointer is NULL */
+    LSR_ELAUNCH = -3,    /* HIP runtime reported an error (see lsr_last_hip_error) */
+    LSR_ECAPACITY = -4,  /* num_pairs smaller than what prepare() counted */
+    LSR_EUNSUPPORTED = -5
+};
+
+typedef void *lsr_stream_t; /* a hipStream_t */
+
+typedef struct lsr_dims {
+    int32_t num_views;      /* V >= 1 */
+    int32_t num_gaussians;  /* G >= 0 */
+    int32_t height, width;  /* image size in pixels */
+    int32_t feat_channels;  /* C: 0 = no `features=` input (feature_map is None) */
+    int32_t color_mode;     /* LSR_COLOR_* : none / `shs=` / `colors_precomp=` */
+    int32_t sh_degree;      /* `settings.sh_degree`, 0..4 */
+    int32_t sh_coeffs;      /* K = shs.shape[1] >= (sh_degree+1)^2 */
+    /* element strides between consecutive views; 0 = shared by all views */
+    int64_t vs_means;       /* means3D   (G,3)   */
+    int64_t vs_cov;         /* cov3D_precomp (G,6): xx,xy,xz,yy,yz,zz (cuda_splatting.py:148,157) */
+    int64_t vs_opac;        /* opacities (G,1)   */
+    int64_t vs_color;       /* shs (G,K,3) or colors_precomp (G,3) */
+    int64_t vs_feat;        /* features  (G,C)   */
+} lsr_dims;
+
+typedef struct lsr_inputs {
+    const float *views;      /* [V][LSR_VIEW_FLOATS] */
+    const float *means3D;
+    const float *cov3D;
+    const float *opacities;
+    const float *color;      /* shs or colors_precomp, NULL when color_mode == NONE */
+    const float *features;   /* NULL when feat_channels == 0 */
+} lsr_inputs;
+
+typedef struct lsr_outputs {
+    float *color;    /* [V][3][H][W] or NULL */
+    float *feature;  /* [V][C][H][W] or NULL */
+    float *mask;     /* [V][H][W]  = 1 - T_final */
+    float *depth;    /* [V][H][W]  = sum_i alpha_i T_i z_i */
+    int32_t *radii;  /* [V][G] screen radius in pixels, 0 = culled (5th tuple element) */
+} lsr_outputs;
+
+typedef struct lsr_out_grads { /* any may be NULL (treated as zero) */
+    const float *color, *feature, *mask, *depth;
+} lsr_out_grads;
+
+typedef struct lsr_in_grads { /* shapes follow the inputs: (G,..) when the stride is 0 (summed
+                                 over views) else (V,G,..). Fully overwritten by lsr_backward. */
+    float *means3D;   /* required */
+    float *cov3D;     /* required */
+    float *opacities; /* required */
+    float *color;     /* dL/dshs or dL/dcolors_precomp; required iff color_mode != NONE */
+    float *features;  /* required iff feat_channels > 0 */
+    float *means2D;   /* [V][G][3] NDC-space gradient of the projected mean (x,y,0); optional */
+} lsr_in_grads;
+
+/* Debug / test view of the workspaces (byte offsets from the respective workspace base). */
+typedef struct lsr_layout {
+    size_t geom_q0, geom_q1, geom_rect, geom_rgb, geom_tile_count, geom_tile_start, geom_header;
+    size_t bin_keys, bin_point_list;
+    size_t img_final_T, img_n_contrib;
+} lsr_layout;
+
+int lsr_abi_version(void);
+const char *lsr_error_string(int code);
+int lsr_last_hip_error(void); /* last hipError_t seen by this thread's lsr call (0 = none) */
+
+/* ---- workspace sizing (host only, no GPU work) ---- */
+size_t lsr_geom_workspace_bytes(const lsr_dims *d);
+size_t lsr_image_workspace_bytes(const lsr_dims *d);
+size_t lsr_binning_workspace_bytes(const lsr_dims *d, int64_t num_pairs, int32_t max_tile_pairs);
+size_t lsr_grad_workspace_bytes(const lsr_dims *d);
+int lsr_get_layout(const lsr_dims *d, int64_t num_pairs, lsr_layout *out);
+
+/* ---- forward, phase 1: per-Gaussian preprocess + per-tile counting + tile offset scan.
+ * Writes radii.  Synchronises `stream` once to return the pair count and the longest tile list
+ * through the two host pointers (both required). */
+int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii,
+                        int64_t *num_pairs_host, int32_t *max_tile_pairs_host,
+                        lsr_stream_t stream);
+
+/* ---- forward, phase 2: binning, per-tile depth sort, front-to-back compositing. Async. */
+int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, void *bin_ws,
+                       void *img_ws, int64_t num_pairs, int32_t max_tile_pairs,
+                       const lsr_outputs *out, lsr_stream_t stream);
+
+/* ---- backward. Needs the three workspaces of the matching forward, unmodified. Async. */
+int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws,
+                 const void *bin_ws, const void *img_ws, int64_t num_pairs,
+                 const int32_t *radii, const lsr_out_grads *gout, void *grad_ws,
+                 const lsr_in_grads *gin, lsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSR_RASTERIZER_H */

@@ -1,0 +1,123 @@
+"""ctypes binding of ``liblsr_hip.so`` (C ABI: include/lsr_rasterizer.h).
+
+The library is built in-tree by ``latentsplat_amd/csrc/Makefile`` (``__graft_entry__.build()``).
+There is no CPU fallback: if the shared object is missing or not loadable this module raises, and
+every product entry point above it fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_SO = os.path.join(_CSRC, "liblsr_hip.so")
+
+VIEW_FLOATS = 40
+COLOR_NONE, COLOR_SH, COLOR_PRECOMP = 0, 1, 2
+MAX_FEAT_CHANNELS = 32
+
+
+class LsrError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [("num_views", C.c_int32), ("num_gaussians", C.c_int32), ("height", C.c_int32),
+                ("width", C.c_int32), ("feat_channels", C.c_int32), ("color_mode", C.c_int32),
+                ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32), ("vs_means", C.c_int64),
+                ("vs_cov", C.c_int64), ("vs_opac", C.c_int64), ("vs_color", C.c_int64),
+                ("vs_feat", C.c_int64)]
+
+
+class Inputs(C.Structure):
+    _fields_ = [("views", C.c_void_p), ("means3D", C.c_void_p), ("cov3D", C.c_void_p),
+                ("opacities", C.c_void_p), ("color", C.c_void_p), ("features", C.c_void_p)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("feature", C.c_void_p), ("mask", C.c_void_p),
+                ("depth", C.c_void_p), ("radii", C.c_void_p)]
+
+
+class OutGrads(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("feature", C.c_void_p), ("mask", C.c_void_p),
+                ("depth", C.c_void_p)]
+
+
+class InGrads(C.Structure):
+    _fields_ = [("means3D", C.c_void_p), ("cov3D", C.c_void_p), ("opacities", C.c_void_p),
+                ("color", C.c_void_p), ("features", C.c_void_p), ("means2D", C.c_void_p)]
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in
+                ("geom_q0", "geom_q1", "geom_rect", "geom_rgb", "geom_tile_count", "geom_tile_start",
+                 "geom_header", "bin_keys", "bin_point_list", "img_final_T", "img_n_contrib")]
+
+
+EXPORTS = (
+    "lsr_abi_version", "lsr_error_string", "lsr_last_hip_error", "lsr_geom_workspace_bytes",
+    "lsr_image_workspace_bytes", "lsr_binning_workspace_bytes", "lsr_grad_workspace_bytes",
+    "lsr_get_layout", "lsr_forward_prepare", "lsr_forward_render", "lsr_backward",
+)
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def so_path() -> str:
+    return _SO
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise LsrError(
+            f"{_SO} not found: the MI355X rasterizer extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU "
+            "fallback for the product path.")
+    try:
+        lib = C.CDLL(_SO)
+    except OSError as e:  # e.g. libamdhip64 missing on a machine without ROCm
+        raise LsrError(f"cannot load {_SO}: {e}") from e
+    P, I32, I64, SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    lib.lsr_abi_version.restype = C.c_int
+    lib.lsr_error_string.restype = C.c_char_p
+    lib.lsr_error_string.argtypes = [C.c_int]
+    lib.lsr_last_hip_error.restype = C.c_int
+    for name in ("lsr_geom_workspace_bytes", "lsr_image_workspace_bytes", "lsr_grad_workspace_bytes"):
+        getattr(lib, name).restype = SZ
+        getattr(lib, name).argtypes = [C.POINTER(Dims)]
+    lib.lsr_binning_workspace_bytes.restype = SZ
+    lib.lsr_binning_workspace_bytes.argtypes = [C.POINTER(Dims), I64, I32]
+    lib.lsr_get_layout.restype = C.c_int
+    lib.lsr_get_layout.argtypes = [C.POINTER(Dims), I64, C.POINTER(Layout)]
+    lib.lsr_forward_prepare.restype = C.c_int
+    lib.lsr_forward_prepare.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, C.POINTER(I64),
+                                        C.POINTER(I32), P]
+    lib.lsr_forward_render.restype = C.c_int
+    lib.lsr_forward_render.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, I32,
+                                       C.POINTER(Outputs), P]
+    lib.lsr_backward.restype = C.c_int
+    lib.lsr_backward.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, P,
+                                 C.POINTER(OutGrads), P, C.POINTER(InGrads), P]
+    if lib.lsr_abi_version() != 1:
+        raise LsrError("liblsr_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        lib = load()
+        msg = lib.lsr_error_string(rc).decode()
+        raise LsrError(f"{what} failed: {msg} (code {rc}, hipError {lib.lsr_last_hip_error()})")

@@ -1,0 +1,162 @@
+// api.hip — the C ABI declared in include/lsr_rasterizer.h (argument validation, workspace
+// layout, stage sequencing).  No torch, no allocation, nothing thrown across the boundary.
+#include <string.h>
+
+#include "lsr_internal.h"
+
+using namespace lsr;
+
+static thread_local int g_last_hip_error = 0;
+
+static int fail_hip(hipError_t e) {
+    g_last_hip_error = (int)e;
+    return LSR_ELAUNCH;
+}
+#define LSR_HIP(call)                                 \
+    do {                                              \
+        hipError_t e__ = (call);                      \
+        if (e__ != hipSuccess) return fail_hip(e__);  \
+    } while (0)
+
+static int check_dims(const lsr_dims *d) {
+    if (!d) return LSR_ENULL;
+    if (d->num_views < 1 || d->num_gaussians < 0 || d->height < 1 || d->width < 1) return LSR_EINVAL;
+    if (d->feat_channels < 0 || d->feat_channels > LSR_MAX_FEAT_CHANNELS) return LSR_EINVAL;
+    if (d->color_mode < LSR_COLOR_NONE || d->color_mode > LSR_COLOR_PRECOMP) return LSR_EINVAL;
+    if (d->color_mode == LSR_COLOR_NONE && d->feat_channels == 0) return LSR_EINVAL;
+    if (d->color_mode == LSR_COLOR_SH) {
+        if (d->sh_degree < 0 || d->sh_degree > LSR_MAX_SH_DEGREE) return LSR_EINVAL;
+        if (d->sh_coeffs < (d->sh_degree + 1) * (d->sh_degree + 1)) return LSR_EINVAL;
+    }
+    if (tiles_x(*d) > 65535 || tiles_y(*d) > 65535) return LSR_EUNSUPPORTED;
+    if ((int64_t)d->num_views * num_tiles(*d) > (int64_t)1 << 30) return LSR_EUNSUPPORTED;
+    // per-view strides: 0 (shared scene) or exactly one dense (G, ...) array per view
+    const int64_t G = d->num_gaussians;
+    const int64_t color_elems = d->color_mode == LSR_COLOR_SH ? (int64_t)d->sh_coeffs * 3 : 3;
+    if (d->vs_means != 0 && d->vs_means != 3 * G) return LSR_EINVAL;
+    if (d->vs_cov != 0 && d->vs_cov != 6 * G) return LSR_EINVAL;
+    if (d->vs_opac != 0 && d->vs_opac != G) return LSR_EINVAL;
+    if (d->color_mode != LSR_COLOR_NONE && d->vs_color != 0 && d->vs_color != color_elems * G) return LSR_EINVAL;
+    if (d->feat_channels > 0 && d->vs_feat != 0 && d->vs_feat != (int64_t)d->feat_channels * G) return LSR_EINVAL;
+    return LSR_OK;
+}
+static int check_inputs(const lsr_dims *d, const lsr_inputs *in) {
+    if (!in || !in->views) return LSR_ENULL;
+    if (d->num_gaussians > 0) {
+        if (!in->means3D || !in->cov3D || !in->opacities) return LSR_ENULL;
+        if (d->color_mode != LSR_COLOR_NONE && !in->color) return LSR_ENULL;
+        if (d->feat_channels > 0 && !in->features) return LSR_ENULL;
+    }
+    return LSR_OK;
+}
+
+extern "C" {
+
+int lsr_abi_version(void) { return LSR_ABI_VERSION; }
+int lsr_last_hip_error(void) { return g_last_hip_error; }
+
+const char *lsr_error_string(int code) {
+    switch (code) {
+        case LSR_OK: return "ok";
+        case LSR_EINVAL: return "invalid dimensions or argument combination";
+        case LSR_ENULL: return "required pointer is NULL";
+        case LSR_ELAUNCH: return "HIP runtime error (see lsr_last_hip_error)";
+        case LSR_ECAPACITY: return "num_pairs is smaller than the pair count of lsr_forward_prepare";
+        case LSR_EUNSUPPORTED: return "unsupported size";
+        default: return "unknown lsr error";
+    }
+}
+
+size_t lsr_geom_workspace_bytes(const lsr_dims *d) { return check_dims(d) ? 0 : geom_layout(*d).total; }
+size_t lsr_image_workspace_bytes(const lsr_dims *d) { return check_dims(d) ? 0 : img_layout(*d).total; }
+size_t lsr_binning_workspace_bytes(const lsr_dims *d, int64_t num_pairs, int32_t max_tile_pairs) {
+    return check_dims(d) ? 0 : bin_layout(*d, num_pairs, max_tile_pairs).total;
+}
+size_t lsr_grad_workspace_bytes(const lsr_dims *d) { return check_dims(d) ? 0 : grad_layout(*d).total; }
+
+int lsr_get_layout(const lsr_dims *d, int64_t num_pairs, lsr_layout *out) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!out) return LSR_ENULL;
+    const GeomLayout L = geom_layout(*d);
+    const BinLayout B = bin_layout(*d, num_pairs, 0);
+    const ImgLayout I = img_layout(*d);
+    out->geom_q0 = L.q0; out->geom_q1 = L.q1; out->geom_rect = L.rect; out->geom_rgb = L.rgb;
+    out->geom_tile_count = L.tile_count; out->geom_tile_start = L.tile_start; out->geom_header = L.header;
+    out->bin_keys = B.keys; out->bin_point_list = B.point_list;
+    out->img_final_T = I.final_T; out->img_n_contrib = I.n_contrib;
+    return LSR_OK;
+}
+
+int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii,
+                        int64_t *num_pairs_host, int32_t *max_tile_pairs_host, lsr_stream_t stream) {
+    g_last_hip_error = 0;
+    int rc = check_dims(d);
+    if (rc) return rc;
+    rc = check_inputs(d, in);
+    if (rc) return rc;
+    if (!geom_ws || !num_pairs_host || !max_tile_pairs_host) return LSR_ENULL;
+    if (d->num_gaussians > 0 && !radii) return LSR_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    char *geom = (char *)geom_ws;
+    LSR_HIP(launch_preprocess(*d, *in, geom, radii, s));
+    LSR_HIP(launch_tile_scan(*d, geom, s));
+    uint32_t hdr[2] = {0, 0};
+    LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));
+    LSR_HIP(hipStreamSynchronize(s));
+    *num_pairs_host = (int64_t)hdr[0];
+    *max_tile_pairs_host = (int32_t)hdr[1];
+    return LSR_OK;
+}
+
+int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, void *bin_ws,
+                       void *img_ws, int64_t num_pairs, int32_t max_tile_pairs,
+                       const lsr_outputs *out, lsr_stream_t stream) {
+    g_last_hip_error = 0;
+    int rc = check_dims(d);
+    if (rc) return rc;
+    rc = check_inputs(d, in);
+    if (rc) return rc;
+    if (!geom_ws || !img_ws || !out || !out->mask || !out->depth) return LSR_ENULL;
+    if (num_pairs > 0 && !bin_ws) return LSR_ENULL;
+    if (d->color_mode != LSR_COLOR_NONE && !out->color) return LSR_ENULL;
+    if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
+    if (num_pairs < 0 || max_tile_pairs < 0) return LSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    LSR_HIP(launch_binning(*d, (char *)geom_ws, (char *)bin_ws, num_pairs, max_tile_pairs, out->radii, s));
+    LSR_HIP(launch_render_forward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, (char *)img_ws, *out, s));
+    return LSR_OK;
+}
+
+int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, const void *bin_ws,
+                 const void *img_ws, int64_t num_pairs, const int32_t *radii,
+                 const lsr_out_grads *gout, void *grad_ws, const lsr_in_grads *gin,
+                 lsr_stream_t stream) {
+    g_last_hip_error = 0;
+    int rc = check_dims(d);
+    if (rc) return rc;
+    rc = check_inputs(d, in);
+    if (rc) return rc;
+    if (!gout || !gin || !geom_ws || !img_ws || !grad_ws) return LSR_ENULL;
+    if (d->num_gaussians == 0) return LSR_OK;
+    if (!radii || !gin->means3D || !gin->cov3D || !gin->opacities) return LSR_ENULL;
+    if (d->color_mode != LSR_COLOR_NONE && !gin->color) return LSR_ENULL;
+    if (d->feat_channels > 0 && !gin->features) return LSR_ENULL;
+    if (num_pairs > 0 && !bin_ws) return LSR_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t V = d->num_views, G = d->num_gaussians;
+    // zero every accumulation target of the compositing backward
+    LSR_HIP(hipMemsetAsync(grad_ws, 0, grad_layout(*d).total, s));
+    LSR_HIP(hipMemsetAsync(gin->opacities, 0, (d->vs_opac ? V : 1) * G * sizeof(float), s));
+    if (d->feat_channels > 0)
+        LSR_HIP(hipMemsetAsync(gin->features, 0, (d->vs_feat ? V : 1) * G * d->feat_channels * sizeof(float), s));
+    if (d->color_mode == LSR_COLOR_PRECOMP)
+        LSR_HIP(hipMemsetAsync(gin->color, 0, (d->vs_color ? V : 1) * G * 3 * sizeof(float), s));
+    if (num_pairs > 0)
+        LSR_HIP(launch_render_backward(*d, *in, (const char *)geom_ws, (const char *)bin_ws,
+                                       (const char *)img_ws, *gout, (char *)grad_ws, *gin, s));
+    LSR_HIP(launch_preprocess_backward(*d, *in, (const char *)geom_ws, radii, (const char *)grad_ws, *gin, s));
+    return LSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,229 @@
+// binning.hip — stages K2-K5 re-designed for CDNA4: instead of one global 64-bit radix sort over
+// all (tile, depth) keys, pairs are binned straight into per-tile segments and every tile list
+// is depth-sorted inside LDS by its own workgroup.
+//
+//   k_tile_scan : exclusive scan of the per-tile pair counts (V*T entries) -> tile_start,
+//                 total pair count and the longest list (header[0], header[1]).
+//   k_scatter   : every visible Gaussian writes (depth_bits<<32 | index) into each tile segment
+//                 it overlaps.  Slots come from a two-level reservation: LDS counters per block,
+//                 then ONE global atomic per (block, tile).
+//   k_sort_tiles: per-tile bitonic sort of the 64-bit keys in LDS.  Ascending (depth bits, index)
+//                 == the published stable sort by depth with ties in emission (= index) order,
+//                 so lists are bit-exact whatever order the scatter produced.
+#include "lsr_internal.h"
+
+namespace lsr {
+
+// ------------------------------------------------------------------------------------------
+constexpr int kScanThreads = 1024;
+
+__global__ void __launch_bounds__(kScanThreads)
+k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *header, int N) {
+    __shared__ uint32_t s_sum[kScanThreads];
+    __shared__ uint32_t s_max[kScanThreads];
+    const int tid = threadIdx.x;
+    const int per = (N + kScanThreads - 1) / kScanThreads;
+    const int lo = tid * per, hi = min(N, lo + per);
+    uint32_t sum = 0, mx = 0;
+    for (int i = lo; i < hi; ++i) { const uint32_t c = count[i]; sum += c; mx = max(mx, c); }
+    s_sum[tid] = sum; s_max[tid] = mx;
+    __syncthreads();
+    for (int off = 1; off < kScanThreads; off <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t a = 0, m = 0;
+        if (tid >= off) { a = s_sum[tid - off]; m = s_max[tid - off]; }
+        __syncthreads();
+        s_sum[tid] += a; s_max[tid] = max(s_max[tid], m);
+        __syncthreads();
+    }
+    uint32_t run = s_sum[tid] - sum;  // exclusive prefix of this thread's chunk
+    for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
+    if (tid == kScanThreads - 1) { start[N] = s_sum[tid]; header[0] = s_sum[tid]; header[1] = s_max[tid]; }
+}
+
+hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s) {
+    const GeomLayout L = geom_layout(d);
+    const int N = d.num_views * (int)num_tiles(d);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
+                       (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
+                       (uint32_t *)(geom + L.header), N);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+constexpr int kScatThreads = 256;
+constexpr int kScatItems = 8;
+
+template <bool LDS_RESERVE>
+__global__ void __launch_bounds__(kScatThreads)
+k_scatter(int G, int gx, int T, const ushort4 *__restrict__ rect, const float4 *__restrict__ q1,
+          const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ tile_cursor,
+          uint64_t *__restrict__ keys) {
+    extern __shared__ uint32_t s_mem[];  // [T] counts, [T] bases
+    uint32_t *s_cnt = s_mem, *s_base = s_mem + T;
+    const int v = blockIdx.y;
+    const size_t vo = (size_t)v * G;
+    const uint32_t *ts = tile_start + (size_t)v * T;
+    uint32_t *cur = tile_cursor + (size_t)v * T;
+    const int base = blockIdx.x * (kScatThreads * kScatItems);
+    ushort4 r[kScatItems];
+#pragma unroll
+    for (int it = 0; it < kScatItems; ++it) {
+        const int i = base + it * kScatThreads + threadIdx.x;
+        r[it] = i < G ? rect[vo + i] : make_ushort4(0, 0, 0, 0);
+    }
+    if (LDS_RESERVE) {
+        for (int t = threadIdx.x; t < T; t += kScatThreads) s_cnt[t] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kScatItems; ++it)
+            for (int y = r[it].y; y < r[it].w; ++y)
+                for (int x = r[it].x; x < r[it].z; ++x) atomicAdd(&s_cnt[y * gx + x], 1u);
+        __syncthreads();
+        for (int t = threadIdx.x; t < T; t += kScatThreads) {
+            const uint32_t c = s_cnt[t];
+            if (c) s_base[t] = ts[t] + atomicAdd(&cur[t], c);
+            s_cnt[t] = 0;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < kScatItems; ++it) {
+        const int i = base + it * kScatThreads + threadIdx.x;
+        if (r[it].z <= r[it].x || r[it].w <= r[it].y) continue;
+        const uint64_t key = ((uint64_t)__float_as_uint(q1[vo + i].z) << 32) | (uint32_t)i;
+        for (int y = r[it].y; y < r[it].w; ++y)
+            for (int x = r[it].x; x < r[it].z; ++x) {
+                const int t = y * gx + x;
+                uint32_t pos;
+                if (LDS_RESERVE) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
+                else pos = ts[t] + atomicAdd(&cur[t], 1u);
+                keys[pos] = key;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+constexpr int kSortThreads = 256;
+
+__device__ __forceinline__ void cmpswap(uint64_t &a, uint64_t &b, bool up) {
+    if ((a > b) == up) { const uint64_t t = a; a = b; b = t; }
+}
+
+// One workgroup per (tile, view); list length n <= CAP (power of two), keys staged in LDS.
+template <int CAP>
+__global__ void __launch_bounds__(kSortThreads)
+k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
+             uint32_t *__restrict__ point_list) {
+    extern __shared__ uint64_t s_keys[];
+    const size_t vt = (size_t)blockIdx.y * T + blockIdx.x;
+    const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
+    if (n == 0) return;
+    if (n > (uint32_t)CAP) return;  // handled by the global-memory path
+    uint32_t npad = 2;
+    while (npad < n) npad <<= 1;
+    for (uint32_t i = threadIdx.x; i < npad; i += kSortThreads)
+        s_keys[i] = i < n ? keys[start + i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += kSortThreads) {
+                // t-th compare-exchange of this stage: partner indices differ in bit j
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t hi = lo | j;
+                const bool up = (lo & k) == 0;
+                uint64_t a = s_keys[lo], b = s_keys[hi];
+                if ((a > b) == up) { s_keys[lo] = b; s_keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
+        point_list[start + i] = (uint32_t)(s_keys[i] & 0xffffffffull);
+}
+
+// Global-memory path for lists longer than the LDS capacity: bottom-up merge sort by one
+// workgroup per oversized tile (rank-by-binary-search merges, ping-pong between keys and tmp).
+// Rare (needs > kSortLdsMax Gaussians over one 16x16 tile); correctness path, not tuned.
+__device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t n, uint64_t x) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ void __launch_bounds__(kSortThreads)
+k_sort_tiles_global(int T, uint32_t cap, const uint32_t *__restrict__ tile_start,
+                    uint64_t *keys, uint64_t *tmp, uint32_t *__restrict__ point_list) {
+    const size_t vt = (size_t)blockIdx.y * T + blockIdx.x;
+    const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
+    if (n <= cap) return;
+    uint64_t *src = keys + start, *dst = tmp + start;
+    // width-1 runs are trivially sorted; keys are unique (index in the low word) so ranks are exact
+    for (uint32_t w = 1; w < n; w <<= 1) {
+        for (uint32_t i = threadIdx.x; i < n; i += kSortThreads) {
+            const uint32_t pair = i / (2 * w), a0 = pair * 2 * w;
+            const uint32_t a1 = min(a0 + w, n), b1 = min(a0 + 2 * w, n);
+            const uint64_t x = src[i];
+            uint32_t pos;
+            if (i < a1) pos = a0 + (i - a0) + lower_bound_u64(src + a1, b1 - a1, x);
+            else pos = a0 + (i - a1) + lower_bound_u64(src + a0, a1 - a0, x);
+            dst[pos] = x;
+        }
+        __threadfence_block();
+        __syncthreads();
+        uint64_t *t = src; src = dst; dst = t;
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
+        point_list[start + i] = (uint32_t)(src[i] & 0xffffffffull);
+}
+
+hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
+                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s) {
+    (void)radii;
+    if (num_pairs <= 0 || d.num_gaussians == 0) return hipSuccess;
+    const GeomLayout L = geom_layout(d);
+    const BinLayout B = bin_layout(d, num_pairs, max_tile_pairs);
+    const int T = (int)num_tiles(d), gx = tiles_x(d);
+    uint64_t *keys = (uint64_t *)(bin + B.keys);
+    uint32_t *plist = (uint32_t *)(bin + B.point_list);
+    const uint32_t *ts = (const uint32_t *)(geom + L.tile_start);
+    {
+        dim3 grid((d.num_gaussians + kScatThreads * kScatItems - 1) / (kScatThreads * kScatItems), d.num_views);
+        const bool lds = T <= 8192;
+        if (lds)
+            hipLaunchKernelGGL((k_scatter<true>), grid, dim3(kScatThreads), (size_t)T * 8, s,
+                               d.num_gaussians, gx, T, (const ushort4 *)(geom + L.rect),
+                               (const float4 *)(geom + L.q1), ts, (uint32_t *)(geom + L.tile_cursor), keys);
+        else
+            hipLaunchKernelGGL((k_scatter<false>), grid, dim3(kScatThreads), 0, s, d.num_gaussians,
+                               gx, T, (const ushort4 *)(geom + L.rect), (const float4 *)(geom + L.q1),
+                               ts, (uint32_t *)(geom + L.tile_cursor), keys);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    {
+        dim3 grid(T, d.num_views);
+        int cap;
+#define LSR_SORT(CAPV)                                                                           \
+    do {                                                                                         \
+        cap = CAPV;                                                                              \
+        hipLaunchKernelGGL((k_sort_tiles<CAPV>), grid, dim3(kSortThreads), (size_t)CAPV * 8, s,  \
+                           T, ts, (const uint64_t *)keys, plist);                                \
+    } while (0)
+        if (max_tile_pairs <= 1024) LSR_SORT(1024);
+        else if (max_tile_pairs <= 2048) LSR_SORT(2048);
+        else if (max_tile_pairs <= 4096) LSR_SORT(4096);
+        else if (max_tile_pairs <= 8192) LSR_SORT(8192);
+        else LSR_SORT(16384);
+#undef LSR_SORT
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (max_tile_pairs > cap) {
+            hipLaunchKernelGGL(k_sort_tiles_global, grid, dim3(kSortThreads), 0, s, T, (uint32_t)cap,
+                               ts, keys, (uint64_t *)(bin + B.tmp), plist);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
+}  // namespace lsr

@@ -1,0 +1,89 @@
+// lsr_blend.h — per-(pixel, Gaussian) blending arithmetic shared by the forward and backward
+// compositing kernels, so both make bit-identical alpha / skip decisions (the backward rebuilds
+// the transmittance by dividing out exactly the alphas the forward multiplied in).
+//
+// Work decomposition (CDNA4, wave64): a 16x16 tile is four 8x8 quadrants.  One wave owns PXL of
+// them (1, 2 or 4) with lane l at position (l & 7, l >> 3) inside each owned quadrant, i.e. PXL
+// pixels per lane.  Waves never synchronise with each other: each stages 64 list entries at a
+// time into its own LDS slice and then walks only the entries whose exact alpha >= 1/255
+// footprint can reach one of its quadrants (per-entry 4-bit quadrant mask, wave-uniform
+// branches).  Skipping is lossless: a culled (entry, quadrant) would fail the alpha test at every
+// pixel of the quadrant.
+#pragma once
+#include "lsr_internal.h"
+
+namespace lsr {
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+// alpha_raw = opacity * exp(power), power = -0.5 (A dx^2 + C dy^2) - B dx dy, evaluated as
+// exp2(e) with e = a2 dx^2 + b2 dx dy + c2 dy^2 + log2(opacity), (a2,b2,c2) = log2(e)*(-A/2,-B,-C/2).
+__device__ __forceinline__ float blend_exponent(float dx, float dy, float a2, float b2, float c2, float l2o) {
+    float p1 = a2 * dx;
+    p1 = __builtin_fmaf(b2, dy, p1);
+    float p2 = c2 * dy;
+    p2 = __builtin_fmaf(p2, dy, l2o);
+    return __builtin_fmaf(p1, dx, p2);
+}
+__device__ __forceinline__ float fast_exp2(float e) { return __builtin_amdgcn_exp2f(e); }
+
+struct FoldedConic { float a2, b2, c2, l2o; };
+__device__ __forceinline__ FoldedConic fold_conic(float A, float B, float C, float o) {
+    FoldedConic f;
+    f.a2 = (-0.5f * kLog2e) * A;
+    f.b2 = (-kLog2e) * B;
+    f.c2 = (-0.5f * kLog2e) * C;
+    f.l2o = __log2f(o);
+    return f;
+}
+
+// Conservative 4-bit mask of the tile's 8x8 quadrants that the Gaussian can touch with
+// alpha >= 1/255: axis-aligned bounding box of { d : 1/2 d^T Q d <= ln(255 o) } (+ slack).
+// bit q <-> quadrant with origin (8*(q&1), 8*(q>>1)).
+__device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float A, float B, float C, float o,
+                                                  float tile_x0, float tile_y0) {
+    if (!(o >= LSR_ALPHA_MIN)) return 0u;  // alpha = min(.99, o*G) <= o < 1/255 everywhere (also NaN)
+    const float det = A * C - B * B;
+    // Fall back to "all quadrants" for non-positive-definite or badly conditioned conics, where
+    // the box computed from (A,B,C) would not be trustworthy.
+    if (!(det > 0.0f) || !(A * C < 1000.0f * det)) return 0xFu;
+    const float tau = __logf(255.0f * o) * 1.0001f + 1e-4f;
+    const float s = 2.0f * tau / det;
+    const float ex = __fsqrt_rn(s * C) * 1.001f + 0.05f;
+    const float ey = __fsqrt_rn(s * A) * 1.001f + 0.05f;
+    const float x0 = x - ex - tile_x0, x1 = x + ex - tile_x0;
+    const float y0 = y - ey - tile_y0, y1 = y + ey - tile_y0;
+    if (!(x0 == x0) || !(x1 == x1) || !(y0 == y0) || !(y1 == y1)) return 0xFu;
+    const bool xl = x0 <= 7.0f && x1 >= 0.0f;    // columns 0..7
+    const bool xr = x0 <= 15.0f && x1 >= 8.0f;   // columns 8..15
+    const bool yt = y0 <= 7.0f && y1 >= 0.0f;    // rows 0..7
+    const bool yb = y0 <= 15.0f && y1 >= 8.0f;   // rows 8..15
+    return (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) |
+           ((uint32_t)(xr && yb) << 3);
+}
+
+// Quadrants owned by wave `part` of a tile for a given pixels-per-lane setting.
+template <int PXL>
+__device__ __forceinline__ int owned_quadrant(int part, int k) {
+    return PXL == 4 ? k : (PXL == 2 ? 2 * part + k : part);
+}
+template <int PXL>
+__device__ __forceinline__ uint32_t owned_mask(int part) {
+    return PXL == 4 ? 0xFu : (PXL == 2 ? (0x3u << (2 * part)) : (1u << part));
+}
+
+// Wave-wide sum (wave64) with DPP; the total ends up in lanes 48..63.
+#define LSR_DPP_ADD(v, ctrl, rmask)                                                              \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, \
+                                                                rmask, 0xf, false))
+__device__ __forceinline__ float wave_sum_to_row3(float v) {
+    LSR_DPP_ADD(v, 0xB1, 0xf);   // quad_perm [1,0,3,2]
+    LSR_DPP_ADD(v, 0x4E, 0xf);   // quad_perm [2,3,0,1]
+    LSR_DPP_ADD(v, 0x141, 0xf);  // row_half_mirror
+    LSR_DPP_ADD(v, 0x140, 0xf);  // row_mirror
+    LSR_DPP_ADD(v, 0x142, 0xa);  // row_bcast:15 into rows 1,3
+    LSR_DPP_ADD(v, 0x143, 0xc);  // row_bcast:31 into rows 2,3
+    return v;
+}
+
+}  // namespace lsr

@@ -1,0 +1,98 @@
+// lsr_internal.h — shared device/host declarations of the lsr HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lsr_rasterizer.h"
+
+#define LSR_WAVE 64
+#define LSR_NEAR_CULL 0.2f
+#define LSR_LOWPASS 0.3f
+#define LSR_ALPHA_MAX 0.99f
+#define LSR_ALPHA_MIN (1.0f / 255.0f)
+#define LSR_T_EPS 0.0001f
+
+namespace lsr {
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct GeomLayout {
+    size_t header, q0, q1, rect, rgb, tile_count, tile_start, tile_cursor, total;
+};
+struct ImgLayout {
+    size_t final_T, n_contrib, total;
+};
+struct BinLayout {
+    size_t keys, point_list, tmp, total;
+};
+struct GradLayout {
+    size_t dxy, dconic, drgb, dz, total;  // float2, float4 (3 used), float4 (3 used), float
+};
+
+inline int tiles_x(const lsr_dims &d) { return (d.width + LSR_TILE - 1) / LSR_TILE; }
+inline int tiles_y(const lsr_dims &d) { return (d.height + LSR_TILE - 1) / LSR_TILE; }
+inline int64_t num_tiles(const lsr_dims &d) { return (int64_t)tiles_x(d) * tiles_y(d); }
+
+inline GeomLayout geom_layout(const lsr_dims &d) {
+    GeomLayout L;
+    const size_t VG = (size_t)d.num_views * (size_t)d.num_gaussians;
+    const size_t VT = (size_t)d.num_views * (size_t)num_tiles(d);
+    size_t o = 0;
+    L.header = o; o += 256;
+    L.q0 = o; o = align_up(o + VG * 16);
+    L.q1 = o; o = align_up(o + VG * 16);
+    L.rect = o; o = align_up(o + VG * 8);
+    L.rgb = o; o = align_up(o + (d.color_mode != LSR_COLOR_NONE ? VG * 16 : 0));
+    L.tile_count = o; o = align_up(o + VT * 4);
+    L.tile_cursor = o; o = align_up(o + VT * 4);   // adjacent to tile_count: one memset clears both
+    L.tile_start = o; o = align_up(o + (VT + 1) * 4);
+    L.total = o;
+    return L;
+}
+inline ImgLayout img_layout(const lsr_dims &d) {
+    ImgLayout L;
+    const size_t n = (size_t)d.num_views * d.height * d.width;
+    L.final_T = 0;
+    L.n_contrib = align_up(n * 4);
+    L.total = L.n_contrib + align_up(n * 4);
+    return L;
+}
+// Longest per-tile list the LDS sort handles; longer lists go through the global-memory path.
+constexpr int kSortLdsMax = 16384;
+inline BinLayout bin_layout(const lsr_dims &d, int64_t num_pairs, int32_t max_tile_pairs) {
+    BinLayout L;
+    const size_t P = (size_t)(num_pairs > 0 ? num_pairs : 1);
+    L.keys = 0;
+    L.point_list = align_up(P * 8);
+    L.tmp = L.point_list + align_up(P * 4);
+    L.total = L.tmp + (max_tile_pairs > kSortLdsMax ? align_up(P * 8) : 0);
+    return L;
+}
+inline GradLayout grad_layout(const lsr_dims &d) {
+    GradLayout L;
+    const size_t VG = (size_t)d.num_views * (size_t)d.num_gaussians;
+    size_t o = 0;
+    L.dxy = o; o = align_up(o + VG * 8);
+    L.dconic = o; o = align_up(o + VG * 16);
+    L.dz = o; o = align_up(o + VG * 4);
+    L.drgb = o; o = align_up(o + (d.color_mode == LSR_COLOR_SH ? VG * 16 : 0));
+    L.total = o;
+    return L;
+}
+
+// ---- stage launchers (defined one per .hip file) ----
+hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii,
+                             hipStream_t s);
+hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s);
+hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
+                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s);
+hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
+                                 const char *bin, char *img, const lsr_outputs &out, hipStream_t s);
+hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
+                                  const char *bin, const char *img, const lsr_out_grads &gout,
+                                  char *grad, const lsr_in_grads &gin, hipStream_t s);
+hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
+                                      const int32_t *radii, const char *grad,
+                                      const lsr_in_grads &gin, hipStream_t s);
+
+}  // namespace lsr

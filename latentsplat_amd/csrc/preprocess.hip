@@ -1,0 +1,186 @@
+// preprocess.hip — stage K1: per-(view, Gaussian) projection, EWA covariance, conic, radius,
+// tile rectangle, colour from SH, plus the per-tile pair histogram (LDS-privatised).
+//
+// Build this file with -ffp-contract=off: radius / rectangle / depth bits feed the bit-exact
+// tile lists, so every float operation must be the single IEEE operation written here (the CPU
+// oracle performs the identical sequence).  Spec: SURVEY.md Appendix A.1-A.3.
+#include "lsr_internal.h"
+#include "lsr_sh.h"
+
+namespace lsr {
+
+__device__ __forceinline__ float fmin_sel(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float fmax_sel(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin_sel(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax_sel(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ float ndc2pix(float v, int S) {
+    return (float)(((v + 1.0) * S - 1.0) * 0.5);
+}
+
+constexpr int kPreThreads = 256;
+constexpr int kPreItems = 8;  // Gaussians per thread => 2048 per block, one histogram flush each
+
+template <int COLOR_MODE, bool LDS_HIST>
+__global__ void __launch_bounds__(kPreThreads)
+k_preprocess(lsr_dims d, lsr_inputs in, float4 *__restrict__ q0, float4 *__restrict__ q1,
+             ushort4 *__restrict__ rect, float4 *__restrict__ rgb, int32_t *__restrict__ radii,
+             uint32_t *__restrict__ tile_count) {
+    extern __shared__ uint32_t s_hist[];
+    const int v = blockIdx.y;
+    const int G = d.num_gaussians;
+    const int gx = (d.width + LSR_TILE - 1) / LSR_TILE, gy = (d.height + LSR_TILE - 1) / LSR_TILE;
+    const int T = gx * gy;
+    if (LDS_HIST) {
+        for (int t = threadIdx.x; t < T; t += kPreThreads) s_hist[t] = 0;
+        __syncthreads();
+    }
+    const float *vw = in.views + (size_t)v * LSR_VIEW_FLOATS;
+    float vm[16], pm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { vm[k] = vw[k]; pm[k] = vw[16 + k]; }
+    const float camx = vw[32], camy = vw[33], camz = vw[34];
+    const float tanfovx = vw[35], tanfovy = vw[36];
+    const float focal_x = d.width / (2.0f * tanfovx);
+    const float focal_y = d.height / (2.0f * tanfovy);
+    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    const float *means = in.means3D + (size_t)v * d.vs_means;
+    const float *covs = in.cov3D + (size_t)v * d.vs_cov;
+    const float *opac = in.opacities + (size_t)v * d.vs_opac;
+    uint32_t *tc = tile_count + (size_t)v * T;
+
+    const int base = blockIdx.x * (kPreThreads * kPreItems);
+#pragma unroll 1
+    for (int it = 0; it < kPreItems; ++it) {
+        const int i = base + it * kPreThreads + threadIdx.x;
+        if (i >= G) break;
+        const size_t o = (size_t)v * G + i;
+        const float p0 = means[3 * (size_t)i], p1 = means[3 * (size_t)i + 1], p2 = means[3 * (size_t)i + 2];
+        int32_t out_radius = 0;
+        ushort4 out_rect = make_ushort4(0, 0, 0, 0);
+        do {
+            const float t0 = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
+            const float t1 = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
+            const float t2 = vm[2] * p0 + vm[6] * p1 + vm[10] * p2 + vm[14];
+            if (t2 <= LSR_NEAR_CULL) break;
+            const float h0 = pm[0] * p0 + pm[4] * p1 + pm[8] * p2 + pm[12];
+            const float h1 = pm[1] * p0 + pm[5] * p1 + pm[9] * p2 + pm[13];
+            const float h3 = pm[3] * p0 + pm[7] * p1 + pm[11] * p2 + pm[15];
+            const float p_w = 1.0f / (h3 + 0.0000001f);
+            const float ndc_x = h0 * p_w, ndc_y = h1 * p_w;
+
+            const float txtz = t0 / t2, tytz = t1 / t2;
+            const float tx = fmin_sel(limx, fmax_sel(-limx, txtz)) * t2;
+            const float ty = fmin_sel(limy, fmax_sel(-limy, tytz)) * t2;
+            const float tz = t2;
+            const float j00 = focal_x / tz, j02 = -(focal_x * tx) / (tz * tz);
+            const float j11 = focal_y / tz, j12 = -(focal_y * ty) / (tz * tz);
+            const float m00 = j00 * vm[0] + j02 * vm[2];
+            const float m01 = j00 * vm[4] + j02 * vm[6];
+            const float m02 = j00 * vm[8] + j02 * vm[10];
+            const float m10 = j11 * vm[1] + j12 * vm[2];
+            const float m11 = j11 * vm[5] + j12 * vm[6];
+            const float m12 = j11 * vm[9] + j12 * vm[10];
+            const float *c6 = covs + 6 * (size_t)i;
+            const float s0 = c6[0], s1 = c6[1], s2 = c6[2], s3 = c6[3], s4 = c6[4], s5 = c6[5];
+            const float v00 = s0 * m00 + s1 * m01 + s2 * m02;
+            const float v01 = s1 * m00 + s3 * m01 + s4 * m02;
+            const float v02 = s2 * m00 + s4 * m01 + s5 * m02;
+            const float v10 = s0 * m10 + s1 * m11 + s2 * m12;
+            const float v11 = s1 * m10 + s3 * m11 + s4 * m12;
+            const float v12 = s2 * m10 + s4 * m11 + s5 * m12;
+            const float ca = (m00 * v00 + m01 * v01 + m02 * v02) + LSR_LOWPASS;
+            const float cb = m00 * v10 + m01 * v11 + m02 * v12;
+            const float cc = (m10 * v10 + m11 * v11 + m12 * v12) + LSR_LOWPASS;
+            const float det = ca * cc - cb * cb;
+            if (det == 0.0f) break;
+            const float det_inv = 1.0f / det;
+            const float conic_a = cc * det_inv, conic_b = -cb * det_inv, conic_c = ca * det_inv;
+            const float mid = 0.5f * (ca + cc);
+            const float disc = sqrtf(fmax_sel(0.1f, mid * mid - det));
+            const float lambda1 = mid + disc, lambda2 = mid - disc;
+            const float my_radius = ceilf(3.0f * sqrtf(fmax_sel(lambda1, lambda2)));
+            const float px = ndc2pix(ndc_x, d.width), py = ndc2pix(ndc_y, d.height);
+            const int rminx = imin_sel(gx, imax_sel(0, (int)((px - my_radius) / LSR_TILE)));
+            const int rminy = imin_sel(gy, imax_sel(0, (int)((py - my_radius) / LSR_TILE)));
+            const int rmaxx = imin_sel(gx, imax_sel(0, (int)((px + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
+            const int rmaxy = imin_sel(gy, imax_sel(0, (int)((py + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
+            if ((rmaxx - rminx) * (rmaxy - rminy) == 0) break;
+
+            if (COLOR_MODE == LSR_COLOR_SH) {
+                float dx = p0 - camx, dy = p1 - camy, dz = p2 - camz;
+                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                dx = dx / len; dy = dy / len; dz = dz / len;
+                float b[25];
+                sh_basis(d.sh_degree, dx, dy, dz, b);
+                const int nb = (d.sh_degree + 1) * (d.sh_degree + 1);
+                const float *sh = in.color + (size_t)v * d.vs_color + (size_t)i * d.sh_coeffs * 3;
+                float r[3];
+                uint32_t clampbits = 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float acc = 0.0f;
+                    for (int k = 0; k < nb; ++k) acc += b[k] * sh[3 * k + c];
+                    acc += 0.5f;
+                    if (acc < 0.0f) clampbits |= 1u << c;
+                    r[c] = fmax_sel(acc, 0.0f);
+                }
+                rgb[o] = make_float4(r[0], r[1], r[2], __uint_as_float(clampbits));
+            } else if (COLOR_MODE == LSR_COLOR_PRECOMP) {
+                const float *cp = in.color + (size_t)v * d.vs_color + 3 * (size_t)i;
+                rgb[o] = make_float4(cp[0], cp[1], cp[2], 0.0f);
+            }
+            out_radius = (int32_t)my_radius;
+            out_rect = make_ushort4((unsigned short)rminx, (unsigned short)rminy,
+                                    (unsigned short)rmaxx, (unsigned short)rmaxy);
+            q0[o] = make_float4(px, py, conic_a, conic_b);
+            q1[o] = make_float4(conic_c, opac[i], tz, ca /* cov2D.xx, kept for diagnostics */);
+            for (int y = rminy; y < rmaxy; ++y)
+                for (int x = rminx; x < rmaxx; ++x) {
+                    if (LDS_HIST) atomicAdd(&s_hist[y * gx + x], 1u);
+                    else atomicAdd(&tc[y * gx + x], 1u);
+                }
+        } while (0);
+        radii[o] = out_radius;
+        rect[o] = out_rect;
+    }
+    if (LDS_HIST) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < T; t += kPreThreads) {
+            const uint32_t c = s_hist[t];
+            if (c) atomicAdd(&tc[t], c);
+        }
+    }
+}
+
+hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii,
+                             hipStream_t s) {
+    const GeomLayout L = geom_layout(d);
+    const int T = (int)num_tiles(d);
+    // zero header + tile_count + tile_cursor (adjacent)
+    hipError_t e = hipMemsetAsync(geom + L.header, 0, 256, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(geom + L.tile_count, 0, L.tile_start - L.tile_count, s);
+    if (e != hipSuccess) return e;
+    if (d.num_gaussians == 0) return hipSuccess;
+    dim3 grid((d.num_gaussians + kPreThreads * kPreItems - 1) / (kPreThreads * kPreItems), d.num_views);
+    float4 *q0 = (float4 *)(geom + L.q0), *q1 = (float4 *)(geom + L.q1);
+    ushort4 *rect = (ushort4 *)(geom + L.rect);
+    float4 *rgb = (float4 *)(geom + L.rgb);
+    uint32_t *tc = (uint32_t *)(geom + L.tile_count);
+    const bool lds = T <= 8192;
+    const size_t shm = lds ? (size_t)T * 4 : 0;
+#define LSR_PRE(CM)                                                                              \
+    do {                                                                                         \
+        if (lds) hipLaunchKernelGGL((k_preprocess<CM, true>), grid, dim3(kPreThreads), shm, s,   \
+                                    d, in, q0, q1, rect, rgb, radii, tc);                        \
+        else hipLaunchKernelGGL((k_preprocess<CM, false>), grid, dim3(kPreThreads), 0, s, d, in, \
+                                q0, q1, rect, rgb, radii, tc);                                   \
+    } while (0)
+    if (d.color_mode == LSR_COLOR_SH) LSR_PRE(LSR_COLOR_SH);
+    else if (d.color_mode == LSR_COLOR_PRECOMP) LSR_PRE(LSR_COLOR_PRECOMP);
+    else LSR_PRE(LSR_COLOR_NONE);
+#undef LSR_PRE
+    return hipGetLastError();
+}
+
+}  // namespace lsr

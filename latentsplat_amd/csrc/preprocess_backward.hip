@@ -1,0 +1,212 @@
+// preprocess_backward.hip — stages K8+K9 fused: per Gaussian, push the screen-space gradients
+// collected by the compositing backward through
+//   conic -> 2D covariance -> 3D covariance (6 packed values) and -> view-space mean (via J),
+//   NDC mean -> world mean (perspective divide),  rgb -> SH coefficients and view direction,
+//   view z -> world mean (depth output).
+// One thread owns one Gaussian for ALL views, so inputs shared between views (stride 0) get their
+// gradients summed in registers / thread-private read-modify-write, without atomics.
+// Spec: SURVEY.md Appendix A.6.
+#include "lsr_internal.h"
+#include "lsr_sh.h"
+
+namespace lsr {
+
+struct PreBwdParams {
+    lsr_dims d;
+    lsr_inputs in;
+    const int32_t *radii;
+    const float4 *rgb;      // .w = clamp bits (SH mode)
+    const float2 *dxy;      // pixel-space
+    const float4 *dconic;
+    const float *dz;
+    const float4 *drgb;
+    lsr_in_grads g;
+};
+
+__global__ void __launch_bounds__(256)
+k_preprocess_bwd(PreBwdParams p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const lsr_dims &d = p.d;
+    const int G = d.num_gaussians;
+    if (i >= G) return;
+    const int V = d.num_views;
+    const bool sh_mode = d.color_mode == LSR_COLOR_SH;
+    const int nb = (d.sh_degree + 1) * (d.sh_degree + 1);
+    float am[3] = {0, 0, 0}, ac[6] = {0, 0, 0, 0, 0, 0};  // accumulators for shared inputs
+    for (int v = 0; v < V; ++v) {
+        const size_t o = (size_t)v * G + i;
+        float gm[3] = {0, 0, 0}, gc[6] = {0, 0, 0, 0, 0, 0};
+        float m2x = 0.0f, m2y = 0.0f;
+        const bool vis = p.radii[o] > 0;
+        float *gsh = sh_mode ? p.g.color + (size_t)v * d.vs_color + (size_t)i * d.sh_coeffs * 3 : nullptr;
+        const bool sh_first = sh_mode && (d.vs_color != 0 || v == 0);
+        if (vis) {
+            const float *vw = p.in.views + (size_t)v * LSR_VIEW_FLOATS;
+            const float *vm = vw, *pm = vw + 16;
+            const float tanfovx = vw[35], tanfovy = vw[36];
+            const float focal_x = d.width / (2.0f * tanfovx), focal_y = d.height / (2.0f * tanfovy);
+            const float *mp = p.in.means3D + (size_t)v * d.vs_means + 3 * (size_t)i;
+            const float p0 = mp[0], p1 = mp[1], p2 = mp[2];
+            // ---- covariance path ----
+            const float t0 = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
+            const float t1 = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
+            const float tz = vm[2] * p0 + vm[6] * p1 + vm[10] * p2 + vm[14];
+            const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+            const float txtz = t0 / tz, tytz = t1 / tz;
+            const float xm = (txtz < -limx || txtz > limx) ? 0.0f : 1.0f;
+            const float ym = (tytz < -limy || tytz > limy) ? 0.0f : 1.0f;
+            const float tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+            const float ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+            const float itz = 1.0f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+            const float j00 = focal_x * itz, j02 = -(focal_x * tx) * itz2;
+            const float j11 = focal_y * itz, j12 = -(focal_y * ty) * itz2;
+            // Wr[r][c] = vm[4c + r]; M = J * Wr (2x3)
+            float M[2][3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                M[0][c] = j00 * vm[4 * c + 0] + j02 * vm[4 * c + 2];
+                M[1][c] = j11 * vm[4 * c + 1] + j12 * vm[4 * c + 2];
+            }
+            const float *c6 = p.in.cov3D + (size_t)v * d.vs_cov + 6 * (size_t)i;
+            const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+            float MS[2][3];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) MS[r][c] = M[r][0] * S[0][c] + M[r][1] * S[1][c] + M[r][2] * S[2][c];
+            const float a = MS[0][0] * M[0][0] + MS[0][1] * M[0][1] + MS[0][2] * M[0][2] + LSR_LOWPASS;
+            const float b = MS[0][0] * M[1][0] + MS[0][1] * M[1][1] + MS[0][2] * M[1][2];
+            const float c = MS[1][0] * M[1][0] + MS[1][1] * M[1][1] + MS[1][2] * M[1][2] + LSR_LOWPASS;
+            const float det = a * c - b * b;
+            const float4 gcon = p.dconic[o];
+            float dL_da = 0.0f, dL_db = 0.0f, dL_dc = 0.0f;
+            if (det != 0.0f) {
+                const float d2 = 1.0f / (det * det);
+                // conic = (c, -b, a) / det
+                dL_da = d2 * (gcon.x * (-c * c) + gcon.y * (b * c) + gcon.z * (det - a * c));
+                dL_dc = d2 * (gcon.x * (det - a * c) + gcon.y * (a * b) + gcon.z * (-a * a));
+                dL_db = d2 * (gcon.x * (2.0f * b * c) - gcon.y * (det + 2.0f * b * b) + gcon.z * (2.0f * a * b));
+            }
+            // packed Sigma gradient: diagonal once, off-diagonals twice (stored once)
+            gc[0] = dL_da * M[0][0] * M[0][0] + dL_db * M[0][0] * M[1][0] + dL_dc * M[1][0] * M[1][0];
+            gc[3] = dL_da * M[0][1] * M[0][1] + dL_db * M[0][1] * M[1][1] + dL_dc * M[1][1] * M[1][1];
+            gc[5] = dL_da * M[0][2] * M[0][2] + dL_db * M[0][2] * M[1][2] + dL_dc * M[1][2] * M[1][2];
+            gc[1] = 2.0f * dL_da * M[0][0] * M[0][1] + dL_db * (M[0][0] * M[1][1] + M[0][1] * M[1][0]) + 2.0f * dL_dc * M[1][0] * M[1][1];
+            gc[2] = 2.0f * dL_da * M[0][0] * M[0][2] + dL_db * (M[0][0] * M[1][2] + M[0][2] * M[1][0]) + 2.0f * dL_dc * M[1][0] * M[1][2];
+            gc[4] = 2.0f * dL_da * M[0][1] * M[0][2] + dL_db * (M[0][1] * M[1][2] + M[0][2] * M[1][1]) + 2.0f * dL_dc * M[1][1] * M[1][2];
+            // dL/dM, then dL/dJ = dM * Wr^T
+            float dM[2][3];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                dM[0][cc] = 2.0f * MS[0][cc] * dL_da + MS[1][cc] * dL_db;
+                dM[1][cc] = 2.0f * MS[1][cc] * dL_dc + MS[0][cc] * dL_db;
+            }
+            // Wr[k][cc] = vm[4cc + k]
+            const float dJ00 = dM[0][0] * vm[0] + dM[0][1] * vm[4] + dM[0][2] * vm[8];
+            const float dJ02 = dM[0][0] * vm[2] + dM[0][1] * vm[6] + dM[0][2] * vm[10];
+            const float dJ11 = dM[1][0] * vm[1] + dM[1][1] * vm[5] + dM[1][2] * vm[9];
+            const float dJ12 = dM[1][0] * vm[2] + dM[1][1] * vm[6] + dM[1][2] * vm[10];
+            const float dL_dtx = xm * (-focal_x * itz2) * dJ02;
+            const float dL_dty = ym * (-focal_y * itz2) * dJ12;
+            float dL_dtz = -focal_x * itz2 * dJ00 - focal_y * itz2 * dJ11 +
+                           (2.0f * focal_x * tx) * itz3 * dJ02 + (2.0f * focal_y * ty) * itz3 * dJ12;
+            dL_dtz += p.dz[o];
+            // t = Wr p + trans  =>  dL/dp[cc] = sum_k Wr[k][cc] dt[k] = vm[4cc + k] dt[k]
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+                gm[cc] = vm[4 * cc + 0] * dL_dtx + vm[4 * cc + 1] * dL_dty + vm[4 * cc + 2] * dL_dtz;
+            // ---- NDC mean path ----
+            const float h0 = pm[0] * p0 + pm[4] * p1 + pm[8] * p2 + pm[12];
+            const float h1 = pm[1] * p0 + pm[5] * p1 + pm[9] * p2 + pm[13];
+            const float h3 = pm[3] * p0 + pm[7] * p1 + pm[11] * p2 + pm[15];
+            const float m_w = 1.0f / (h3 + 0.0000001f);
+            const float mul1 = h0 * m_w * m_w, mul2 = h1 * m_w * m_w;
+            const float2 gp = p.dxy[o];
+            m2x = gp.x * (0.5f * d.width);   // d pixel / d ndc
+            m2y = gp.y * (0.5f * d.height);
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+                gm[cc] += (pm[4 * cc + 0] * m_w - pm[4 * cc + 3] * mul1) * m2x +
+                          (pm[4 * cc + 1] * m_w - pm[4 * cc + 3] * mul2) * m2y;
+            // ---- colour path (SH) ----
+            if (sh_mode) {
+                const float dxr = p0 - vw[32], dyr = p1 - vw[33], dzr = p2 - vw[34];
+                const float len = sqrtf(dxr * dxr + dyr * dyr + dzr * dzr);
+                const float ilen = 1.0f / len;
+                const float x = dxr * ilen, y = dyr * ilen, z = dzr * ilen;
+                float bas[25];
+                float dbas[25][3];
+                sh_basis(d.sh_degree, x, y, z, bas);
+                sh_basis_grad(d.sh_degree, x, y, z, dbas);
+                const float *sh = p.in.color + (size_t)v * d.vs_color + (size_t)i * d.sh_coeffs * 3;
+                const float4 col = p.rgb[o];
+                const uint32_t clampbits = __float_as_uint(col.w);
+                const float4 gr = p.drgb[o];
+                const float gcol[3] = {(clampbits & 1u) ? 0.0f : gr.x, (clampbits & 2u) ? 0.0f : gr.y,
+                                       (clampbits & 4u) ? 0.0f : gr.z};
+                float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
+                for (int k = 0; k < nb; ++k) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float gval = bas[k] * gcol[ch];
+                        float *dst = gsh + 3 * k + ch;
+                        *dst = sh_first ? gval : *dst + gval;
+                        const float sg = sh[3 * k + ch] * gcol[ch];
+                        ddx += dbas[k][0] * sg; ddy += dbas[k][1] * sg; ddz += dbas[k][2] * sg;
+                    }
+                }
+                if (sh_first)
+                    for (int k = nb * 3; k < d.sh_coeffs * 3; ++k) gsh[k] = 0.0f;
+                const float dot = ddx * x + ddy * y + ddz * z;
+                gm[0] += (ddx - x * dot) * ilen;
+                gm[1] += (ddy - y * dot) * ilen;
+                gm[2] += (ddz - z * dot) * ilen;
+            }
+        } else if (sh_first) {
+            for (int k = 0; k < d.sh_coeffs * 3; ++k) gsh[k] = 0.0f;
+        }
+        if (d.vs_means != 0) {
+            float *o3 = p.g.means3D + (size_t)v * d.vs_means + 3 * (size_t)i;
+            o3[0] = gm[0]; o3[1] = gm[1]; o3[2] = gm[2];
+        } else { am[0] += gm[0]; am[1] += gm[1]; am[2] += gm[2]; }
+        if (d.vs_cov != 0) {
+            float *o6 = p.g.cov3D + (size_t)v * d.vs_cov + 6 * (size_t)i;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o6[k] = gc[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ac[k] += gc[k];
+        }
+        if (p.g.means2D) {
+            float *o2 = p.g.means2D + 3 * o;
+            o2[0] = m2x; o2[1] = m2y; o2[2] = 0.0f;
+        }
+    }
+    if (d.vs_means == 0) {
+        float *o3 = p.g.means3D + 3 * (size_t)i;
+        o3[0] = am[0]; o3[1] = am[1]; o3[2] = am[2];
+    }
+    if (d.vs_cov == 0) {
+        float *o6 = p.g.cov3D + 6 * (size_t)i;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o6[k] = ac[k];
+    }
+}
+
+hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
+                                      const int32_t *radii, const char *grad,
+                                      const lsr_in_grads &gin, hipStream_t s) {
+    if (d.num_gaussians == 0) return hipSuccess;
+    const GeomLayout L = geom_layout(d);
+    const GradLayout R = grad_layout(d);
+    PreBwdParams p;
+    p.d = d; p.in = in; p.radii = radii;
+    p.rgb = (const float4 *)(geom + L.rgb);
+    p.dxy = (const float2 *)(grad + R.dxy); p.dconic = (const float4 *)(grad + R.dconic);
+    p.dz = (const float *)(grad + R.dz); p.drgb = (const float4 *)(grad + R.drgb);
+    p.g = gin;
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3((d.num_gaussians + 255) / 256), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace lsr

@@ -1,0 +1,277 @@
+// render_backward.hip — stage K7: per-pixel back-to-front gradient of the compositing, with the
+// same wave/quadrant decomposition and culling as the forward (lsr_blend.h).
+//
+// Per (entry, pixel): recompute alpha with the forward's exact arithmetic, divide it out of the
+// running transmittance, form dL/dalpha from the colour accumulated behind the entry, and emit
+//   dL/d(x,y)_pixel, dL/d(A,B,C) conic, dL/d opacity, dL/d payload (rgb / features), dL/d z.
+// Per (entry, wave): contributions of the wave's 64*PXL pixels are summed with a DPP butterfly
+// (no LDS traffic) and ONE lane issues the float atomics for the (tile, Gaussian) pair.
+// Spec: SURVEY.md Appendix A.6.
+#include "lsr_blend.h"
+
+namespace lsr {
+
+struct RenderBwdParams {
+    int H, W, gx, T, G, C, has_color, color_direct;  // color_direct: rgb grads go straight to gin.color
+    int64_t vs_feat, vs_opac, vs_color;
+    const float *views;
+    const float4 *q0, *q1, *rgb;
+    const float *features;
+    const uint32_t *tile_start, *point_list;
+    const float *final_T;
+    const uint32_t *n_contrib;
+    const float *g_color, *g_feat, *g_mask, *g_depth;  // dL/d outputs (any may be NULL)
+    float2 *dxy;        // [V*G] pixel-space gradient of the projected mean
+    float4 *dconic;     // [V*G] (A, B, C, -)
+    float *dz;          // [V*G]
+    float4 *drgb;       // [V*G] (SH mode)
+    float *d_opac;      // gin.opacities
+    float *d_feat;      // gin.features
+    float *d_color;     // gin.color (PRECOMP mode)
+};
+
+__device__ __forceinline__ void atomic_add_f32(float *addr, float v) { unsafeAtomicAdd(addr, v); }
+
+template <int NCHP, int PXL, bool DEPTH_GRAD>
+__global__ void __launch_bounds__(LSR_WAVE)
+k_render_bwd(RenderBwdParams p) {
+    constexpr int NW = 4 / PXL;
+    __shared__ float4 s_q0[LSR_WAVE];  // x, y, A, B
+    __shared__ float4 s_q1[LSR_WAVE];  // C, o, z, mask bits
+    __shared__ float4 s_q2[LSR_WAVE];  // a2, b2, c2, log2(o)
+    __shared__ float4 s_pay[LSR_WAVE][NCHP / 4];
+    __shared__ uint32_t s_gid[LSR_WAVE];
+
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x / NW, part = blockIdx.x % NW;
+    const int v = blockIdx.y;
+    const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE;
+    const size_t vG = (size_t)v * p.G;
+    const uint32_t start = p.tile_start[(size_t)v * p.T + tile];
+    const uint32_t own = owned_mask<PXL>(part);
+    const int coff = p.has_color ? 3 : 0;
+    const float *vw = p.views + (size_t)v * LSR_VIEW_FLOATS;
+    const size_t HW = (size_t)p.H * p.W;
+
+    float pxf[PXL], pyf[PXL], Tr[PXL], Tfin[PXL], bgdot[PXL], ddep[PXL], accd[PXL];
+    float dpix[PXL][NCHP], accum[PXL][NCHP];
+    uint32_t last[PXL];
+    uint32_t maxlast = 0;
+#pragma unroll
+    for (int k = 0; k < PXL; ++k) {
+        const int q = owned_quadrant<PXL>(part, k);
+        const int px = tx0 + 8 * (q & 1) + (lane & 7), py = ty0 + 8 * (q >> 1) + (lane >> 3);
+        pxf[k] = (float)px; pyf[k] = (float)py;
+        const bool inside = px < p.W && py < p.H;
+        const size_t pix = (size_t)py * p.W + px, vp = (size_t)v * HW + pix;
+        Tfin[k] = inside ? p.final_T[vp] : 1.0f;
+        Tr[k] = Tfin[k];
+        last[k] = inside ? p.n_contrib[vp] : 0u;
+        maxlast = max(maxlast, last[k]);
+        float bd = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCHP; ++c) { dpix[k][c] = 0.0f; accum[k][c] = 0.0f; }
+        if (inside) {
+            if (p.has_color && p.g_color) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    dpix[k][c] = p.g_color[((size_t)v * 3 + c) * HW + pix];
+                    bd = __builtin_fmaf(vw[37 + c], dpix[k][c], bd);
+                }
+            }
+            if (p.g_feat) {
+#pragma unroll
+                for (int c = 0; c < NCHP; ++c)
+                    if (c >= coff && c - coff < p.C) dpix[k][c] = p.g_feat[((size_t)v * p.C + (c - coff)) * HW + pix];
+            }
+            if (p.g_mask) bd -= p.g_mask[vp];  // mask = 1 - T_final
+        }
+        bgdot[k] = bd;
+        ddep[k] = (DEPTH_GRAD && inside) ? p.g_depth[vp] : 0.0f;
+        accd[k] = 0.0f;
+    }
+    // wave-uniform upper bound of the entries any owned pixel blended
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxlast = max(maxlast, (uint32_t)__shfl_xor((int)maxlast, off));
+    maxlast = __builtin_amdgcn_readfirstlane(maxlast);
+    if (maxlast == 0) return;
+
+    const float half_w = 0.5f * p.W, half_h = 0.5f * p.H;
+    (void)half_w; (void)half_h;
+    for (int chunk = (int)((maxlast - 1) / LSR_WAVE); chunk >= 0; --chunk) {
+        const uint32_t rel = (uint32_t)chunk * LSR_WAVE + lane;  // 0-based position in the list
+        uint32_t m = 0;
+        if (rel < maxlast) {
+            const uint32_t g = p.point_list[start + rel];
+            const float4 a = p.q0[vG + g], b = p.q1[vG + g];
+            m = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own;
+            if (m) {
+                const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
+                s_q0[lane] = a;
+                s_q1[lane] = make_float4(b.x, b.y, b.z, __uint_as_float(m));
+                s_q2[lane] = make_float4(f.a2, f.b2, f.c2, f.l2o);
+                s_gid[lane] = g;
+                float pay[NCHP];
+#pragma unroll
+                for (int c = 0; c < NCHP; ++c) pay[c] = 0.0f;
+                if (p.has_color) {
+                    const float4 col = p.rgb[vG + g];
+                    pay[0] = col.x; pay[1] = col.y; pay[2] = col.z;
+                }
+                const float *fp = p.features + (size_t)v * p.vs_feat + (size_t)g * p.C;
+#pragma unroll
+                for (int c = 0; c < NCHP; ++c)
+                    if (c >= coff && c - coff < p.C) pay[c] = fp[c - coff];
+#pragma unroll
+                for (int c4 = 0; c4 < NCHP / 4; ++c4)
+                    s_pay[lane][c4] = make_float4(pay[4 * c4], pay[4 * c4 + 1], pay[4 * c4 + 2], pay[4 * c4 + 3]);
+            }
+        }
+        uint64_t todo = __ballot(m != 0);
+        __syncthreads();
+
+        while (todo) {
+            const int j = 63 - __builtin_clzll(todo);  // back to front
+            todo &= ~(1ull << j);
+            const float4 a = s_q0[j], b = s_q1[j], f2 = s_q2[j];
+            const uint32_t mj = __builtin_amdgcn_readfirstlane(__float_as_uint(b.w));
+            const uint32_t pos = (uint32_t)chunk * LSR_WAVE + (uint32_t)j + 1u;
+            float pay[NCHP];
+#pragma unroll
+            for (int c4 = 0; c4 < NCHP / 4; ++c4) {
+                const float4 t = s_pay[j][c4];
+                pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
+            }
+            const float inv_o = __builtin_amdgcn_rcpf(b.y);
+            float gx = 0.0f, gy = 0.0f, gA = 0.0f, gB = 0.0f, gC = 0.0f, go = 0.0f, gz = 0.0f;
+            float gpay[NCHP];
+#pragma unroll
+            for (int c = 0; c < NCHP; ++c) gpay[c] = 0.0f;
+            bool any_valid = false;
+#pragma unroll
+            for (int k = 0; k < PXL; ++k) {
+                if (!(mj & (1u << owned_quadrant<PXL>(part, k)))) continue;  // wave-uniform
+                const float dx = a.x - pxf[k], dy = a.y - pyf[k];
+                const float ex = blend_exponent(dx, dy, f2.x, f2.y, f2.z, f2.w);
+                const float araw = fast_exp2(ex);
+                const float alpha = fminf(LSR_ALPHA_MAX, araw);
+                const bool valid = (pos <= last[k]) && (ex <= f2.w) && (alpha >= LSR_ALPHA_MIN);
+                if (!valid) continue;
+                any_valid = true;
+                const float one_m = 1.0f - alpha;
+                const float rcp1m = __builtin_amdgcn_rcpf(one_m);
+                const float Tk = Tr[k] * rcp1m;  // transmittance in front of this entry
+                Tr[k] = Tk;
+                const float w = alpha * Tk;
+                float dL_dalpha = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NCHP; ++c) {
+                    const float diff = pay[c] - accum[k][c];
+                    dL_dalpha = __builtin_fmaf(diff, dpix[k][c], dL_dalpha);
+                    accum[k][c] = __builtin_fmaf(alpha, diff, accum[k][c]);
+                    gpay[c] = __builtin_fmaf(w, dpix[k][c], gpay[c]);
+                }
+                if (DEPTH_GRAD) {
+                    const float diff = b.z - accd[k];
+                    dL_dalpha = __builtin_fmaf(diff, ddep[k], dL_dalpha);
+                    accd[k] = __builtin_fmaf(alpha, diff, accd[k]);
+                    gz = __builtin_fmaf(w, ddep[k], gz);
+                }
+                dL_dalpha *= Tk;
+                dL_dalpha = __builtin_fmaf(-Tfin[k] * rcp1m, bgdot[k], dL_dalpha);
+                const float Gv = araw * inv_o;          // exp(power)
+                const float dL_dG = b.y * dL_dalpha;    // straight through the 0.99 clamp (A.6)
+                const float gdx = Gv * dx, gdy = Gv * dy;
+                const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                const float dG_ddely = -gdy * b.x - gdx * a.w;
+                gx = __builtin_fmaf(dL_dG, dG_ddelx, gx);
+                gy = __builtin_fmaf(dL_dG, dG_ddely, gy);
+                gA = __builtin_fmaf(-0.5f * gdx * dx, dL_dG, gA);
+                gB = __builtin_fmaf(-gdx * dy, dL_dG, gB);
+                gC = __builtin_fmaf(-0.5f * gdy * dy, dL_dG, gC);
+                go = __builtin_fmaf(Gv, dL_dalpha, go);
+            }
+            if (!__any(any_valid)) continue;
+            gx = wave_sum_to_row3(gx); gy = wave_sum_to_row3(gy);
+            gA = wave_sum_to_row3(gA); gB = wave_sum_to_row3(gB); gC = wave_sum_to_row3(gC);
+            go = wave_sum_to_row3(go);
+            if (DEPTH_GRAD) gz = wave_sum_to_row3(gz);
+#pragma unroll
+            for (int c = 0; c < NCHP; ++c)
+                if (c < coff + p.C) gpay[c] = wave_sum_to_row3(gpay[c]);
+            if (lane == 63) {
+                const uint32_t g = s_gid[j];
+                float *dxy = (float *)&p.dxy[vG + g];
+                atomic_add_f32(dxy, gx); atomic_add_f32(dxy + 1, gy);
+                float *dcn = (float *)&p.dconic[vG + g];
+                atomic_add_f32(dcn, gA); atomic_add_f32(dcn + 1, gB); atomic_add_f32(dcn + 2, gC);
+                atomic_add_f32(p.d_opac + (size_t)v * p.vs_opac + g, go);
+                if (DEPTH_GRAD) atomic_add_f32(p.dz + vG + g, gz);
+                if (p.has_color) {
+                    float *dc = p.color_direct ? p.d_color + (size_t)v * p.vs_color + 3 * (size_t)g
+                                               : (float *)&p.drgb[vG + g];
+                    atomic_add_f32(dc, gpay[0]); atomic_add_f32(dc + 1, gpay[1]); atomic_add_f32(dc + 2, gpay[2]);
+                }
+                float *df = p.d_feat + (size_t)v * p.vs_feat + (size_t)g * p.C;
+#pragma unroll
+                for (int c = 0; c < NCHP; ++c)
+                    if (c >= coff && c - coff < p.C) atomic_add_f32(df + (c - coff), gpay[c]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int pick_pxl_bwd(int nchp, int64_t tiles_total) {
+    if (const char *e = getenv("LSR_PXL_BWD")) {
+        const int x = atoi(e);
+        if (x == 1 || x == 2 || x == 4) return nchp > 12 ? 1 : ((nchp > 4 && x == 4) ? 2 : x);
+    }
+    int pxl = tiles_total >= 2048 ? 4 : (tiles_total >= 1024 ? 2 : 1);
+    if (nchp > 4 && pxl == 4) pxl = 2;  // dpix + accum double the per-pixel register cost
+    if (nchp > 12) pxl = 1;
+    return pxl;
+}
+
+hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
+                                  const char *bin, const char *img, const lsr_out_grads &gout,
+                                  char *grad, const lsr_in_grads &gin, hipStream_t s) {
+    const GeomLayout L = geom_layout(d);
+    const ImgLayout I = img_layout(d);
+    const BinLayout B = bin_layout(d, 1, 0);
+    const GradLayout R = grad_layout(d);
+    RenderBwdParams p;
+    p.H = d.height; p.W = d.width; p.gx = tiles_x(d); p.T = (int)num_tiles(d); p.G = d.num_gaussians;
+    p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE;
+    p.color_direct = d.color_mode == LSR_COLOR_PRECOMP;
+    p.vs_feat = d.vs_feat; p.vs_opac = d.vs_opac; p.vs_color = d.vs_color;
+    p.views = in.views;
+    p.q0 = (const float4 *)(geom + L.q0); p.q1 = (const float4 *)(geom + L.q1);
+    p.rgb = (const float4 *)(geom + L.rgb);
+    p.features = in.features;
+    p.tile_start = (const uint32_t *)(geom + L.tile_start);
+    p.point_list = (const uint32_t *)(bin + B.point_list);
+    p.final_T = (const float *)(img + I.final_T); p.n_contrib = (const uint32_t *)(img + I.n_contrib);
+    p.g_color = gout.color; p.g_feat = gout.feature; p.g_mask = gout.mask; p.g_depth = gout.depth;
+    p.dxy = (float2 *)(grad + R.dxy); p.dconic = (float4 *)(grad + R.dconic);
+    p.dz = (float *)(grad + R.dz); p.drgb = (float4 *)(grad + R.drgb);
+    p.d_opac = gin.opacities; p.d_feat = gin.features; p.d_color = gin.color;
+    const int nch = (p.has_color ? 3 : 0) + d.feat_channels;
+    const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));
+    const int pxl = pick_pxl_bwd(nchp, (int64_t)p.T * d.num_views);
+    const bool dg = gout.depth != nullptr;
+    dim3 grid(p.T * (4 / pxl), d.num_views);
+#define LSR_RB(N, X)                                                                              \
+    do {                                                                                          \
+        if (dg) hipLaunchKernelGGL((k_render_bwd<N, X, true>), grid, dim3(LSR_WAVE), 0, s, p);    \
+        else hipLaunchKernelGGL((k_render_bwd<N, X, false>), grid, dim3(LSR_WAVE), 0, s, p);      \
+    } while (0)
+    if (nchp == 4) { if (pxl == 4) LSR_RB(4, 4); else if (pxl == 2) LSR_RB(4, 2); else LSR_RB(4, 1); }
+    else if (nchp == 8) { if (pxl == 2) LSR_RB(8, 2); else LSR_RB(8, 1); }
+    else if (nchp == 12) { if (pxl == 2) LSR_RB(12, 2); else LSR_RB(12, 1); }
+    else LSR_RB(36, 1);
+#undef LSR_RB
+    return hipGetLastError();
+}
+
+}  // namespace lsr

@@ -1,0 +1,260 @@
+"""Host side of the rasterizer: the drop-in ``GaussianRasterizationSettings`` /
+``GaussianRasterizer`` API of the reference's external dependency plus a multi-view batched
+autograd op, both running on the hand-written HIP library (``liblsr_hip.so``).
+
+Reference boundary (paths relative to /root/reference):
+  * constructed with 12 keyword fields at src/model/decoder/cuda_splatting.py:132-145;
+  * called as ``rasterizer(means3D=, means2D=, shs=, colors_precomp=, features=, opacities=,
+    cov3D_precomp=)`` and unpacked as ``image, feature_map, mask, depth_map, _`` at :150-158;
+  * matrices are row-major tensors holding the transposed matrices (:116-118).
+
+No CPU fallback exists here on purpose: inputs must live on a ROCm device and the extension must
+be loadable, otherwise a ``RuntimeError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+from ._lib import Dims, InGrads, Inputs, LsrError, OutGrads, Outputs
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: Tensor
+    scale_modifier: float
+    viewmatrix: Tensor
+    projmatrix: Tensor
+    sh_degree: int
+    campos: Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def make_view_table(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx, tanfovy,
+                    bg: Tensor) -> Tensor:
+    """(V,40) device table: viewmatrix(16) projmatrix(16) campos(3) tanfovx tanfovy bg(3).
+    All arguments batched over V; tanfov may be python floats or tensors (no host sync)."""
+    V = viewmatrix.shape[0]
+    dev, dt = viewmatrix.device, torch.float32
+
+    def col(t):
+        if not torch.is_tensor(t):
+            t = torch.full((V,), float(t), dtype=dt, device=dev)
+        return t.to(device=dev, dtype=dt).reshape(-1, 1).expand(V, 1)
+
+    return torch.cat([viewmatrix.reshape(V, 16).to(dt), projmatrix.reshape(V, 16).to(dt),
+                      campos.reshape(V, 3).to(dt), col(tanfovx), col(tanfovy),
+                      bg.reshape(-1, 3).to(dt).expand(V, 3)], dim=1).contiguous()
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _prep(t: Optional[Tensor], name: str, dev) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.device != dev:
+        raise LsrError(f"{name} is on {t.device}, expected {dev}")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stride(t: Optional[Tensor], base_dims: int, V: int, name: str) -> int:
+    """0 for a tensor shared by all views (G,...), elements-per-view for a (V,G,...) tensor."""
+    if t is None or t.dim() == base_dims:
+        return 0
+    if t.dim() != base_dims + 1 or t.shape[0] != V:
+        raise LsrError(f"{name}: expected {base_dims} dims (shared) or a leading view dim of {V}, got {tuple(t.shape)}")
+    return t[0].numel()
+
+
+class _Plan:
+    """Everything one forward call hands to the matching backward."""
+    __slots__ = ("dims", "geom", "bin", "img", "num_pairs", "radii", "V", "G", "H", "W", "C",
+                 "color_mode", "K")
+
+
+class _RasterizeViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, views, means3D, means2D, cov3D, opacities, shs, colors_precomp, features,
+                H: int, W: int, sh_degree: int, debug: bool):
+        lib = _lib.load()
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise LsrError("latentsplat_amd rasterizer runs on MI355X only: tensors must be on a "
+                           "ROCm ('cuda') device; there is no CPU fallback")
+        if shs is not None and colors_precomp is not None:
+            raise LsrError("provide at most one of shs / colors_precomp")
+        if shs is None and colors_precomp is None and features is None:
+            raise LsrError("nothing to render: shs, colors_precomp and features are all None")
+        views = _prep(views, "views", dev)
+        V = views.shape[0]
+        means3D = _prep(means3D, "means3D", dev)
+        cov3D = _prep(cov3D, "cov3D_precomp", dev)
+        opacities = _prep(opacities, "opacities", dev)
+        shs = _prep(shs, "shs", dev)
+        colors_precomp = _prep(colors_precomp, "colors_precomp", dev)
+        features = _prep(features, "features", dev)
+        G = means3D.shape[-2]
+        color = shs if shs is not None else colors_precomp
+        color_mode = _lib.COLOR_SH if shs is not None else (
+            _lib.COLOR_PRECOMP if colors_precomp is not None else _lib.COLOR_NONE)
+        Cf = 0 if features is None else features.shape[-1]
+        if Cf > _lib.MAX_FEAT_CHANNELS:
+            raise LsrError(f"features has {Cf} channels; at most {_lib.MAX_FEAT_CHANNELS} are supported")
+        K = shs.shape[-2] if shs is not None else 0
+        d = Dims(V, G, H, W, Cf, color_mode, int(sh_degree), K,
+                 _stride(means3D, 2, V, "means3D"), _stride(cov3D, 2, V, "cov3D_precomp"),
+                 _stride(opacities, 2, V, "opacities"),
+                 _stride(color, 3 if shs is not None else 2, V, "shs/colors_precomp"),
+                 _stride(features, 2, V, "features"))
+        inp = Inputs(_ptr(views), _ptr(means3D), _ptr(cov3D), _ptr(opacities), _ptr(color), _ptr(features))
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        geom_bytes = lib.lsr_geom_workspace_bytes(C.byref(d))
+        if geom_bytes == 0:
+            raise LsrError("invalid rasterizer dimensions / argument shapes")
+        geom = torch.empty(geom_bytes, **u8)
+        img = torch.empty(lib.lsr_image_workspace_bytes(C.byref(d)), **u8)
+        radii = torch.empty((V, G), dtype=torch.int32, device=dev)
+        npairs, maxtile = C.c_int64(0), C.c_int32(0)
+        with torch.cuda.device(dev):
+            _lib.check(lib.lsr_forward_prepare(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii),
+                                               C.byref(npairs), C.byref(maxtile), stream),
+                       "lsr_forward_prepare")
+            binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), npairs.value, maxtile.value), **u8)
+            f32 = dict(dtype=torch.float32, device=dev)
+            out_color = torch.empty((V, 3, H, W), **f32) if color is not None else None
+            out_feat = torch.empty((V, Cf, H, W), **f32) if Cf else None
+            out_mask = torch.empty((V, H, W), **f32)
+            out_depth = torch.empty((V, H, W), **f32)
+            outs = Outputs(_ptr(out_color), _ptr(out_feat), _ptr(out_mask), _ptr(out_depth), _ptr(radii))
+            _lib.check(lib.lsr_forward_render(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img),
+                                              npairs.value, maxtile.value, C.byref(outs), stream),
+                       "lsr_forward_render")
+            if debug:
+                torch.cuda.synchronize(dev)
+        plan = _Plan()
+        plan.dims, plan.geom, plan.bin, plan.img = d, geom, binws, img
+        plan.num_pairs, plan.radii = npairs.value, radii
+        plan.V, plan.G, plan.H, plan.W, plan.C, plan.color_mode, plan.K = V, G, H, W, Cf, color_mode, K
+        ctx.plan = plan
+        ctx.debug = debug
+        ctx.m2d_shape = None if means2D is None else tuple(means2D.shape)
+        ctx.has = (shs is not None, colors_precomp is not None, features is not None)
+        ctx.save_for_backward(views, means3D, cov3D, opacities,
+                              color if color is not None else views.new_empty(0),
+                              features if features is not None else views.new_empty(0))
+        ctx.mark_non_differentiable(radii)
+        empty = views.new_empty(0)
+        return (out_color if out_color is not None else empty,
+                out_feat if out_feat is not None else empty, out_mask, out_depth, radii)
+
+    @staticmethod
+    def backward(ctx, g_color, g_feat, g_mask, g_depth, _g_radii):
+        lib = _lib.load()
+        plan: _Plan = ctx.plan
+        views, means3D, cov3D, opacities, color, features = ctx.saved_tensors
+        has_shs, has_cp, has_f = ctx.has
+        dev = means3D.device
+        d = plan.dims
+        V, G = plan.V, plan.G
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        def g_in(t):  # contiguous fp32 grad or None
+            return None if t is None else t.contiguous().float()
+
+        g_color = g_in(g_color) if (has_shs or has_cp) else None
+        g_feat = g_in(g_feat) if has_f else None
+        g_mask, g_depth = g_in(g_mask), g_in(g_depth)
+        inp = Inputs(_ptr(views), _ptr(means3D), _ptr(cov3D), _ptr(opacities),
+                     _ptr(color) if (has_shs or has_cp) else None, _ptr(features) if has_f else None)
+        d_means = torch.empty_like(means3D)
+        d_cov = torch.empty_like(cov3D)
+        d_opac = torch.empty_like(opacities)
+        d_color = torch.empty_like(color) if (has_shs or has_cp) else None
+        d_feat = torch.empty_like(features) if has_f else None
+        d_m2d = torch.empty((V, G, 3), **f32)
+        gradws = torch.empty(lib.lsr_grad_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+        gout = OutGrads(_ptr(g_color), _ptr(g_feat), _ptr(g_mask), _ptr(g_depth))
+        gin = InGrads(_ptr(d_means), _ptr(d_cov), _ptr(d_opac), _ptr(d_color), _ptr(d_feat), _ptr(d_m2d))
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            _lib.check(lib.lsr_backward(C.byref(d), C.byref(inp), _ptr(plan.geom), _ptr(plan.bin),
+                                        _ptr(plan.img), plan.num_pairs, _ptr(plan.radii), C.byref(gout),
+                                        _ptr(gradws), C.byref(gin), stream), "lsr_backward")
+            if ctx.debug:
+                torch.cuda.synchronize(dev)
+        if ctx.m2d_shape is None or not ctx.needs_input_grad[2]:
+            d_m2d = None
+        elif len(ctx.m2d_shape) == 2:  # one (G,3) tensor shared by the views
+            d_m2d = d_m2d.sum(0) if V > 1 else d_m2d[0]
+        # order: views, means3D, means2D, cov3D, opacities, shs, colors_precomp, features, H, W, deg, debug
+        return (None, d_means, d_m2d, d_cov, d_opac, d_color if has_shs else None,
+                d_color if has_cp else None, d_feat, None, None, None, None)
+
+
+def rasterize_views(views: Tensor, image_height: int, image_width: int, sh_degree: int, means3D: Tensor,
+                    cov3D_precomp: Tensor, opacities: Tensor, shs: Optional[Tensor] = None,
+                    colors_precomp: Optional[Tensor] = None, features: Optional[Tensor] = None,
+                    means2D: Optional[Tensor] = None, debug: bool = False):
+    """Render V views in one call.  ``views`` is the (V,40) table of :func:`make_view_table`; every
+    per-Gaussian tensor is either shared ``(G,...)`` or per view ``(V,G,...)``.
+    Returns ``(color (V,3,H,W)|None, feature (V,C,H,W)|None, mask (V,H,W), depth (V,H,W), radii (V,G))``.
+    ``means2D`` (optional, ``(V,G,3)``) only exists to receive the NDC-space mean gradient."""
+    V = views.shape[0]
+    if means2D is None:
+        means2D = torch.zeros((V, means3D.shape[-2], 3), dtype=torch.float32, device=means3D.device)
+    color, feat, mask, depth, radii = _RasterizeViews.apply(
+        views, means3D, means2D, cov3D_precomp, opacities, shs, colors_precomp, features,
+        int(image_height), int(image_width), int(sh_degree), bool(debug))
+    return (color if color.numel() else None, feat if feat.numel() else None, mask, depth, radii)
+
+
+def _covariance_from_scale_rotation(scales: Tensor, rotations: Tensor, modifier: float) -> Tensor:
+    """Sigma = R S S^T R^T packed as xx,xy,xz,yy,yz,zz; quaternion (w,x,y,z) as upstream."""
+    q = rotations / rotations.norm(dim=-1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)
+    R = R.reshape(*q.shape[:-1], 3, 3)
+    M = R * (scales * modifier)[..., None, :]
+    S = M @ M.transpose(-1, -2)
+    return torch.stack([S[..., 0, 0], S[..., 0, 1], S[..., 0, 2], S[..., 1, 1], S[..., 1, 2], S[..., 2, 2]], -1)
+
+
+class GaussianRasterizer(nn.Module):
+    """Drop-in for ``diff_gaussian_rasterization.GaussianRasterizer`` (one view per call)."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, features=None,
+                scales=None, rotations=None, cov3D_precomp=None):
+        rs = self.raster_settings
+        if shs is not None and colors_precomp is not None:
+            raise Exception("Please provide at most one of SHs / precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if cov3D_precomp is None:
+            cov3D_precomp = _covariance_from_scale_rotation(scales, rotations, float(rs.scale_modifier))
+        views = make_view_table(rs.viewmatrix[None], rs.projmatrix[None], rs.campos[None],
+                                rs.tanfovx, rs.tanfovy, rs.bg[None])
+        color, feat, mask, depth, radii = _RasterizeViews.apply(
+            views, means3D, means2D, cov3D_precomp, opacities, shs, colors_precomp, features,
+            int(rs.image_height), int(rs.image_width), int(rs.sh_degree), bool(rs.debug))
+        return (color[0] if color.numel() else None, feat[0] if feat.numel() else None,
+                mask, depth, radii[0])
