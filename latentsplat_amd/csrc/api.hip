@@ -1,5 +1,7 @@
 // api.hip — the C ABI declared in include/lsr_rasterizer.h (argument validation, workspace
 // layout, stage sequencing).  No torch, no allocation, nothing thrown across the boundary.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "lsr_internal.h"
@@ -16,6 +18,19 @@ static int fail_hip(hipError_t e) {
     do {                                              \
         hipError_t e__ = (call);                      \
         if (e__ != hipSuccess) return fail_hip(e__);  \
+    } while (0)
+
+// LSR_DEBUG_SYNC=1: announce and synchronise after every stage (the analogue of the upstream
+// op's debug=True mode) so a faulting kernel can be identified.
+static bool debug_sync() {
+    static const bool on = getenv("LSR_DEBUG_SYNC") != nullptr;
+    return on;
+}
+#define LSR_STAGE(name, s, call)                                        \
+    do {                                                                \
+        if (debug_sync()) { fprintf(stderr, "[lsr] %s ...\n", name); fflush(stderr); } \
+        LSR_HIP(call);                                                  \
+        if (debug_sync()) { LSR_HIP(hipStreamSynchronize(s)); fprintf(stderr, "[lsr] %s ok\n", name); } \
     } while (0)
 
 static int check_dims(const lsr_dims *d) {
@@ -99,8 +114,8 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
     if (d->num_gaussians > 0 && !radii) return LSR_ENULL;
     hipStream_t s = (hipStream_t)stream;
     char *geom = (char *)geom_ws;
-    LSR_HIP(launch_preprocess(*d, *in, geom, radii, s));
-    LSR_HIP(launch_tile_scan(*d, geom, s));
+    LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, s));
+    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, s));
     uint32_t hdr[2] = {0, 0};
     LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));
     LSR_HIP(hipStreamSynchronize(s));
@@ -123,8 +138,8 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
     if (num_pairs < 0 || max_tile_pairs < 0) return LSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    LSR_HIP(launch_binning(*d, (char *)geom_ws, (char *)bin_ws, num_pairs, max_tile_pairs, out->radii, s));
-    LSR_HIP(launch_render_forward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, (char *)img_ws, *out, s));
+    LSR_STAGE("binning", s, launch_binning(*d, (char *)geom_ws, (char *)bin_ws, num_pairs, max_tile_pairs, out->radii, s));
+    LSR_STAGE("render_forward", s, launch_render_forward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs, (char *)img_ws, *out, s));
     return LSR_OK;
 }
 
@@ -153,9 +168,9 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
     if (d->color_mode == LSR_COLOR_PRECOMP)
         LSR_HIP(hipMemsetAsync(gin->color, 0, (d->vs_color ? V : 1) * G * 3 * sizeof(float), s));
     if (num_pairs > 0)
-        LSR_HIP(launch_render_backward(*d, *in, (const char *)geom_ws, (const char *)bin_ws,
+        LSR_STAGE("render_backward", s, launch_render_backward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs,
                                        (const char *)img_ws, *gout, (char *)grad_ws, *gin, s));
-    LSR_HIP(launch_preprocess_backward(*d, *in, (const char *)geom_ws, radii, (const char *)grad_ws, *gin, s));
+    LSR_STAGE("preprocess_backward", s, launch_preprocess_backward(*d, *in, (const char *)geom_ws, radii, (const char *)grad_ws, *gin, s));
     return LSR_OK;
 }
 

@@ -87,10 +87,12 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s);
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
                           int32_t max_tile_pairs, const int32_t *radii, hipStream_t s);
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
-                                 const char *bin, char *img, const lsr_outputs &out, hipStream_t s);
+                                 const char *bin, int64_t num_pairs, char *img, const lsr_outputs &out,
+                                 hipStream_t s);
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
-                                  const char *bin, const char *img, const lsr_out_grads &gout,
-                                  char *grad, const lsr_in_grads &gin, hipStream_t s);
+                                  const char *bin, int64_t num_pairs, const char *img,
+                                  const lsr_out_grads &gout, char *grad, const lsr_in_grads &gin,
+                                  hipStream_t s);
 hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                       const int32_t *radii, const char *grad,
                                       const lsr_in_grads &gin, hipStream_t s);

@@ -234,11 +234,12 @@ static int pick_pxl_bwd(int nchp, int64_t tiles_total) {
 }
 
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
-                                  const char *bin, const char *img, const lsr_out_grads &gout,
-                                  char *grad, const lsr_in_grads &gin, hipStream_t s) {
+                                  const char *bin, int64_t num_pairs, const char *img,
+                                  const lsr_out_grads &gout, char *grad, const lsr_in_grads &gin,
+                                  hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const ImgLayout I = img_layout(d);
-    const BinLayout B = bin_layout(d, 1, 0);
+    const BinLayout B = bin_layout(d, num_pairs, 0);
     const GradLayout R = grad_layout(d);
     RenderBwdParams p;
     p.H = d.height; p.W = d.width; p.gx = tiles_x(d); p.T = (int)num_tiles(d); p.G = d.num_gaussians;

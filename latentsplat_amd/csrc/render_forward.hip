@@ -157,10 +157,11 @@ static int pick_pxl(int nchp, int64_t tiles_total) {
 }
 
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
-                                 const char *bin, char *img, const lsr_outputs &out, hipStream_t s) {
+                                 const char *bin, int64_t num_pairs, char *img, const lsr_outputs &out,
+                                 hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const ImgLayout I = img_layout(d);
-    const BinLayout B = bin_layout(d, 1, 0);
+    const BinLayout B = bin_layout(d, num_pairs, 0);
     RenderFwdParams p;
     p.H = d.height; p.W = d.width; p.gx = tiles_x(d); p.T = (int)num_tiles(d); p.G = d.num_gaussians;
     p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE; p.vs_feat = d.vs_feat;
