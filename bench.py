@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py — headline measurement of the rasterizer hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path (preprocess -> bin -> per-tile sort -> composite) over one
+batch of synthetic input: ``--views`` target views (default 16) of one seeded random-init scene of
+``--gaussians`` latent Gaussians (default 300 000; 4 feature channels + opacity, no colour) at
+256x256 — BASELINE.json configs[1].  Inputs are resident in HBM before the timed region.
+``value`` = views rendered per second by the whole job (all ranks).  With N > 1 every rank renders
+its own scene (disjoint seeds), there is no data-path collective: weak scaling.
+
+The same JSON line also carries
+  * ``fwdbwd``   : configs[2] (forward + backward) timed the same way right after the headline run;
+  * ``roofline`` : the dominant kernel (k_render_fwd) against the HBM roofline — algorithmic bytes
+                   of that kernel per launch / its mean duration measured live with hipEvents
+                   on the launch stream (lsr_profile_* hook), see DESIGN.md §Measurement;
+  * ``cpu_baseline`` : the CPU oracle (oracle/raster_oracle.c, OpenMP) timed on this box's host
+                   cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def build_inputs(G, V, size, device, seed):
+    """Rasterizer-boundary tensors for one scene / V views, produced by the package's wrapper math."""
+    from latentsplat_amd.decoder import cuda_splatting as cs
+    from latentsplat_amd.decoder.geometry import get_fov
+    from latentsplat_amd.rasterizer import make_view_table
+    from latentsplat_amd.synthetic import make_scene
+    sc = make_scene(G, image_size=size, views=V, color_sh_degree=None, feature_channels=4,
+                    feature_sh_degree=0, seed=seed).to(device)
+    means = sc.means[None].expand(V, -1, -1)
+    covs = sc.covariances[None].expand(V, -1, -1, -1)
+    ext, nr, fr, means, covs = cs._scale_scene(sc.extrinsics, sc.near, sc.far, means, covs)
+    fov_x, fov_y = get_fov(sc.intrinsics).unbind(-1)
+    cams = cs._cameras(ext, nr, fr, fov_x, fov_y)
+    _, _, _, features = cs._payload(means, cams.campos, None, sc.feature_sh[None], True)
+    bg = torch.zeros((V, 3), device=device)
+    views = make_view_table(cams.view_matrix, cams.full_projection, cams.campos, cams.tan_fov_x,
+                            cams.tan_fov_y, bg)
+    return dict(views=views, means=means.contiguous(), cov6=cs._pack_covariances(covs).contiguous(),
+                opac=sc.opacities[:, None].contiguous(), features=features.contiguous(), cams=cams)
+
+
+def cpu_baseline(G, size, seed, budget_s=12.0):
+    """Oracle (port) on the host cores: whole forward of single views of the same workload."""
+    from oracle import oracle as orc
+    from tests import util
+    from latentsplat_amd.synthetic import make_scene
+    sc = make_scene(G, image_size=size, views=1, color_sh_degree=None, feature_channels=4, seed=seed)
+    bi = util.boundary_inputs(sc, size, size)
+    util.oracle_forward(bi, 0)  # warm-up (page in, build)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        util.oracle_forward(bi, 0)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return dict(value=n / el, unit="views/s", cores=os.cpu_count(), kind="port",
+                sample=f"{n} forward renders of the same {G}-Gaussian {size}x{size} view "
+                       f"(oracle/raster_oracle.c, gcc -O2 -fopenmp, {os.cpu_count()} threads)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views", type=int, default=16, help="views per step (batch of the hot path)")
+    ap.add_argument("--gaussians", type=int, default=300_000)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bwd", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from latentsplat_amd import _lib
+    from latentsplat_amd.rasterizer import rasterize_views
+    _lib.load()
+    G, V, S = args.gaussians, args.views, args.size
+    inp = build_inputs(G, V, S, dev, seed=1234 + rank)
+
+    def fwd(need_grad=False):
+        m, c, o, f = inp["means"], inp["cov6"], inp["opac"], inp["features"]
+        if need_grad:
+            m, c, o, f = (t.detach().requires_grad_(True) for t in (m, c, o, f))
+        out = rasterize_views(inp["views"], S, S, 0, m, c, o, features=f)
+        return out, (m, c, o, f)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        barrier()
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    # ---- headline: forward only (configs[1]) ----
+    _lib.profile_enable(True)
+    _lib.profile_read()
+    el_fwd = timed(lambda: fwd(False), args.steps, args.warmup)
+    prof = _lib.profile_read()          # includes warm-up launches; per-launch means are unaffected
+    _lib.profile_enable(False)
+    views_total = V * args.steps * world
+    value = views_total / el_fwd
+
+    # ---- fwd+bwd (configs[2]) ----
+    fb = None
+    if not args.no_bwd:
+        gen = torch.Generator(device="cpu").manual_seed(99)
+        gf = torch.randn((V, 4, S, S), generator=gen).to(dev)
+
+        def step_fb():
+            (color, feat, mask, depth, radii), leaves = fwd(True)
+            feat.backward(gf)
+        _lib.profile_enable(True)
+        _lib.profile_read()
+        el_fb = timed(step_fb, args.steps, args.warmup)
+        prof_fb = _lib.profile_read()
+        _lib.profile_enable(False)
+        fb = dict(views_per_s=views_total / el_fb, ms_per_view=1e3 * el_fb / (V * args.steps),
+                  kernel_ms_per_launch={k: (ms / n if n else None) for k, (ms, n) in prof_fb.items()})
+
+    # ---- workload statistics for the byte model (outside the timed region) ----
+    (color, feat, mask, depth, radii), _ = fwd(False)
+    torch.cuda.synchronize(dev)
+    g_vis = int((radii > 0).sum().item())
+    from latentsplat_amd.rasterizer import LAST_STATS
+    P = int(LAST_STATS["num_pairs"])  # sum of tile-rectangle areas over the step's V views
+    C = 4
+    b_in = 12 + 24 + 4 + 4 * C
+    b_rec = 8 + 16 + 4 * C
+    b_out = 4 * (C + 2)
+    render_ms, render_n = prof["render_forward"]
+    render_ms_per_launch = render_ms / max(render_n, 1)
+    roofline = None
+    path = None
+    if P is not None:
+        # algorithmic bytes of ONE render launch (V views): sorted index + gathered record per pair,
+        # every output word once (SURVEY.md §8(d) terms P*b_rec + H*W*b_out, plus the 4-byte index)
+        render_bytes = P * (4 + b_rec) + V * S * S * b_out
+        achieved = render_bytes / (render_ms_per_launch * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_render_forward.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = dict(bound="hbm", kernel="k_render_fwd", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                        algorithmic_bytes_per_launch=render_bytes, launch_ms=render_ms_per_launch)
+        # whole forward path per view against the same roofline (SURVEY §8(d) B_fwd)
+        B_fwd_step = V * G * b_in + g_vis * b_rec + P * 16 + P * b_rec + V * S * S * b_out
+        step_s = el_fwd / args.steps
+        path = dict(algorithmic_bytes_per_view=B_fwd_step / V, achieved=B_fwd_step / step_s / 1e9,
+                    frac=B_fwd_step / step_s / 1e9 / HBM_PEAK_GBS, pairs_per_view=P / V,
+                    visible_fraction=g_vis / (V * G))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(G, S, 1234)
+
+    if rank == 0:
+        line = {
+            "metric": "rendered target views/sec at 256x256, ~300k Gaussians (forward); fwd+bwd ms/view in `fwdbwd`",
+            "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * el_fwd / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {G} latent Gaussians (4-ch features + opacity), "
+                                   f"{S}x{S}, forward render; {V} views of one scene per step per GPU",
+                       "views_per_step": V, "gaussians": G, "image": [S, S],
+                       "parallelism": f"replicas x{world} (one scene per rank, no data-path collective)"},
+            "ms_per_view_fwd": 1e3 * el_fwd / (V * args.steps),
+            "kernel_ms_per_launch": {k: (ms / n if n else None) for k, (ms, n) in prof.items()},
+            "fwdbwd": fb, "roofline": roofline, "roofline_path": path, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

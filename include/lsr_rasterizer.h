@@ -149,6 +149,16 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws,
                  const int32_t *radii, const lsr_out_grads *gout, void *grad_ws,
                  const lsr_in_grads *gin, lsr_stream_t stream);
 
+/* ---- optional measurement hook (bench.py): when enabled, every stage kernel is bracketed by
+ * hipEvents on the caller's stream; lsr_profile_read() waits for them, returns the accumulated
+ * milliseconds and launch counts per stage since the previous read, and resets the totals.
+ * Arrays must hold lsr_profile_num_stages() entries. Not thread-safe; one instance per process,
+ * matching the reference's one-rasterizer-per-DDP-process use. */
+int lsr_profile_enable(int on);
+int lsr_profile_num_stages(void);
+const char *lsr_profile_stage_name(int stage);
+int lsr_profile_read(double *ms_out, int64_t *launches_out);
+
 #ifdef __cplusplus
 }
 #endif

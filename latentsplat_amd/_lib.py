@@ -60,6 +60,7 @@ EXPORTS = (
     "lsr_abi_version", "lsr_error_string", "lsr_last_hip_error", "lsr_geom_workspace_bytes",
     "lsr_image_workspace_bytes", "lsr_binning_workspace_bytes", "lsr_grad_workspace_bytes",
     "lsr_get_layout", "lsr_forward_prepare", "lsr_forward_render", "lsr_backward",
+    "lsr_profile_enable", "lsr_profile_num_stages", "lsr_profile_stage_name", "lsr_profile_read",
 )
 
 _lib = None
@@ -110,10 +111,27 @@ def load():
     lib.lsr_backward.restype = C.c_int
     lib.lsr_backward.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, P,
                                  C.POINTER(OutGrads), P, C.POINTER(InGrads), P]
+    lib.lsr_profile_enable.argtypes = [C.c_int]
+    lib.lsr_profile_stage_name.restype = C.c_char_p
+    lib.lsr_profile_stage_name.argtypes = [C.c_int]
+    lib.lsr_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(I64)]
     if lib.lsr_abi_version() != 1:
         raise LsrError("liblsr_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
+
+
+def profile_enable(on: bool) -> None:
+    load().lsr_profile_enable(1 if on else 0)
+
+
+def profile_read() -> dict:
+    """{stage: (total_ms, launches)} since the previous read (blocks until the events finish)."""
+    lib = load()
+    n = lib.lsr_profile_num_stages()
+    ms, cnt = (C.c_double * n)(), (C.c_int64 * n)()
+    check(lib.lsr_profile_read(ms, cnt), "lsr_profile_read")
+    return {lib.lsr_profile_stage_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}
 
 
 def check(rc: int, what: str):

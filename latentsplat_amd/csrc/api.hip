@@ -8,7 +8,42 @@
 
 using namespace lsr;
 
+#include <vector>
+
 static thread_local int g_last_hip_error = 0;
+
+// ---- per-stage timing with hipEvents recorded on the caller's stream -----------------------
+namespace {
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> pool;                       // free events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[lsr::kNumStages];
+    hipEvent_t open_ev[lsr::kNumStages] = {};
+    double ms[lsr::kNumStages] = {};
+    int64_t n[lsr::kNumStages] = {};
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+Prof g_prof;
+}  // namespace
+void lsr::prof_begin(int stage, hipStream_t s) {
+    if (!g_prof.on) return;
+    hipEvent_t e = g_prof.get();
+    (void)hipEventRecord(e, s);
+    g_prof.open_ev[stage] = e;
+}
+void lsr::prof_end(int stage, hipStream_t s) {
+    if (!g_prof.on || !g_prof.open_ev[stage]) return;
+    hipEvent_t e = g_prof.get();
+    (void)hipEventRecord(e, s);
+    g_prof.pending[stage].push_back({g_prof.open_ev[stage], e});
+    g_prof.open_ev[stage] = nullptr;
+}
+
 
 static int fail_hip(hipError_t e) {
     g_last_hip_error = (int)e;
@@ -68,6 +103,37 @@ static int check_inputs(const lsr_dims *d, const lsr_inputs *in) {
 extern "C" {
 
 int lsr_abi_version(void) { return LSR_ABI_VERSION; }
+
+int lsr_profile_enable(int on) {
+    g_prof.on = on != 0;
+    return LSR_OK;
+}
+int lsr_profile_num_stages(void) { return lsr::kNumStages; }
+const char *lsr_profile_stage_name(int stage) {
+    static const char *names[lsr::kNumStages] = {"preprocess", "tile_scan", "scatter", "sort_tiles",
+                                                  "render_forward", "render_backward", "preprocess_backward"};
+    return (stage >= 0 && stage < lsr::kNumStages) ? names[stage] : "?";
+}
+int lsr_profile_read(double *ms_out, int64_t *launches_out) {
+    if (!ms_out || !launches_out) return LSR_ENULL;
+    for (int st = 0; st < lsr::kNumStages; ++st) {
+        for (auto &pr : g_prof.pending[st]) {
+            float t = 0.0f;
+            if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) {
+                g_prof.ms[st] += t;
+                g_prof.n[st] += 1;
+            }
+            g_prof.pool.push_back(pr.first);
+            g_prof.pool.push_back(pr.second);
+        }
+        g_prof.pending[st].clear();
+        ms_out[st] = g_prof.ms[st];
+        launches_out[st] = g_prof.n[st];
+        g_prof.ms[st] = 0.0;
+        g_prof.n[st] = 0;
+    }
+    return LSR_OK;
+}
 int lsr_last_hip_error(void) { return g_last_hip_error; }
 
 const char *lsr_error_string(int code) {

@@ -43,9 +43,11 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
 hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const int N = d.num_views * (int)num_tiles(d);
+    prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
                        (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
                        (uint32_t *)(geom + L.header), N);
+    prof_end(kStTileScan, s);
     return hipGetLastError();
 }
 
@@ -188,6 +190,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     {
         dim3 grid((d.num_gaussians + kScatThreads * kScatItems - 1) / (kScatThreads * kScatItems), d.num_views);
         const bool lds = T <= 8192;
+        prof_begin(kStScatter, s);
         if (lds)
             hipLaunchKernelGGL((k_scatter<true>), grid, dim3(kScatThreads), (size_t)T * 8, s,
                                d.num_gaussians, gx, T, (const ushort4 *)(geom + L.rect),
@@ -196,12 +199,14 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
             hipLaunchKernelGGL((k_scatter<false>), grid, dim3(kScatThreads), 0, s, d.num_gaussians,
                                gx, T, (const ushort4 *)(geom + L.rect), (const float4 *)(geom + L.q1),
                                ts, (uint32_t *)(geom + L.tile_cursor), keys);
+        prof_end(kStScatter, s);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     {
         dim3 grid(T, d.num_views);
         int cap;
+        prof_begin(kStSort, s);
 #define LSR_SORT(CAPV)                                                                           \
     do {                                                                                         \
         cap = CAPV;                                                                              \
@@ -222,6 +227,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }
+        prof_end(kStSort, s);
     }
     return hipSuccess;
 }

@@ -80,6 +80,11 @@ inline GradLayout grad_layout(const lsr_dims &d) {
     return L;
 }
 
+// ---- optional per-stage hipEvent timing (api.hip); no-ops unless lsr_profile_enable(1) ----
+enum Stage { kStPreprocess = 0, kStTileScan, kStScatter, kStSort, kStRenderFwd, kStRenderBwd, kStPreprocessBwd, kNumStages };
+void prof_begin(int stage, hipStream_t s);
+void prof_end(int stage, hipStream_t s);
+
 // ---- stage launchers (defined one per .hip file) ----
 hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii,
                              hipStream_t s);

@@ -176,10 +176,12 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
         else hipLaunchKernelGGL((k_preprocess<CM, false>), grid, dim3(kPreThreads), 0, s, d, in, \
                                 q0, q1, rect, rgb, radii, tc);                                   \
     } while (0)
+    prof_begin(kStPreprocess, s);
     if (d.color_mode == LSR_COLOR_SH) LSR_PRE(LSR_COLOR_SH);
     else if (d.color_mode == LSR_COLOR_PRECOMP) LSR_PRE(LSR_COLOR_PRECOMP);
     else LSR_PRE(LSR_COLOR_NONE);
 #undef LSR_PRE
+    prof_end(kStPreprocess, s);
     return hipGetLastError();
 }
 

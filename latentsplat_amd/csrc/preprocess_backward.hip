@@ -205,7 +205,9 @@ hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, c
     p.dxy = (const float2 *)(grad + R.dxy); p.dconic = (const float4 *)(grad + R.dconic);
     p.dz = (const float *)(grad + R.dz); p.drgb = (const float4 *)(grad + R.drgb);
     p.g = gin;
+    prof_begin(kStPreprocessBwd, s);
     hipLaunchKernelGGL(k_preprocess_bwd, dim3((d.num_gaussians + 255) / 256), dim3(256), 0, s, p);
+    prof_end(kStPreprocessBwd, s);
     return hipGetLastError();
 }
 

@@ -267,11 +267,13 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
         if (dg) hipLaunchKernelGGL((k_render_bwd<N, X, true>), grid, dim3(LSR_WAVE), 0, s, p);    \
         else hipLaunchKernelGGL((k_render_bwd<N, X, false>), grid, dim3(LSR_WAVE), 0, s, p);      \
     } while (0)
+    prof_begin(kStRenderBwd, s);
     if (nchp == 4) { if (pxl == 4) LSR_RB(4, 4); else if (pxl == 2) LSR_RB(4, 2); else LSR_RB(4, 1); }
     else if (nchp == 8) { if (pxl == 2) LSR_RB(8, 2); else LSR_RB(8, 1); }
     else if (nchp == 12) { if (pxl == 2) LSR_RB(12, 2); else LSR_RB(12, 1); }
     else LSR_RB(36, 1);
 #undef LSR_RB
+    prof_end(kStRenderBwd, s);
     return hipGetLastError();
 }
 

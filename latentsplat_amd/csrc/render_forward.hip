@@ -184,12 +184,14 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
         else if (pxl == 2) LSR_RF(N, 2);             \
         else LSR_RF(N, 1);                           \
     } while (0)
+    prof_begin(kStRenderFwd, s);
     if (nchp == 4) LSR_RF_N(4);
     else if (nchp == 8) LSR_RF_N(8);
     else if (nchp == 12) LSR_RF_N(12);
     else { if (pxl == 2) LSR_RF(36, 2); else LSR_RF(36, 1); }
 #undef LSR_RF_N
 #undef LSR_RF
+    prof_end(kStRenderFwd, s);
     return hipGetLastError();
 }
 

@@ -78,6 +78,10 @@ def _stride(t: Optional[Tensor], base_dims: int, V: int, name: str) -> int:
     return t[0].numel()
 
 
+# statistics of the most recent forward (host-side; the pair count is known after prepare())
+LAST_STATS: dict = {}
+
+
 class _Plan:
     """Everything one forward call hands to the matching backward."""
     __slots__ = ("dims", "geom", "bin", "img", "num_pairs", "radii", "V", "G", "H", "W", "C",
@@ -149,6 +153,7 @@ class _RasterizeViews(torch.autograd.Function):
         plan.num_pairs, plan.radii = npairs.value, radii
         plan.V, plan.G, plan.H, plan.W, plan.C, plan.color_mode, plan.K = V, G, H, W, Cf, color_mode, K
         ctx.plan = plan
+        LAST_STATS.update(num_pairs=npairs.value, max_tile_pairs=maxtile.value, views=V, gaussians=G)
         ctx.debug = debug
         ctx.m2d_shape = None if means2D is None else tuple(means2D.shape)
         ctx.has = (shs is not None, colors_precomp is not None, features is not None)
