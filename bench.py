@@ -76,6 +76,40 @@ def cpu_baseline(G, size, seed, budget_s=12.0):
                        f"(oracle/raster_oracle.c, gcc -O2 -fopenmp, {os.cpu_count()} threads)")
 
 
+def timed_region(step, steps, warmup, dist=None, device_sync=lambda: None, reduce_device="cpu"):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + device sync on
+    both sides; returns the MAX elapsed seconds over ranks (every rank gets the same number)."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        device_sync()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    device_sync()
+    el = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        t = torch.tensor([el], device=reduce_device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el
+
+
+def whole_job_views_per_s(views_per_step, steps, world, elapsed_max):
+    """Weak scaling: every rank renders its own `views_per_step` views per step (disjoint scenes,
+    no data-path collective), so the job rate is the total view count over the slowest rank's time."""
+    return views_per_step * steps * world / elapsed_max
+
+
+def rank_seed(base, rank):
+    return base + rank
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,7 +139,7 @@ def main():
     from latentsplat_amd.rasterizer import rasterize_views
     _lib.load()
     G, V, S = args.gaussians, args.views, args.size
-    inp = build_inputs(G, V, S, dev, seed=1234 + rank)
+    inp = build_inputs(G, V, S, dev, seed=rank_seed(1234, rank))
 
     def fwd(need_grad=False):
         m, c, o, f = inp["means"], inp["cov6"], inp["opac"], inp["features"]
@@ -114,26 +148,8 @@ def main():
         out = rasterize_views(inp["views"], S, S, 0, m, c, o, features=f)
         return out, (m, c, o, f)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
     def timed(fn, steps, warmup):
-        for _ in range(warmup):
-            fn()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize(dev)
-        el = time.perf_counter() - t0
-        barrier()
-        if dist is not None:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el
+        return timed_region(fn, steps, warmup, dist, lambda: torch.cuda.synchronize(dev), dev)
 
     # ---- headline: forward only (configs[1]) ----
     _lib.profile_enable(True)
@@ -142,7 +158,7 @@ def main():
     prof = _lib.profile_read()          # includes warm-up launches; per-launch means are unaffected
     _lib.profile_enable(False)
     views_total = V * args.steps * world
-    value = views_total / el_fwd
+    value = whole_job_views_per_s(V, args.steps, world, el_fwd)
 
     # ---- fwd+bwd (configs[2]) ----
     fb = None

@@ -11,7 +11,8 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_SO = os.path.join(_CSRC, "liblsr_hip.so")
+# LSR_LIB selects an alternative build of the same library (kernel A/B experiments only)
+_SO = os.environ.get("LSR_LIB") or os.path.join(_CSRC, "liblsr_hip.so")
 
 VIEW_FLOATS = 40
 COLOR_NONE, COLOR_SH, COLOR_PRECOMP = 0, 1, 2

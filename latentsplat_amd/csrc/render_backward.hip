@@ -192,6 +192,10 @@ k_render_bwd(RenderBwdParams p) {
                 go = __builtin_fmaf(Gv, dL_dalpha, go);
             }
             if (!__any(any_valid)) continue;
+#ifdef LSR_ABLATE_REDUCE
+            asm volatile("" ::"v"(gx), "v"(gy), "v"(gA), "v"(gB), "v"(gC), "v"(go), "v"(gpay[0]), "v"(gpay[1]), "v"(gpay[2]), "v"(gpay[3]));
+            continue;
+#endif
             gx = wave_sum_to_row3(gx); gy = wave_sum_to_row3(gy);
             gA = wave_sum_to_row3(gA); gB = wave_sum_to_row3(gB); gC = wave_sum_to_row3(gC);
             go = wave_sum_to_row3(go);
@@ -199,6 +203,10 @@ k_render_bwd(RenderBwdParams p) {
 #pragma unroll
             for (int c = 0; c < NCHP; ++c)
                 if (c < coff + p.C) gpay[c] = wave_sum_to_row3(gpay[c]);
+#ifdef LSR_ABLATE_ATOMICS
+            asm volatile("" ::"v"(gx), "v"(gy), "v"(gA), "v"(gB), "v"(gC), "v"(go), "v"(gpay[0]), "v"(gpay[1]), "v"(gpay[2]), "v"(gpay[3]));
+            continue;
+#endif
             if (lane == 63) {
                 const uint32_t g = s_gid[j];
                 float *dxy = (float *)&p.dxy[vG + g];

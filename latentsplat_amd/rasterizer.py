@@ -93,6 +93,7 @@ class _RasterizeViews(torch.autograd.Function):
     def forward(ctx, views, means3D, means2D, cov3D, opacities, shs, colors_precomp, features,
                 H: int, W: int, sh_degree: int, debug: bool):
         lib = _lib.load()
+        ctx.set_materialize_grads(False)  # unused outputs (mask / depth ...) arrive as None, not zeros
         dev = means3D.device
         if dev.type != "cuda":
             raise LsrError("latentsplat_amd rasterizer runs on MI355X only: tensors must be on a "

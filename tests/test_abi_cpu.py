@@ -1,0 +1,85 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol the public header
+declares; host-only entry points (sizing, validation) behave as documented."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from latentsplat_amd import _lib
+from latentsplat_amd._lib import Dims, Inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "lsr_rasterizer.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lsr_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 15
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(names) == set(_lib.EXPORTS)
+    assert lib.lsr_abi_version() == 1
+
+
+def _dims(**kw):
+    base = dict(num_views=2, num_gaussians=1000, height=64, width=64, feat_channels=4, color_mode=0,
+                sh_degree=0, sh_coeffs=0, vs_means=0, vs_cov=0, vs_opac=0, vs_color=0, vs_feat=0)
+    base.update(kw)
+    return Dims(**base)
+
+
+def test_workspace_sizes():
+    lib = _lib.load()
+    d = _dims()
+    g, i = lib.lsr_geom_workspace_bytes(C.byref(d)), lib.lsr_image_workspace_bytes(C.byref(d))
+    assert g >= 2 * 1000 * (16 + 16 + 8) and i >= 2 * 64 * 64 * 8
+    assert lib.lsr_binning_workspace_bytes(C.byref(d), 5000, 100) >= 5000 * 12
+    # lists longer than the LDS capacity need the merge scratch
+    assert lib.lsr_binning_workspace_bytes(C.byref(d), 50000, 20000) > lib.lsr_binning_workspace_bytes(C.byref(d), 50000, 100)
+    d2 = _dims(num_views=4)
+    assert lib.lsr_geom_workspace_bytes(C.byref(d2)) > g
+    assert lib.lsr_grad_workspace_bytes(C.byref(d)) >= 2 * 1000 * (8 + 16 + 4)
+
+
+@pytest.mark.parametrize("bad", [
+    dict(num_views=0), dict(height=0), dict(feat_channels=33), dict(feat_channels=0, color_mode=0),
+    dict(color_mode=1, sh_degree=5, sh_coeffs=36), dict(color_mode=1, sh_degree=2, sh_coeffs=4),
+    dict(vs_means=7), dict(vs_feat=5),
+])
+def test_invalid_dims_are_rejected(bad):
+    lib = _lib.load()
+    d = _dims(**bad)
+    assert lib.lsr_geom_workspace_bytes(C.byref(d)) == 0
+    npairs, maxtile = C.c_int64(0), C.c_int32(0)
+    rc = lib.lsr_forward_prepare(C.byref(d), C.byref(Inputs()), None, None, C.byref(npairs), C.byref(maxtile), None)
+    assert rc == -1 and b"invalid" in lib.lsr_error_string(rc)
+
+
+def test_null_pointers_are_rejected_before_any_gpu_work():
+    lib = _lib.load()
+    d = _dims()
+    npairs, maxtile = C.c_int64(0), C.c_int32(0)
+    assert lib.lsr_forward_prepare(C.byref(d), C.byref(Inputs()), None, None, C.byref(npairs), C.byref(maxtile), None) == -2
+    assert lib.lsr_forward_render(C.byref(d), C.byref(Inputs()), None, None, None, 0, 0, None, None) == -2
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from latentsplat_amd.rasterizer import rasterize_views
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rasterize_views(torch.zeros(1, 40), 16, 16, 0, torch.zeros(4, 3), torch.zeros(4, 6), torch.zeros(4, 1),
+                        features=torch.zeros(4, 4))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_SO", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.LsrError, match="no CPU"):
+        _lib.load()

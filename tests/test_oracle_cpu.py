@@ -1,0 +1,193 @@
+"""Known-answer tests for the CPU oracle itself (SURVEY.md §8(c) self-consistency KATs) and the
+cross-check of its hand-derived backward against an independent autograd restatement."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from oracle import torch_oracle as to
+from tests import util
+
+EYE = np.eye(4, dtype=np.float32)
+
+
+def _simple_view(H=32, W=32, tanfov=0.5, bg=(0.0, 0.0, 0.0), near=1.0, far=100.0):
+    """Camera at the origin looking down +z; projection as get_projection_matrix builds it."""
+    P = np.zeros((4, 4), np.float32)
+    P[0, 0] = 1 / tanfov; P[1, 1] = 1 / tanfov; P[3, 2] = 1
+    P[2, 2] = far / (far - near); P[2, 3] = -(far * near) / (far - near)
+    return orc.View(H, W, tanfov, tanfov, np.array(bg, np.float32), EYE.T.copy(), P.T.copy(),
+                    np.zeros(3, np.float32), 0)
+
+
+def _iso_cov(s2, n=1):
+    c = np.zeros((n, 6), np.float32)
+    c[:, 0] = c[:, 3] = c[:, 5] = s2
+    return c
+
+
+def _center_mean(view, px, py, z):
+    """World point that projects exactly onto pixel centre (px, py)."""
+    fx = view.W / (2 * view.tanfovx)
+    ndc_x = (2 * px + 1) / view.W - 1
+    ndc_y = (2 * py + 1) / view.H - 1
+    return np.array([[ndc_x * view.tanfovx * z, ndc_y * view.tanfovy * z, z]], np.float32), fx
+
+
+def test_single_gaussian_analytic():
+    # 33x33: the principal point falls exactly on pixel (16,16), where the EWA Jacobian has no
+    # shear term and an isotropic 3D Gaussian projects to an isotropic 2D one
+    view = _simple_view(H=33, W=33, bg=(0.2, 0.4, 0.6))
+    z, op, s = 4.0, 0.7, 0.05
+    mean, fx = _center_mean(view, 16, 16, z)
+    col = np.array([[0.9, 0.5, 0.1]], np.float32)
+    feat = np.array([[1.0, -2.0, 3.0, 0.25]], np.float32)
+    o = orc.forward(view, mean, _iso_cov(s * s), np.array([[op]], np.float32), colors_precomp=col, features=feat)
+    var = (fx * s / z) ** 2 + 0.3   # EWA: isotropic 3D sigma -> pixels, + low-pass 0.3
+    assert o["radii"][0] == int(np.ceil(3 * np.sqrt(var)))
+    np.testing.assert_allclose(o["xy"][0], [16, 16], atol=1e-4)
+    ys, xs = np.mgrid[0:33, 0:33]
+    d2 = (xs - 16.0) ** 2 + (ys - 16.0) ** 2
+    alpha = np.minimum(0.99, op * np.exp(-0.5 * d2 / var))
+    alpha[alpha < 1 / 255] = 0
+    # only tiles inside the radius rectangle are rasterized
+    r = o["rect"][0]
+    inside = (xs // 16 >= r[0]) & (xs // 16 < r[2]) & (ys // 16 >= r[1]) & (ys // 16 < r[3])
+    alpha = alpha * inside
+    np.testing.assert_allclose(o["mask"], alpha, atol=2e-6)
+    np.testing.assert_allclose(o["depth"], alpha * z, atol=1e-5)
+    for c in range(3):
+        np.testing.assert_allclose(o["color"][c], alpha * col[0, c] + (1 - alpha) * view.bg[c], atol=2e-6)
+    for c in range(4):   # feature background is 0
+        np.testing.assert_allclose(o["feature"][c], alpha * feat[0, c], atol=1e-5)
+    assert o["n_contrib"][16, 16] == 1 and o["final_T"][16, 16] == pytest.approx(1 - op, abs=1e-6)
+
+
+def test_depth_order_and_stable_ties():
+    view = _simple_view()
+    m_far, _ = _center_mean(view, 8, 8, 6.0)
+    m_near, _ = _center_mean(view, 8, 8, 3.0)
+    means = np.concatenate([m_far, m_near, m_near, m_far]).astype(np.float32)   # indices 0..3
+    o = orc.forward(view, means, _iso_cov(0.01, 4), np.full((4, 1), 0.5, np.float32),
+                    colors_precomp=np.eye(4, 3, dtype=np.float32))
+    s, e = o["ranges"][0]
+    np.testing.assert_array_equal(o["point_list"][s:e], [1, 2, 0, 3])   # depth asc, ties by index
+    assert np.all(np.diff(o["keys"].astype(np.uint64)) >= 0)
+    # front-to-back: weights 0.5, 0.25, 0.125, 0.0625 at the centre pixel
+    np.testing.assert_allclose(o["color"][:, 8, 8], [0.125, 0.5, 0.25], atol=1e-5)
+
+
+def test_culling_rules():
+    view = _simple_view()
+    means = np.array([[0, 0, -1.0], [0, 0, 0.2], [0, 0, 0.2001], [50.0, 0, 4.0], [0, 0, 4.0]], np.float32)
+    o = orc.forward(view, means, _iso_cov(1e-4, 5), np.full((5, 1), 0.5, np.float32),
+                    features=np.ones((5, 4), np.float32))
+    assert list(o["radii"] > 0) == [False, False, True, False, True]   # behind, z==0.2, ok, off-screen, ok
+    assert o["tiles_touched"][3] == 0 and o["P"] == int(o["tiles_touched"].sum())
+
+
+def test_early_termination_and_n_contrib():
+    view = _simple_view()
+    n = 10
+    means = np.concatenate([_center_mean(view, 5, 5, 2.0 + 0.1 * i)[0] for i in range(n)])
+    o = orc.forward(view, means, _iso_cov(0.01, n), np.full((n, 1), 0.8, np.float32),
+                    features=np.ones((n, 4), np.float32))
+    # T: .2 .04 .008 .0016 .00032 -> the 6th would give 6.4e-5 < 1e-4: not blended
+    assert o["n_contrib"][5, 5] == 5
+    assert o["final_T"][5, 5] == pytest.approx(0.2 ** 5, rel=1e-5)
+    assert o["mask"][5, 5] == pytest.approx(1 - 0.2 ** 5, rel=1e-6)
+
+
+def test_empty_scene():
+    view = _simple_view(bg=(0.1, 0.2, 0.3))
+    o = orc.forward(view, np.zeros((0, 3), np.float32), np.zeros((0, 6), np.float32), np.zeros((0, 1), np.float32),
+                    colors_precomp=np.zeros((0, 3), np.float32))
+    assert o["P"] == 0 and np.all(o["mask"] == 0)
+    np.testing.assert_allclose(o["color"][:, 3, 3], [0.1, 0.2, 0.3])
+
+
+def test_color_sh_convention_matches_reference_eval_sh():
+    """Kernel-side colour SH (upstream axes) == the reference's eval_sh (e3nn axes) evaluated at
+    the permuted direction (x,y,z)_ref = (y,z,x)_kernel, for every degree up to 4.
+
+    One coefficient is excluded: index 14 (l=3, m=2).  The reference's Python eval_sh has
+    ``C3[5] * z * (zz - xx)`` there (src/misc/sh_utils.py:84), which under the permutation is
+    x(xx-yy) — not a harmonic function (its Laplacian is 4x) — whereas the published rasterizer,
+    and therefore this kernel, uses the harmonic z(xx-yy).  The reference only ever evaluates its
+    Python eval_sh up to degree 2 (latent features), so the discrepancy is unobservable there; the
+    host-side eval_sh of this repo reproduces the reference formula verbatim (test_golden_cpu)."""
+    from latentsplat_amd.decoder.geometry import eval_sh
+    rng = np.random.default_rng(3)
+    view = _simple_view(H=64, W=64)
+    G = 200
+    means = np.stack([rng.uniform(-1, 1, G), rng.uniform(-1, 1, G), rng.uniform(2, 6, G)], 1).astype(np.float32)
+    for deg in range(5):
+        K = (deg + 1) ** 2
+        shs = rng.normal(0, 0.3, (G, K, 3)).astype(np.float32)
+        if K > 14:
+            shs[:, 14] = 0
+        v = view._replace(sh_degree=deg, campos=np.array([0.3, -0.2, 0.1], np.float32))
+        o = orc.forward(v, means, _iso_cov(1e-3, G), np.full((G, 1), 0.5, np.float32), shs=shs)
+        d = means - v.campos
+        d = d / np.linalg.norm(d, axis=1, keepdims=True)
+        d_ref = torch.from_numpy(np.stack([d[:, 1], d[:, 2], d[:, 0]], 1))
+        want = 0.5 + eval_sh(deg, torch.from_numpy(shs).permute(0, 2, 1), d_ref).numpy()
+        vis = o["radii"] > 0
+        np.testing.assert_allclose(o["rgb"][vis], np.maximum(want, 0)[vis], atol=3e-6)
+        np.testing.assert_array_equal(o["clamped"][vis].astype(bool), (want < 0)[vis])
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(G=1500, size=64, color_sh_degree=2, feature_channels=4, feature_sh_degree=1),
+    dict(G=800, size=48, color_sh_degree=4, feature_channels=8, feature_sh_degree=0),
+    dict(G=800, size=48, color_sh_degree=None, feature_channels=4, feature_sh_degree=2, sigma_px=(2.0, 12.0), opacity_scale=1.0),
+])
+def test_c_oracle_matches_autograd_oracle(cfg):
+    cfg = dict(cfg)
+    G, size = cfg.pop("G"), cfg.pop("size")
+    sc = util.make_scene(G, image_size=size, views=1, **cfg)
+    bi = util.boundary_inputs(sc, size, size, bg=(0.1, 0.2, 0.3))
+    fwd = util.oracle_forward(bi, 0)
+    c = bi["cams"]
+    req = lambda x: None if x is None else x.clone().requires_grad_(True)
+    means, cov6, opac, shs, feats = req(bi["means"][0]), req(bi["cov6"][0]), req(bi["opac"]), req(bi["shs"]), req(bi["features"][0])
+    color, feat, mask, depth, radii = to.rasterize(size, size, float(c.tan_fov_x[0]), float(c.tan_fov_y[0]), bi["bg"][0],
+                                                   c.view_matrix[0], c.full_projection[0], c.campos[0], bi["sh_degree"],
+                                                   means, cov6, opac, shs, None, feats)
+    np.testing.assert_array_equal(radii.numpy(), fwd["radii"])
+    gen = torch.Generator().manual_seed(1)
+    loss, grads = 0, {}
+    for name, t, ref in (("color", color, fwd["color"]), ("feature", feat, fwd["feature"]),
+                         ("mask", mask, fwd["mask"][None]), ("depth", depth, fwd["depth"][None])):
+        if t is None:
+            grads[name] = None
+            continue
+        np.testing.assert_allclose(t.detach().numpy(), ref, atol=5e-6, rtol=1e-5)
+        grads[name] = torch.randn(t.shape, generator=gen)
+        loss = loss + (t * grads[name]).sum()
+    loss.backward()
+    n = lambda g: None if g is None else g.numpy()
+    bw = util.oracle_backward(bi, 0, fwd, n(grads["color"]), n(grads["feature"]), n(grads["mask"])[0], n(grads["depth"])[0])
+    for name, a, b in (("means", means.grad, bw["means3D"]), ("cov", cov6.grad, bw["cov3D"]), ("opac", opac.grad, bw["opacities"]),
+                       ("shs", None if shs is None else shs.grad, bw["shs"]), ("feat", feats.grad, bw["features"])):
+        if a is None:
+            continue
+        a = a.numpy()
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), name
+
+
+def test_autograd_oracle_gradcheck_float64():
+    """Finite differences (float64) agree with the autograd oracle -> with the C backward."""
+    sc = util.make_scene(6, image_size=16, views=1, color_sh_degree=1, feature_channels=2, sigma_px=(1.0, 3.0), opacity_scale=1.0)
+    bi = util.boundary_inputs(sc, 16, 16, bg=(0.1, 0.2, 0.3))
+    c = bi["cams"]
+    d = lambda t: t.double().clone().requires_grad_(True)
+    means, cov6, opac, shs, feats = d(bi["means"][0]), d(bi["cov6"][0]), d(bi["opac"]), d(bi["shs"]), d(bi["features"][0])
+
+    def f(means, cov6, opac, shs, feats):
+        color, feat, mask, depth, _ = to.rasterize(16, 16, float(c.tan_fov_x[0]), float(c.tan_fov_y[0]), bi["bg"][0].double(),
+                                                   c.view_matrix[0].double(), c.full_projection[0].double(), c.campos[0].double(),
+                                                   bi["sh_degree"], means, cov6, opac, shs, None, feats)
+        return torch.cat([color.flatten(), feat.flatten(), mask.flatten(), depth.flatten()])
+
+    assert torch.autograd.gradcheck(f, (means, cov6, opac, shs, feats), eps=1e-6, atol=1e-5, rtol=1e-3, nondet_tol=0)

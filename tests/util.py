@@ -146,3 +146,24 @@ class HipRun:
         n = self.d.num_views * self.d.height * self.d.width
         return self._view(self.img, self.layout.img_final_T, n * 4, torch.float32).cpu().numpy().reshape(
             self.d.num_views, self.d.height, self.d.width)
+
+
+def oracle_rasterize_views(views, image_height, image_width, sh_degree, means3D, cov3D_precomp, opacities,
+                           shs=None, colors_precomp=None, features=None, means2D=None, debug=False):
+    """CPU stand-in with the signature of latentsplat_amd.rasterizer.rasterize_views, served by the
+    oracle.  TESTS ONLY: lets the not-gpu suite pin the host-side wrapper logic."""
+    V = views.shape[0]
+    n = lambda t: None if t is None else t.detach().cpu().float().numpy()
+    per_view = lambda t, base, v: None if t is None else (t[v] if t.dim() == base + 1 else t)
+    cols, feats, masks, depths, radii = [], [], [], [], []
+    for v in range(V):
+        vw = views[v].detach().cpu()
+        view = orc.View(image_height, image_width, float(vw[35]), float(vw[36]), vw[37:40].numpy(),
+                        vw[0:16].numpy().reshape(4, 4), vw[16:32].numpy().reshape(4, 4), vw[32:35].numpy(), sh_degree)
+        o = orc.forward(view, n(per_view(means3D, 2, v)), n(per_view(cov3D_precomp, 2, v)),
+                        n(per_view(opacities, 2, v)), n(per_view(shs, 3, v)), n(per_view(colors_precomp, 2, v)),
+                        n(per_view(features, 2, v)), keep_intermediates=False)
+        cols.append(o["color"]); feats.append(o["feature"]); masks.append(o["mask"]); depths.append(o["depth"])
+        radii.append(o["radii"])
+    st = lambda xs: None if xs[0] is None else torch.from_numpy(np.stack(xs))
+    return st(cols), st(feats), st(masks), st(depths), st(radii)
