@@ -225,14 +225,8 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
     if (d->feat_channels > 0 && !gin->features) return LSR_ENULL;
     if (num_pairs > 0 && !bin_ws) return LSR_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    const size_t V = d->num_views, G = d->num_gaussians;
-    // zero every accumulation target of the compositing backward
+    // zero the packed gradient records the compositing backward accumulates into
     LSR_HIP(hipMemsetAsync(grad_ws, 0, grad_layout(*d).total, s));
-    LSR_HIP(hipMemsetAsync(gin->opacities, 0, (d->vs_opac ? V : 1) * G * sizeof(float), s));
-    if (d->feat_channels > 0)
-        LSR_HIP(hipMemsetAsync(gin->features, 0, (d->vs_feat ? V : 1) * G * d->feat_channels * sizeof(float), s));
-    if (d->color_mode == LSR_COLOR_PRECOMP)
-        LSR_HIP(hipMemsetAsync(gin->color, 0, (d->vs_color ? V : 1) * G * 3 * sizeof(float), s));
     if (num_pairs > 0)
         LSR_STAGE("render_backward", s, launch_render_backward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs,
                                        (const char *)img_ws, *gout, (char *)grad_ws, *gin, s));

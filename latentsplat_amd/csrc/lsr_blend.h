@@ -86,4 +86,52 @@ __device__ __forceinline__ float wave_sum_to_row3(float v) {
     return v;
 }
 
+// ---- transposed wave reduction ------------------------------------------------------------
+// Sums 16 per-lane values across the 64 lanes of a wave in ~2 instructions per value instead of
+// 6: every butterfly step halves the number of values a lane still carries.  Afterwards lane l
+// holds the wave-wide total of slot (l >> 2) (replicated over its quad), so ONE atomic
+// instruction with 16 active lanes can add a whole 64-byte gradient record.
+//   step A  v_permlane32_swap : lanes 0-31 keep slot i, lanes 32-63 keep slot i+8
+//   step B  v_permlane16_swap : even rows keep slot i, odd rows slot i+4
+//   step C  DPP row_ror:8     : lane bit 3 selects slot i / i+2
+//   step D  DPP row_half_mirror: lane bit 2 selects slot i / i+1
+//   then the two quad_perm steps finish the sum inside each quad.
+// LIVE is a compile-time bitmask of slots that can be non-zero; dead pairs cost nothing.
+__device__ __forceinline__ float f_from_u(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ unsigned u_from_f(float f) { return __builtin_bit_cast(unsigned, f); }
+
+template <uint32_t LIVE>
+__device__ __forceinline__ float wave_reduce16_transposed(const float (&v)[16], int lane) {
+    float r[8], s[4], t[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if ((LIVE >> i & 1u) || (LIVE >> (i + 8) & 1u)) {
+            const auto w = __builtin_amdgcn_permlane32_swap(u_from_f(v[i]), u_from_f(v[i + 8]), false, false);
+            r[i] = f_from_u(w[0]) + f_from_u(w[1]);
+        } else r[i] = 0.0f;
+    }
+    constexpr uint32_t LA = (LIVE | (LIVE >> 8)) & 0xFFu;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if ((LA >> i & 1u) || (LA >> (i + 4) & 1u)) {
+            const auto w = __builtin_amdgcn_permlane16_swap(u_from_f(r[i]), u_from_f(r[i + 4]), false, false);
+            s[i] = f_from_u(w[0]) + f_from_u(w[1]);
+        } else s[i] = 0.0f;
+    }
+    constexpr uint32_t LB = (LA | (LA >> 4)) & 0xFu;
+    const bool b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if ((LB >> i & 1u) || (LB >> (i + 2) & 1u)) {
+            const float keep = b3 ? s[i + 2] : s[i], send = b3 ? s[i] : s[i + 2];
+            t[i] = keep + f_from_u(__builtin_amdgcn_update_dpp(0, u_from_f(send), 0x128, 0xf, 0xf, false));  // row_ror:8
+        } else t[i] = 0.0f;
+    }
+    const float keep = b2 ? t[1] : t[0], send = b2 ? t[0] : t[1];
+    float u = keep + f_from_u(__builtin_amdgcn_update_dpp(0, u_from_f(send), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    LSR_DPP_ADD(u, 0xB1, 0xf);  // quad_perm [1,0,3,2]
+    LSR_DPP_ADD(u, 0x4E, 0xf);  // quad_perm [2,3,0,1]
+    return u;
+}
+
 }  // namespace lsr

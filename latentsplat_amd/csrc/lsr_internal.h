@@ -25,9 +25,18 @@ struct ImgLayout {
 struct BinLayout {
     size_t keys, point_list, tmp, total;
 };
+// One packed gradient record per (view, Gaussian), accumulated by the compositing backward:
+//   [0] d/dx_pix [1] d/dy_pix [2] d/dA [3] d/dB [4] d/dC (conic) [5] d/dopacity [6] d/dz [7] -
+//   [8 + c] d/d payload channel c  (rgb first when colour is rendered, then features)
+// 16 floats (one 64-byte line) for <= 8 payload channels, 32 for <= 24, 64 beyond.
 struct GradLayout {
-    size_t dxy, dconic, drgb, dz, total;  // float2, float4 (3 used), float4 (3 used), float
+    size_t rec, total;
+    int rec_floats;
 };
+inline int grad_rec_floats(const lsr_dims &d) {
+    const int nch = (d.color_mode != LSR_COLOR_NONE ? 3 : 0) + d.feat_channels;
+    return nch <= 8 ? 16 : (nch <= 24 ? 32 : 64);
+}
 
 inline int tiles_x(const lsr_dims &d) { return (d.width + LSR_TILE - 1) / LSR_TILE; }
 inline int tiles_y(const lsr_dims &d) { return (d.height + LSR_TILE - 1) / LSR_TILE; }
@@ -71,12 +80,9 @@ inline BinLayout bin_layout(const lsr_dims &d, int64_t num_pairs, int32_t max_ti
 inline GradLayout grad_layout(const lsr_dims &d) {
     GradLayout L;
     const size_t VG = (size_t)d.num_views * (size_t)d.num_gaussians;
-    size_t o = 0;
-    L.dxy = o; o = align_up(o + VG * 8);
-    L.dconic = o; o = align_up(o + VG * 16);
-    L.dz = o; o = align_up(o + VG * 4);
-    L.drgb = o; o = align_up(o + (d.color_mode == LSR_COLOR_SH ? VG * 16 : 0));
-    L.total = o;
+    L.rec_floats = grad_rec_floats(d);
+    L.rec = 0;
+    L.total = align_up(VG * (size_t)L.rec_floats * 4 + 256);
     return L;
 }
 

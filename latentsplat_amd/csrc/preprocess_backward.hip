@@ -3,6 +3,8 @@
 //   conic -> 2D covariance -> 3D covariance (6 packed values) and -> view-space mean (via J),
 //   NDC mean -> world mean (perspective divide),  rgb -> SH coefficients and view direction,
 //   view z -> world mean (depth output).
+// Also scatters the per-(view, Gaussian) opacity / feature / precomputed-colour gradients from the
+// packed records to the caller's tensors.
 // One thread owns one Gaussian for ALL views, so inputs shared between views (stride 0) get their
 // gradients summed in registers / thread-private read-modify-write, without atomics.
 // Spec: SURVEY.md Appendix A.6.
@@ -16,10 +18,8 @@ struct PreBwdParams {
     lsr_inputs in;
     const int32_t *radii;
     const float4 *rgb;      // .w = clamp bits (SH mode)
-    const float2 *dxy;      // pixel-space
-    const float4 *dconic;
-    const float *dz;
-    const float4 *drgb;
+    const float *rec;       // packed gradient records (lsr_internal.h GradLayout)
+    int rec_floats;
     lsr_in_grads g;
 };
 
@@ -32,9 +32,24 @@ k_preprocess_bwd(PreBwdParams p) {
     const int V = d.num_views;
     const bool sh_mode = d.color_mode == LSR_COLOR_SH;
     const int nb = (d.sh_degree + 1) * (d.sh_degree + 1);
-    float am[3] = {0, 0, 0}, ac[6] = {0, 0, 0, 0, 0, 0};  // accumulators for shared inputs
+    float am[3] = {0, 0, 0}, ac[6] = {0, 0, 0, 0, 0, 0}, aop = 0.0f;  // accumulators for shared inputs
+    const int coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
     for (int v = 0; v < V; ++v) {
         const size_t o = (size_t)v * G + i;
+        const float *rc = p.rec + o * p.rec_floats;
+        const float4 r0 = *(const float4 *)rc, r1 = *(const float4 *)(rc + 4);  // gx gy gA gB | gC go gz -
+        // opacity / features / precomputed colours: plain pass-through of the record
+        if (d.vs_opac != 0) p.g.opacities[(size_t)v * d.vs_opac + i] = r1.y; else aop += r1.y;
+        if (d.feat_channels > 0) {
+            float *gf = p.g.features + (size_t)v * d.vs_feat + (size_t)i * d.feat_channels;
+            const bool first = d.vs_feat != 0 || v == 0;
+            for (int c = 0; c < d.feat_channels; ++c) gf[c] = first ? rc[8 + coff + c] : gf[c] + rc[8 + coff + c];
+        }
+        if (d.color_mode == LSR_COLOR_PRECOMP) {
+            float *gcp = p.g.color + (size_t)v * d.vs_color + 3 * (size_t)i;
+            const bool first = d.vs_color != 0 || v == 0;
+            for (int c = 0; c < 3; ++c) gcp[c] = first ? rc[8 + c] : gcp[c] + rc[8 + c];
+        }
         float gm[3] = {0, 0, 0}, gc[6] = {0, 0, 0, 0, 0, 0};
         float m2x = 0.0f, m2y = 0.0f;
         const bool vis = p.radii[o] > 0;
@@ -78,7 +93,7 @@ k_preprocess_bwd(PreBwdParams p) {
             const float b = MS[0][0] * M[1][0] + MS[0][1] * M[1][1] + MS[0][2] * M[1][2];
             const float c = MS[1][0] * M[1][0] + MS[1][1] * M[1][1] + MS[1][2] * M[1][2] + LSR_LOWPASS;
             const float det = a * c - b * b;
-            const float4 gcon = p.dconic[o];
+            const float4 gcon = make_float4(r0.z, r0.w, r1.x, 0.0f);
             float dL_da = 0.0f, dL_db = 0.0f, dL_dc = 0.0f;
             if (det != 0.0f) {
                 const float d2 = 1.0f / (det * det);
@@ -110,7 +125,7 @@ k_preprocess_bwd(PreBwdParams p) {
             const float dL_dty = ym * (-focal_y * itz2) * dJ12;
             float dL_dtz = -focal_x * itz2 * dJ00 - focal_y * itz2 * dJ11 +
                            (2.0f * focal_x * tx) * itz3 * dJ02 + (2.0f * focal_y * ty) * itz3 * dJ12;
-            dL_dtz += p.dz[o];
+            dL_dtz += r1.z;
             // t = Wr p + trans  =>  dL/dp[cc] = sum_k Wr[k][cc] dt[k] = vm[4cc + k] dt[k]
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc)
@@ -121,9 +136,8 @@ k_preprocess_bwd(PreBwdParams p) {
             const float h3 = pm[3] * p0 + pm[7] * p1 + pm[11] * p2 + pm[15];
             const float m_w = 1.0f / (h3 + 0.0000001f);
             const float mul1 = h0 * m_w * m_w, mul2 = h1 * m_w * m_w;
-            const float2 gp = p.dxy[o];
-            m2x = gp.x * (0.5f * d.width);   // d pixel / d ndc
-            m2y = gp.y * (0.5f * d.height);
+            m2x = r0.x * (0.5f * d.width);   // d pixel / d ndc
+            m2y = r0.y * (0.5f * d.height);
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc)
                 gm[cc] += (pm[4 * cc + 0] * m_w - pm[4 * cc + 3] * mul1) * m2x +
@@ -141,9 +155,8 @@ k_preprocess_bwd(PreBwdParams p) {
                 const float *sh = p.in.color + (size_t)v * d.vs_color + (size_t)i * d.sh_coeffs * 3;
                 const float4 col = p.rgb[o];
                 const uint32_t clampbits = __float_as_uint(col.w);
-                const float4 gr = p.drgb[o];
-                const float gcol[3] = {(clampbits & 1u) ? 0.0f : gr.x, (clampbits & 2u) ? 0.0f : gr.y,
-                                       (clampbits & 4u) ? 0.0f : gr.z};
+                const float gcol[3] = {(clampbits & 1u) ? 0.0f : rc[8], (clampbits & 2u) ? 0.0f : rc[9],
+                                       (clampbits & 4u) ? 0.0f : rc[10]};
                 float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
                 for (int k = 0; k < nb; ++k) {
 #pragma unroll
@@ -191,6 +204,7 @@ k_preprocess_bwd(PreBwdParams p) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) o6[k] = ac[k];
     }
+    if (d.vs_opac == 0) p.g.opacities[i] = aop;
 }
 
 hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
@@ -202,8 +216,7 @@ hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, c
     PreBwdParams p;
     p.d = d; p.in = in; p.radii = radii;
     p.rgb = (const float4 *)(geom + L.rgb);
-    p.dxy = (const float2 *)(grad + R.dxy); p.dconic = (const float4 *)(grad + R.dconic);
-    p.dz = (const float *)(grad + R.dz); p.drgb = (const float4 *)(grad + R.drgb);
+    p.rec = (const float *)(grad + R.rec); p.rec_floats = R.rec_floats;
     p.g = gin;
     prof_begin(kStPreprocessBwd, s);
     hipLaunchKernelGGL(k_preprocess_bwd, dim3((d.num_gaussians + 255) / 256), dim3(256), 0, s, p);

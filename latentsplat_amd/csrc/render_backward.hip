@@ -4,16 +4,18 @@
 // Per (entry, pixel): recompute alpha with the forward's exact arithmetic, divide it out of the
 // running transmittance, form dL/dalpha from the colour accumulated behind the entry, and emit
 //   dL/d(x,y)_pixel, dL/d(A,B,C) conic, dL/d opacity, dL/d payload (rgb / features), dL/d z.
-// Per (entry, wave): contributions of the wave's 64*PXL pixels are summed with a DPP butterfly
-// (no LDS traffic) and ONE lane issues the float atomics for the (tile, Gaussian) pair.
+// Per (entry, wave): contributions of the wave's 64*PXL pixels are summed with the transposed
+// butterfly of lsr_blend.h (permlane swaps + DPP, no LDS traffic), which leaves the total of
+// gradient slot s in lane 4s; ONE atomic instruction then adds the whole 64-byte gradient record
+// of the (view, Gaussian) (lsr_internal.h GradLayout).
 // Spec: SURVEY.md Appendix A.6.
 #include "lsr_blend.h"
 
 namespace lsr {
 
 struct RenderBwdParams {
-    int H, W, gx, T, G, C, has_color, color_direct;  // color_direct: rgb grads go straight to gin.color
-    int64_t vs_feat, vs_opac, vs_color;
+    int H, W, gx, T, G, C, has_color;
+    int64_t vs_feat;
     const float *views;
     const float4 *q0, *q1, *rgb;
     const float *features;
@@ -21,13 +23,8 @@ struct RenderBwdParams {
     const float *final_T;
     const uint32_t *n_contrib;
     const float *g_color, *g_feat, *g_mask, *g_depth;  // dL/d outputs (any may be NULL)
-    float2 *dxy;        // [V*G] pixel-space gradient of the projected mean
-    float4 *dconic;     // [V*G] (A, B, C, -)
-    float *dz;          // [V*G]
-    float4 *drgb;       // [V*G] (SH mode)
-    float *d_opac;      // gin.opacities
-    float *d_feat;      // gin.features
-    float *d_color;     // gin.color (PRECOMP mode)
+    float *rec;         // [V*G][rec_floats] packed gradient records (zeroed by the caller)
+    int rec_floats;
 };
 
 __device__ __forceinline__ void atomic_add_f32(float *addr, float v) { unsafeAtomicAdd(addr, v); }
@@ -192,38 +189,29 @@ k_render_bwd(RenderBwdParams p) {
                 go = __builtin_fmaf(Gv, dL_dalpha, go);
             }
             if (!__any(any_valid)) continue;
-#ifdef LSR_ABLATE_REDUCE
-            asm volatile("" ::"v"(gx), "v"(gy), "v"(gA), "v"(gB), "v"(gC), "v"(go), "v"(gpay[0]), "v"(gpay[1]), "v"(gpay[2]), "v"(gpay[3]));
-            continue;
-#endif
-            gx = wave_sum_to_row3(gx); gy = wave_sum_to_row3(gy);
-            gA = wave_sum_to_row3(gA); gB = wave_sum_to_row3(gB); gC = wave_sum_to_row3(gC);
-            go = wave_sum_to_row3(go);
-            if (DEPTH_GRAD) gz = wave_sum_to_row3(gz);
+            // ---- wave-wide sums, 16 record slots at a time; lane 4s ends up with slot s ----
+            float *rec = p.rec + (size_t)(vG + s_gid[j]) * p.rec_floats;
+            {
+                constexpr uint32_t LIVE = 0x3Fu | (DEPTH_GRAD ? 0x40u : 0u) | (((1u << (NCHP < 8 ? NCHP : 8)) - 1u) << 8);
+                const float v16[16] = {gx, gy, gA, gB, gC, go, DEPTH_GRAD ? gz : 0.0f, 0.0f,
+                                       gpay[0], gpay[1], gpay[2], gpay[3],
+                                       NCHP > 4 ? gpay[4 % NCHP] : 0.0f, NCHP > 4 ? gpay[5 % NCHP] : 0.0f,
+                                       NCHP > 4 ? gpay[6 % NCHP] : 0.0f, NCHP > 4 ? gpay[7 % NCHP] : 0.0f};
+                const float tot = wave_reduce16_transposed<LIVE>(v16, lane);
+                const int slot = lane >> 2;
+                if ((lane & 3) == 0 && (LIVE >> slot & 1u) && (slot < 8 || slot - 8 < coff + p.C))
+                    atomic_add_f32(rec + slot, tot);
+            }
+            if (NCHP > 8) {
 #pragma unroll
-            for (int c = 0; c < NCHP; ++c)
-                if (c < coff + p.C) gpay[c] = wave_sum_to_row3(gpay[c]);
-#ifdef LSR_ABLATE_ATOMICS
-            asm volatile("" ::"v"(gx), "v"(gy), "v"(gA), "v"(gB), "v"(gC), "v"(go), "v"(gpay[0]), "v"(gpay[1]), "v"(gpay[2]), "v"(gpay[3]));
-            continue;
-#endif
-            if (lane == 63) {
-                const uint32_t g = s_gid[j];
-                float *dxy = (float *)&p.dxy[vG + g];
-                atomic_add_f32(dxy, gx); atomic_add_f32(dxy + 1, gy);
-                float *dcn = (float *)&p.dconic[vG + g];
-                atomic_add_f32(dcn, gA); atomic_add_f32(dcn + 1, gB); atomic_add_f32(dcn + 2, gC);
-                atomic_add_f32(p.d_opac + (size_t)v * p.vs_opac + g, go);
-                if (DEPTH_GRAD) atomic_add_f32(p.dz + vG + g, gz);
-                if (p.has_color) {
-                    float *dc = p.color_direct ? p.d_color + (size_t)v * p.vs_color + 3 * (size_t)g
-                                               : (float *)&p.drgb[vG + g];
-                    atomic_add_f32(dc, gpay[0]); atomic_add_f32(dc + 1, gpay[1]); atomic_add_f32(dc + 2, gpay[2]);
+                for (int grp = 1; grp * 16 - 8 < NCHP; ++grp) {   // payload channels 16*grp-8 .. 16*grp+7
+                    float v16[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v16[i] = (16 * grp - 8 + i) < NCHP ? gpay[(16 * grp - 8 + i) % NCHP] : 0.0f;
+                    const float tot = wave_reduce16_transposed<0xFFFFu>(v16, lane);
+                    const int ch = 16 * grp - 8 + (lane >> 2);
+                    if ((lane & 3) == 0 && ch < coff + p.C) atomic_add_f32(rec + 8 + ch, tot);
                 }
-                float *df = p.d_feat + (size_t)v * p.vs_feat + (size_t)g * p.C;
-#pragma unroll
-                for (int c = 0; c < NCHP; ++c)
-                    if (c >= coff && c - coff < p.C) atomic_add_f32(df + (c - coff), gpay[c]);
             }
         }
         __syncthreads();
@@ -252,8 +240,7 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     RenderBwdParams p;
     p.H = d.height; p.W = d.width; p.gx = tiles_x(d); p.T = (int)num_tiles(d); p.G = d.num_gaussians;
     p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE;
-    p.color_direct = d.color_mode == LSR_COLOR_PRECOMP;
-    p.vs_feat = d.vs_feat; p.vs_opac = d.vs_opac; p.vs_color = d.vs_color;
+    p.vs_feat = d.vs_feat;
     p.views = in.views;
     p.q0 = (const float4 *)(geom + L.q0); p.q1 = (const float4 *)(geom + L.q1);
     p.rgb = (const float4 *)(geom + L.rgb);
@@ -262,9 +249,8 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     p.point_list = (const uint32_t *)(bin + B.point_list);
     p.final_T = (const float *)(img + I.final_T); p.n_contrib = (const uint32_t *)(img + I.n_contrib);
     p.g_color = gout.color; p.g_feat = gout.feature; p.g_mask = gout.mask; p.g_depth = gout.depth;
-    p.dxy = (float2 *)(grad + R.dxy); p.dconic = (float4 *)(grad + R.dconic);
-    p.dz = (float *)(grad + R.dz); p.drgb = (float4 *)(grad + R.drgb);
-    p.d_opac = gin.opacities; p.d_feat = gin.features; p.d_color = gin.color;
+    p.rec = (float *)(grad + R.rec); p.rec_floats = R.rec_floats;
+    (void)gin;
     const int nch = (p.has_color ? 3 : 0) + d.feat_channels;
     const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));
     const int pxl = pick_pxl_bwd(nchp, (int64_t)p.T * d.num_views);
