@@ -3,7 +3,9 @@
 // is depth-sorted inside LDS by its own workgroup.
 //
 //   k_tile_scan : exclusive scan of the per-tile pair counts (V*T entries) -> tile_start,
-//                 total pair count and the longest list (header[0], header[1]).
+//                 total pair count and the longest list (header[0], header[1]); also emits the
+//                 (view,tile) ids ordered longest-list-first (counting sort) — the work queue
+//                 order of the compositing kernels (longest-processing-time-first balancing).
 //   k_scatter   : every visible Gaussian writes (depth_bits<<32 | index) into each tile segment
 //                 it overlaps.  Slots come from a two-level reservation: LDS counters per block,
 //                 then ONE global atomic per (block, tile).
@@ -18,7 +20,8 @@ namespace lsr {
 constexpr int kScanThreads = 1024;
 
 __global__ void __launch_bounds__(kScanThreads)
-k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *header, int N) {
+k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *header,
+            uint32_t *__restrict__ order, int N) {
     __shared__ uint32_t s_sum[kScanThreads];
     __shared__ uint32_t s_max[kScanThreads];
     const int tid = threadIdx.x;
@@ -38,6 +41,31 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
     uint32_t run = s_sum[tid] - sum;  // exclusive prefix of this thread's chunk
     for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
     if (tid == kScanThreads - 1) { start[N] = s_sum[tid]; header[0] = s_sum[tid]; header[1] = s_max[tid]; }
+    // ---- longest-first order: counting sort on kScanThreads length classes ----
+    const uint32_t maxc = s_max[kScanThreads - 1];
+    __syncthreads();
+    s_sum[tid] = 0;
+    __syncthreads();
+    const uint64_t scale = maxc + 1u;
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t b = kScanThreads - 1 - (uint32_t)(((uint64_t)count[i] * kScanThreads) / scale);
+        atomicAdd(&s_sum[b], 1u);
+    }
+    __syncthreads();
+    const uint32_t mine = s_sum[tid];
+    for (int off = 1; off < kScanThreads; off <<= 1) {
+        uint32_t a = 0;
+        if (tid >= off) a = s_sum[tid - off];
+        __syncthreads();
+        s_sum[tid] += a;
+        __syncthreads();
+    }
+    s_max[tid] = s_sum[tid] - mine;  // exclusive start of class tid
+    __syncthreads();
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t b = kScanThreads - 1 - (uint32_t)(((uint64_t)count[i] * kScanThreads) / scale);
+        order[atomicAdd(&s_max[b], 1u)] = (uint32_t)i;
+    }
 }
 
 hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s) {
@@ -46,7 +74,7 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s) {
     prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
                        (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
-                       (uint32_t *)(geom + L.header), N);
+                       (uint32_t *)(geom + L.header), (uint32_t *)(geom + L.tile_order), N);
     prof_end(kStTileScan, s);
     return hipGetLastError();
 }

@@ -17,7 +17,7 @@ namespace lsr {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t header, q0, q1, rect, rgb, tile_count, tile_start, tile_cursor, total;
+    size_t header, q0, q1, rect, rgb, tile_count, tile_start, tile_cursor, tile_order, total;
 };
 struct ImgLayout {
     size_t final_T, n_contrib, total;
@@ -55,6 +55,7 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     L.tile_count = o; o = align_up(o + VT * 4);
     L.tile_cursor = o; o = align_up(o + VT * 4);   // adjacent to tile_count: one memset clears both
     L.tile_start = o; o = align_up(o + (VT + 1) * 4);
+    L.tile_order = o; o = align_up(o + VT * 4);   // (view,tile) ids, longest list first
     L.total = o;
     return L;
 }
@@ -84,6 +85,16 @@ inline GradLayout grad_layout(const lsr_dims &d) {
     L.rec = 0;
     L.total = align_up(VG * (size_t)L.rec_floats * 4 + 256);
     return L;
+}
+
+// Multiplier for the tile-order permutation t -> (t * stride) % T: about 0.618 T, coprime with T.
+inline int coprime_stride(int T) {
+    if (T <= 2) return 1;
+    auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+    int s = (int)(0.6180339887 * T);
+    if (s < 1) s = 1;
+    while (gcd(s, T) != 1) ++s;
+    return s % T ? s % T : 1;
 }
 
 // ---- optional per-stage hipEvent timing (api.hip); no-ops unless lsr_profile_enable(1) ----

@@ -2,12 +2,30 @@
 // Outputs colour (+ bg), features (bg 0), mask = 1 - T, depth = sum alpha T z, and keeps
 // final_T / n_contrib for the backward pass.  Spec: SURVEY.md Appendix A.3 step 7 + A.4.
 // Work decomposition and the lossless quadrant culling are described in lsr_blend.h.
+#include <stdio.h>
+
+#include <vector>
+
 #include "lsr_blend.h"
 
 namespace lsr {
 
+// Workgroups are 4 independent waves (one per SIMD of a CU): the waves never synchronise with each
+// other, the grouping only makes the dispatcher spread them evenly over the SIMDs.
+constexpr int kWavesPerBlock = 4;
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wave execute in order; this only stops the compiler from moving LDS
+    // accesses across the staging / consuming phases and drains the wave's own LDS queue.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 struct RenderFwdParams {
-    int H, W, gx, T, G, C, has_color;
+    int H, W, gx, T, G, C, has_color, num_items;
+    const uint32_t *tile_order;   // (view*T + tile), longest list first
+    uint32_t *queue;              // work-queue head (zeroed per forward)
+    unsigned long long *trace;    // debug (LSR_TRACE): per item {start clk, end clk, hw id, entries}
     int64_t vs_feat;
     const float *views;
     const float4 *q0, *q1, *rgb;
@@ -18,17 +36,36 @@ struct RenderFwdParams {
     uint32_t *n_contrib;
 };
 
-template <int NCHP, int PXL>
-__global__ void __launch_bounds__(LSR_WAVE)
+template <int NCHP, int PXL, int UNR>
+__global__ void __launch_bounds__(LSR_WAVE * kWavesPerBlock)
 k_render_fwd(RenderFwdParams p) {
     constexpr int NW = 4 / PXL;  // waves (= workgroups) per tile
-    __shared__ float4 s_q0[LSR_WAVE];
-    __shared__ float4 s_q1[LSR_WAVE];
-    __shared__ float4 s_pay[LSR_WAVE][NCHP / 4];
+    __shared__ float4 s_q0_all[kWavesPerBlock][LSR_WAVE + 1];   // slot 64: null record (alpha == 0) pads partial groups
+    __shared__ float4 s_q1_all[kWavesPerBlock][LSR_WAVE + 1];
+    __shared__ float4 s_pay_all[kWavesPerBlock][LSR_WAVE + 1][NCHP / 4];
 
-    const int lane = threadIdx.x;
-    const int tile = blockIdx.x / NW, part = blockIdx.x % NW;
-    const int v = blockIdx.y;
+    const int lane = threadIdx.x & (LSR_WAVE - 1);
+    const int wid = threadIdx.x / LSR_WAVE;
+    float4 *s_q0 = s_q0_all[wid], *s_q1 = s_q1_all[wid];
+    float4 (*s_pay)[NCHP / 4] = s_pay_all[wid];
+    if (lane == 0) {
+        s_q0[LSR_WAVE] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_q1[LSR_WAVE] = make_float4(0.0f, -INFINITY, 0.0f, 0.0f);  // log2(opacity) = -inf
+#pragma unroll
+        for (int c4 = 0; c4 < NCHP / 4; ++c4) s_pay[LSR_WAVE][c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    // Persistent wave: pulls (tile, quadrant-set) items from a global queue, longest tile lists
+    // first, until the queue is empty.  Dynamic LPT scheduling: a static one-item-per-wave launch
+    // leaves SIMDs idle for ~1/3 of the kernel because list lengths vary (measured).
+    for (;;) {
+    uint32_t item = 0;
+    if (lane == 0) item = atomicAdd(p.queue, 1u);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= (uint32_t)p.num_items) break;
+    const unsigned long long t_begin = p.trace ? __builtin_readcyclecounter() : 0ull;
+    const uint32_t vt = p.tile_order[item / NW];
+    const int tile = (int)(vt % (uint32_t)p.T), part = (int)(item % NW);
+    const int v = (int)(vt / (uint32_t)p.T);
     const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE;
     const size_t vG = (size_t)v * p.G;
     const uint32_t start = p.tile_start[(size_t)v * p.T + tile];
@@ -38,25 +75,28 @@ k_render_fwd(RenderFwdParams p) {
 
     float pxf[PXL], pyf[PXL], Tr[PXL], accd[PXL];
     float acc[PXL][NCHP];
-    uint32_t last[PXL];
-    bool done[PXL], inside[PXL];
+    uint32_t stop_pos[PXL];
+    // Per-pixel "finished" flags live in scalar registers as 64-bit lane masks, so the skip /
+    // blend / stop decisions are SALU mask algebra instead of per-lane VALU selects.
+    uint64_t done[PXL];
+    bool inside[PXL];
 #pragma unroll
     for (int k = 0; k < PXL; ++k) {
         const int q = owned_quadrant<PXL>(part, k);
         const int px = tx0 + 8 * (q & 1) + (lane & 7), py = ty0 + 8 * (q >> 1) + (lane >> 3);
         pxf[k] = (float)px; pyf[k] = (float)py;
         inside[k] = px < p.W && py < p.H;
-        done[k] = !inside[k];
-        Tr[k] = 1.0f; accd[k] = 0.0f; last[k] = 0;
+        done[k] = __ballot(!inside[k]);
+        Tr[k] = 1.0f; accd[k] = 0.0f; stop_pos[k] = 0;
 #pragma unroll
         for (int c = 0; c < NCHP; ++c) acc[k][c] = 0.0f;
     }
 
     for (uint32_t base = start; base < end; base += LSR_WAVE) {
-        bool all_done = true;
+        uint64_t all_done = ~0ull;
 #pragma unroll
-        for (int k = 0; k < PXL; ++k) all_done = all_done && done[k];
-        if (__all(all_done)) break;
+        for (int k = 0; k < PXL; ++k) all_done &= done[k];
+        if (all_done == ~0ull) break;
 
         // ---- stage up to 64 list entries (one per lane) ----
         const uint32_t e = base + lane;
@@ -85,41 +125,67 @@ k_render_fwd(RenderFwdParams p) {
                     s_pay[lane][c4] = make_float4(pay[4 * c4], pay[4 * c4 + 1], pay[4 * c4 + 2], pay[4 * c4 + 3]);
             }
         }
-        uint64_t todo = __ballot(m != 0);
-        __syncthreads();  // single-wave workgroup: orders the LDS writes above before the reads below
+        // per owned quadrant: which staged entries can touch it (wave-uniform 64-bit masks)
+        uint64_t qbits[PXL];
+#pragma unroll
+        for (int k = 0; k < PXL; ++k) qbits[k] = __ballot((m >> owned_quadrant<PXL>(part, k)) & 1u);
+        wave_lds_fence();  // staged records are visible to this wave's reads below
 
-        while (todo) {
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const float4 a = s_q0[j], b = s_q1[j];
-            const uint32_t mj = __builtin_amdgcn_readfirstlane(__float_as_uint(b.w));
-            const uint32_t pos = base - start + (uint32_t)j + 1u;
-            float pay[NCHP];
+        // Walk each quadrant's entries front to back, UNR at a time: the alpha evaluations of the
+        // UNR entries are independent (instruction-level parallelism hides LDS / exp / compare
+        // latency); only the short transmittance update chain is serial.
 #pragma unroll
-            for (int c4 = 0; c4 < NCHP / 4; ++c4) {
-                const float4 t = s_pay[j][c4];
-                pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
-            }
+        for (int k = 0; k < PXL; ++k) {
+            uint64_t bits = qbits[k];
+            while (bits) {
+                int jj[UNR];
 #pragma unroll
-            for (int k = 0; k < PXL; ++k) {
-                if (!(mj & (1u << owned_quadrant<PXL>(part, k)))) continue;  // wave-uniform
-                const float dx = a.x - pxf[k], dy = a.y - pyf[k];
-                const float ex = blend_exponent(dx, dy, a.z, a.w, b.x, b.y);
-                const float alpha = fminf(LSR_ALPHA_MAX, fast_exp2(ex));
-                const bool live = !done[k] && (ex <= b.y) && (alpha >= LSR_ALPHA_MIN);
-                const float test_T = __builtin_fmaf(-Tr[k], alpha, Tr[k]);
-                const bool stop = live && (test_T < LSR_T_EPS);
-                const bool blend = live && !stop;
-                const float w = blend ? alpha * Tr[k] : 0.0f;
+                for (int u = 0; u < UNR; ++u) {
+                    jj[u] = bits ? __builtin_ctzll(bits) : LSR_WAVE;  // slot 64 = null record
+                    bits &= bits - 1;
+                }
+                float4 a[UNR], b[UNR];
+                float pay[UNR][NCHP];
 #pragma unroll
-                for (int c = 0; c < NCHP; ++c) acc[k][c] = __builtin_fmaf(pay[c], w, acc[k][c]);
-                accd[k] = __builtin_fmaf(b.z, w, accd[k]);
-                Tr[k] = blend ? test_T : Tr[k];
-                last[k] = blend ? pos : last[k];
-                done[k] = done[k] || stop;
+                for (int u = 0; u < UNR; ++u) {
+                    a[u] = s_q0[jj[u]]; b[u] = s_q1[jj[u]];
+#pragma unroll
+                    for (int c4 = 0; c4 < NCHP / 4; ++c4) {
+                        const float4 t = s_pay[jj[u]][c4];
+                        pay[u][4 * c4] = t.x; pay[u][4 * c4 + 1] = t.y; pay[u][4 * c4 + 2] = t.z; pay[u][4 * c4 + 3] = t.w;
+                    }
+                }
+                float alpha[UNR];
+                uint64_t ok[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const float dx = a[u].x - pxf[k], dy = a[u].y - pyf[k];
+                    const float ex = blend_exponent(dx, dy, a[u].z, a[u].w, b[u].x, b[u].y);
+                    alpha[u] = fminf(LSR_ALPHA_MAX, fast_exp2(ex));
+                    // skip if power > 0 or alpha < 1/255 (NaN-safe: comparisons are "keep" tests)
+                    ok[u] = __ballot(ex <= b[u].y) & __ballot(alpha[u] >= LSR_ALPHA_MIN);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const float aT = alpha[u] * Tr[k];
+                    const float tT = Tr[k] - aT;
+                    const uint64_t live = ok[u] & ~done[k];
+                    const uint64_t room = __ballot(tT >= LSR_T_EPS);
+                    const uint64_t blend = live & room, stop = live & ~room;
+                    const float w = __builtin_amdgcn_inverse_ballot_w64(blend) ? aT : 0.0f;
+#pragma unroll
+                    for (int c = 0; c < NCHP; ++c) acc[k][c] = __builtin_fmaf(pay[u][c], w, acc[k][c]);
+                    accd[k] = __builtin_fmaf(b[u].z, w, accd[k]);
+                    Tr[k] -= w;
+                    if (stop) {  // rare, wave-uniform: a pixel's transmittance ran out at this entry
+                        const uint32_t pos = base - start + (uint32_t)jj[u] + 1u;
+                        stop_pos[k] = __builtin_amdgcn_inverse_ballot_w64(stop) ? pos : stop_pos[k];
+                        done[k] |= stop;
+                    }
+                }
             }
         }
-        __syncthreads();  // WAR on the LDS slice before the next batch is staged
+        wave_lds_fence();  // WAR on the LDS slice before the next batch is staged
     }
 
     const float *vw = p.views + (size_t)v * LSR_VIEW_FLOATS;
@@ -130,7 +196,9 @@ k_render_fwd(RenderFwdParams p) {
         const size_t pix = (size_t)pyf[k] * p.W + (size_t)pxf[k];
         const size_t vp = (size_t)v * HW + pix;
         p.final_T[vp] = Tr[k];
-        p.n_contrib[vp] = last[k];
+        // number of leading list entries the backward pass has to consider for this pixel: all of
+        // them, or everything before the entry at which the transmittance test stopped the pixel
+        p.n_contrib[vp] = stop_pos[k] ? stop_pos[k] - 1u : end - start;
         p.out_mask[vp] = 1.0f - Tr[k];
         p.out_depth[vp] = accd[k];
         if (p.has_color) {
@@ -143,6 +211,18 @@ k_render_fwd(RenderFwdParams p) {
             if (c >= coff && c - coff < p.C)
                 p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[k][c];
     }
+    wave_lds_fence();
+    if (p.trace && lane == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.trace[4 * (size_t)item + 0] = t_begin;
+        p.trace[4 * (size_t)item + 1] = __builtin_readcyclecounter();
+        p.trace[4 * (size_t)item + 2] = ((unsigned long long)xcc << 32) | hwid;
+        p.trace[4 * (size_t)item + 3] = end - start;
+    }
+    }  // persistent item loop
 }
 
 static int pick_pxl(int nchp, int64_t tiles_total) {
@@ -176,8 +256,27 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     const int nch = (p.has_color ? 3 : 0) + d.feat_channels;
     const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));
     const int pxl = pick_pxl(nchp, (int64_t)p.T * d.num_views);
-    dim3 grid(p.T * (4 / pxl), d.num_views);
-#define LSR_RF(N, X) hipLaunchKernelGGL((k_render_fwd<N, X>), grid, dim3(LSR_WAVE), 0, s, p)
+    p.num_items = p.T * d.num_views * (4 / pxl);
+    p.tile_order = (const uint32_t *)(geom + L.tile_order);
+    p.queue = (uint32_t *)(geom + L.header) + 2;
+    int res = 4;   // resident waves per SIMD
+    if (const char *e = getenv("LSR_RES")) { const int x = atoi(e); if (x >= 1 && x <= 8) res = x; }
+    const int waves = p.num_items < 1024 * res ? p.num_items : 1024 * res;
+    dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    p.trace = nullptr;
+    const char *trace_path = getenv("LSR_TRACE");
+    if (trace_path) {
+        (void)hipMalloc((void **)&p.trace, (size_t)p.num_items * 32);
+        (void)hipMemsetAsync(p.trace, 0, (size_t)p.num_items * 32, s);
+    }
+    int unr = 4;
+    if (const char *e = getenv("LSR_UNR")) { const int x = atoi(e); if (x == 1 || x == 2 || x == 4) unr = x; }
+#define LSR_RF(N, X)                                                                              \
+    do {                                                                                          \
+        if (unr == 4 && N <= 12) hipLaunchKernelGGL((k_render_fwd<N, X, 4>), grid, dim3(LSR_WAVE * kWavesPerBlock), 0, s, p);      \
+        else if (unr >= 2) hipLaunchKernelGGL((k_render_fwd<N, X, 2>), grid, dim3(LSR_WAVE * kWavesPerBlock), 0, s, p); \
+        else hipLaunchKernelGGL((k_render_fwd<N, X, 1>), grid, dim3(LSR_WAVE * kWavesPerBlock), 0, s, p);          \
+    } while (0)
 #define LSR_RF_N(N)                                  \
     do {                                             \
         if (pxl == 4) LSR_RF(N, 4);                  \
@@ -192,6 +291,13 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
 #undef LSR_RF_N
 #undef LSR_RF
     prof_end(kStRenderFwd, s);
+    if (trace_path) {  // debug only: dump per-item timing of this launch
+        std::vector<unsigned long long> host((size_t)p.num_items * 4);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(host.data(), p.trace, host.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(trace_path, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+        (void)hipFree(p.trace);
+    }
     return hipGetLastError();
 }
 

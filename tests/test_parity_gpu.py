@@ -48,9 +48,10 @@ def _check_forward(bi, run, views=None):
         np.testing.assert_allclose(run.mask_out[v].cpu().numpy(), o["mask"], atol=ABS_TOL, rtol=0)
         dscale = max(1.0, float(np.abs(o["depth"]).max()))
         np.testing.assert_allclose(run.depth_out[v].cpu().numpy(), o["depth"], atol=ABS_TOL * dscale, rtol=0)
-        # n_contrib may differ only where exp rounding flips a threshold decision
-        mism = (ncontrib[v] != o["n_contrib"].astype(np.int32)).mean()
-        assert mism < 2e-3, f"n_contrib mismatch fraction {mism}"
+        # the per-pixel list prefix kept for the backward pass may differ only where exp rounding
+        # flips the transmittance-termination decision
+        mism = (ncontrib[v] != o["n_considered"].astype(np.int32)).mean()
+        assert mism < 2e-3, f"n_considered mismatch fraction {mism}"
     if views is None:
         assert run.P == total_P
 

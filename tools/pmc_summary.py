@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Aggregate rocprofv3 --pmc CSV output (counter_collection.csv of every pass under a directory)
+into per-kernel means per launch.  usage: tools/pmc_summary.py gpurun_out/pmc_<tag> > profiles/<name>.md"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name).replace("void ", "")
+    return name[:60]
+
+
+def main():
+    root = sys.argv[1]
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = short(row["Kernel_Name"])
+                if "lsr::" not in k:
+                    continue
+                a = acc[k][row["Counter_Name"]]
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+    print(f"# PMC counters per launch (mean over launches), {root}\n")
+    print("FETCH_SIZE / WRITE_SIZE are in KiB as reported; on gfx950 FETCH_SIZE under-counts wide")
+    print("coalesced reads by 2x (MI355X_MICROARCH.md §HBM) — `hbm_read_corrected` doubles it.\n")
+    for k in sorted(acc):
+        print(f"## `{k}`\n")
+        print("| counter | mean per launch |")
+        print("|---|---:|")
+        c = {n: v[0] / max(v[1], 1) for n, v in acc[k].items()}
+        for n in sorted(c):
+            print(f"| {n} | {c[n]:.4g} |")
+        if "FETCH_SIZE" in c:
+            print(f"| hbm_read_corrected_bytes (2 x FETCH_SIZE x 1024) | {2 * c['FETCH_SIZE'] * 1024:.4g} |")
+        if "WRITE_SIZE" in c:
+            print(f"| hbm_write_bytes (WRITE_SIZE x 1024) | {c['WRITE_SIZE'] * 1024:.4g} |")
+        if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c and c["SQ_WAVES"]:
+            print(f"| VALU insts per wave | {c['SQ_INSTS_VALU'] / c['SQ_WAVES']:.4g} |")
+        print()
+
+
+if __name__ == "__main__":
+    main()
