@@ -21,7 +21,7 @@ constexpr int kScanThreads = 1024;
 
 __global__ void __launch_bounds__(kScanThreads)
 k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *header,
-            uint32_t *__restrict__ order, int N) {
+            uint32_t *__restrict__ order, int N, int force_base, int limit_pct) {
     __shared__ uint32_t s_sum[kScanThreads];
     __shared__ uint32_t s_max[kScanThreads];
     const int tid = threadIdx.x;
@@ -40,16 +40,28 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
     }
     uint32_t run = s_sum[tid] - sum;  // exclusive prefix of this thread's chunk
     for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
-    if (tid == kScanThreads - 1) { start[N] = s_sum[tid]; header[0] = s_sum[tid]; header[1] = s_max[tid]; }
-    // ---- longest-first order: counting sort on kScanThreads length classes ----
-    const uint32_t maxc = s_max[kScanThreads - 1];
+    if (tid == kScanThreads - 1) { start[N] = s_sum[tid]; header[kHdrPairs] = s_sum[tid]; header[kHdrMaxTile] = s_max[tid]; }
+    // ---- work items, costliest first: counting sort on kScanThreads cost classes ----
+    const uint32_t maxc = s_max[kScanThreads - 1], total = s_sum[kScanThreads - 1];
     __syncthreads();
     s_sum[tid] = 0;
     __syncthreads();
+    uint32_t base = (uint32_t)N >= (uint32_t)kWaveSlots ? 1u : (2u * (uint32_t)N >= (uint32_t)kWaveSlots ? 2u : 4u);
+    if (force_base) base = (uint32_t)force_base;
+    const uint32_t mean = total / (uint32_t)N + 1u;
+    const uint32_t limit = (uint32_t)((uint64_t)mean * (uint32_t)limit_pct / 100u) / base + 1u;   // longest list one item may walk
     const uint64_t scale = maxc + 1u;
+    auto nsplit = [&](uint32_t c) -> uint32_t {
+        uint32_t sp = base;
+        while (sp < 4u && c / sp > limit) sp <<= 1;
+        return sp;
+    };
+    auto cls = [&](uint32_t c, uint32_t sp) -> uint32_t {
+        return kScanThreads - 1 - (uint32_t)(((uint64_t)(c / sp) * kScanThreads) / scale);
+    };
     for (int i = lo; i < hi; ++i) {
-        const uint32_t b = kScanThreads - 1 - (uint32_t)(((uint64_t)count[i] * kScanThreads) / scale);
-        atomicAdd(&s_sum[b], 1u);
+        const uint32_t c = count[i], sp = nsplit(c);
+        atomicAdd(&s_sum[cls(c, sp)], sp);
     }
     __syncthreads();
     const uint32_t mine = s_sum[tid];
@@ -61,10 +73,14 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
         __syncthreads();
     }
     s_max[tid] = s_sum[tid] - mine;  // exclusive start of class tid
+    if (tid == kScanThreads - 1) header[kHdrNumItems] = s_sum[tid];
     __syncthreads();
     for (int i = lo; i < hi; ++i) {
-        const uint32_t b = kScanThreads - 1 - (uint32_t)(((uint64_t)count[i] * kScanThreads) / scale);
-        order[atomicAdd(&s_max[b], 1u)] = (uint32_t)i;
+        const uint32_t c = count[i], sp = nsplit(c);
+        const uint32_t at = atomicAdd(&s_max[cls(c, sp)], sp);
+        if (sp == 1) order[at] = (uint32_t)i | (0xFu << kItemOwnShift);
+        else if (sp == 2) { order[at] = (uint32_t)i | (0x3u << kItemOwnShift); order[at + 1] = (uint32_t)i | (0xCu << kItemOwnShift); }
+        else for (uint32_t q = 0; q < 4; ++q) order[at + q] = (uint32_t)i | ((1u << q) << kItemOwnShift);
     }
 }
 
@@ -74,7 +90,9 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s) {
     prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
                        (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
-                       (uint32_t *)(geom + L.header), (uint32_t *)(geom + L.tile_order), N);
+                       (uint32_t *)(geom + L.header), (uint32_t *)(geom + L.tile_order), N,
+                       getenv("LSR_SPLIT") ? atoi(getenv("LSR_SPLIT")) : 0,
+                       getenv("LSR_LIMIT") ? atoi(getenv("LSR_LIMIT")) : 100000);
     prof_end(kStTileScan, s);
     return hipGetLastError();
 }
@@ -135,39 +153,118 @@ k_scatter(int G, int gx, int T, const ushort4 *__restrict__ rect, const float4 *
 // ------------------------------------------------------------------------------------------
 constexpr int kSortThreads = 256;
 
-__device__ __forceinline__ void cmpswap(uint64_t &a, uint64_t &b, bool up) {
-    if ((a > b) == up) { const uint64_t t = a; a = b; b = t; }
-}
+// One workgroup per (tile, view); list length n <= CAP, keys sorted inside LDS.
+//
+// Fast path — order-preserving bucket sort: bucket = (key - min) >> shift is monotone in the key,
+// so a histogram + scan + scatter puts every key into its final neighbourhood and a tiny
+// insertion sort per bucket (about one key per bucket on average) finishes the job: ~10 LDS
+// operations per key instead of the ~log^2(n) compare-exchange passes of a sorting network.
+// Because the low 32 key bits are the (distinct) Gaussian indices, even identical depths spread
+// over the buckets; only a heavy cluster plus a far outlier can overfill a bucket, and such tiles
+// take the bitonic network below (same LDS array).  Both paths produce the same total order of
+// distinct 64-bit keys, i.e. the bit-exact published ordering.
+constexpr uint32_t kBucketOverflow = 48;   // longest bucket the insertion sort may get
 
-// One workgroup per (tile, view); list length n <= CAP (power of two), keys staged in LDS.
 template <int CAP>
 __global__ void __launch_bounds__(kSortThreads)
 k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
              uint32_t *__restrict__ point_list) {
-    extern __shared__ uint64_t s_keys[];
+    constexpr int NB = CAP < 4096 ? CAP : 4096;          // buckets
+    extern __shared__ uint64_t s_keys[];                  // [CAP] sorted keys
+    uint32_t *s_cnt = (uint32_t *)(s_keys + CAP);         // [NB] histogram -> bucket end offsets
+    __shared__ uint64_t s_red[2 * (kSortThreads / LSR_WAVE)];
+    __shared__ uint32_t s_wsum[kSortThreads / LSR_WAVE];
+    __shared__ uint32_t s_flag;
+    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
     const size_t vt = (size_t)blockIdx.y * T + blockIdx.x;
     const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
     if (n == 0) return;
     if (n > (uint32_t)CAP) return;  // handled by the global-memory path
-    uint32_t npad = 2;
-    while (npad < n) npad <<= 1;
-    for (uint32_t i = threadIdx.x; i < npad; i += kSortThreads)
-        s_keys[i] = i < n ? keys[start + i] : ~0ull;
+    const uint64_t *src = keys + start;
+    if (n == 1) { if (tid == 0) point_list[start] = (uint32_t)src[0]; return; }
+
+    // ---- key range ----
+    uint64_t kmin = ~0ull, kmax = 0ull;
+    for (uint32_t i = tid; i < n; i += kSortThreads) { const uint64_t k = src[i]; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t a = __shfl_xor(kmin, off), b = __shfl_xor(kmax, off);
+        kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) { s_red[2 * wid] = kmin; s_red[2 * wid + 1] = kmax; }
+    for (int b = tid; b < NB; b += kSortThreads) s_cnt[b] = 0;
+    if (tid == 0) s_flag = 0;
     __syncthreads();
-    for (uint32_t k = 2; k <= npad; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (npad >> 1); t += kSortThreads) {
-                // t-th compare-exchange of this stage: partner indices differ in bit j
-                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t hi = lo | j;
-                const bool up = (lo & k) == 0;
-                uint64_t a = s_keys[lo], b = s_keys[hi];
-                if ((a > b) == up) { s_keys[lo] = b; s_keys[hi] = a; }
+#pragma unroll
+    for (int w = 0; w < kSortThreads / LSR_WAVE; ++w) {
+        kmin = s_red[2 * w] < kmin ? s_red[2 * w] : kmin;
+        kmax = s_red[2 * w + 1] > kmax ? s_red[2 * w + 1] : kmax;
+    }
+    const uint64_t range = kmax - kmin;
+    const int bits = range ? 64 - __builtin_clzll(range) : 0;      // range < 2^bits
+    constexpr int LOGNB = NB == 4096 ? 12 : (NB == 2048 ? 11 : 10);
+    const int shift = bits > LOGNB ? bits - LOGNB : 0;
+
+    // ---- histogram, scan ----
+    for (uint32_t i = tid; i < n; i += kSortThreads) atomicAdd(&s_cnt[(uint32_t)((src[i] - kmin) >> shift)], 1u);
+    __syncthreads();
+    constexpr int PER = NB / kSortThreads;
+    uint32_t loc[PER], sum = 0, mx = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { loc[q] = s_cnt[tid * PER + q]; sum += loc[q]; mx = loc[q] > mx ? loc[q] : mx; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < LSR_WAVE; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == LSR_WAVE - 1) s_wsum[wid] = incl;
+    if (mx > kBucketOverflow) s_flag = 1;
+    __syncthreads();
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int w = 0; w < kSortThreads / LSR_WAVE; ++w) run += w < wid ? s_wsum[w] : 0u;
+    const bool overflow = s_flag != 0;
+    if (!overflow) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { s_cnt[tid * PER + q] = run; run += loc[q]; }   // exclusive starts
+        __syncthreads();
+        // ---- scatter into buckets (s_cnt[b] ends up as the END of bucket b) ----
+        for (uint32_t i = tid; i < n; i += kSortThreads) {
+            const uint64_t k = src[i];
+            s_keys[atomicAdd(&s_cnt[(uint32_t)((k - kmin) >> shift)], 1u)] = k;
+        }
+        __syncthreads();
+        // ---- finish inside each bucket ----
+        for (int b = tid; b < NB; b += kSortThreads) {
+            const uint32_t lo = b ? s_cnt[b - 1] : 0u, hi = s_cnt[b];
+            for (uint32_t i = lo + 1; i < hi; ++i) {
+                const uint64_t k = s_keys[i];
+                uint32_t j = i;
+                while (j > lo && s_keys[j - 1] > k) { s_keys[j] = s_keys[j - 1]; --j; }
+                s_keys[j] = k;
             }
-            __syncthreads();
+        }
+        __syncthreads();
+    } else {
+        // ---- bitonic network over the padded list ----
+        uint32_t npad = 2;
+        while (npad < n) npad <<= 1;
+        __syncthreads();
+        for (uint32_t i = tid; i < npad; i += kSortThreads) s_keys[i] = i < n ? src[i] : ~0ull;
+        __syncthreads();
+        for (uint32_t k = 2; k <= npad; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < (npad >> 1); t += kSortThreads) {
+                    // t-th compare-exchange of this stage: partner indices differ in bit j
+                    const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const uint32_t hi = lo | j;
+                    const bool up = (lo & k) == 0;
+                    const uint64_t a = s_keys[lo], b = s_keys[hi];
+                    if ((a > b) == up) { s_keys[lo] = b; s_keys[hi] = a; }
+                }
+                __syncthreads();
+            }
         }
     }
-    for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
+    for (uint32_t i = tid; i < n; i += kSortThreads)
         point_list[start + i] = (uint32_t)(s_keys[i] & 0xffffffffull);
 }
 
@@ -238,7 +335,12 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
 #define LSR_SORT(CAPV)                                                                           \
     do {                                                                                         \
         cap = CAPV;                                                                              \
-        hipLaunchKernelGGL((k_sort_tiles<CAPV>), grid, dim3(kSortThreads), (size_t)CAPV * 8, s,  \
+        if ((size_t)CAPV * 8 + 16384 > 65536)                                                    \
+            (void)hipFuncSetAttribute((const void *)k_sort_tiles<CAPV>,                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,                \
+                                      CAPV * 8 + (CAPV < 4096 ? CAPV : 4096) * 4);               \
+        hipLaunchKernelGGL((k_sort_tiles<CAPV>), grid, dim3(kSortThreads),                       \
+                           (size_t)CAPV * 8 + (size_t)(CAPV < 4096 ? CAPV : 4096) * 4, s,        \
                            T, ts, (const uint64_t *)keys, plist);                                \
     } while (0)
         if (max_tile_pairs <= 1024) LSR_SORT(1024);

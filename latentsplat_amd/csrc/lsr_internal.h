@@ -55,7 +55,7 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     L.tile_count = o; o = align_up(o + VT * 4);
     L.tile_cursor = o; o = align_up(o + VT * 4);   // adjacent to tile_count: one memset clears both
     L.tile_start = o; o = align_up(o + (VT + 1) * 4);
-    L.tile_order = o; o = align_up(o + VT * 4);   // (view,tile) ids, longest list first
+    L.tile_order = o; o = align_up(o + 4 * VT * 4);   // work items (see kItem*), costliest first
     L.total = o;
     return L;
 }
@@ -96,6 +96,18 @@ inline int coprime_stride(int T) {
     while (gcd(s, T) != 1) ++s;
     return s % T ? s % T : 1;
 }
+
+// Compositing work items: one wave renders the quadrants in `own` of one (view, tile).
+//   item = (view*T + tile) | own << 28.  k_tile_scan emits them costliest-first.  When there are
+//   fewer tiles than wave slots every tile is split into 2 or 4 items (disjoint quadrant sets) to
+//   fill the machine.  Splitting only the LONG lists for balance is implemented but off by
+//   default (LSR_LIMIT=<percent of mean length>): measured on MI355X each extra item re-pays the
+//   per-entry staging cost and the makespan did not improve (experiments).
+constexpr uint32_t kItemTileMask = 0x0FFFFFFFu;
+constexpr int kItemOwnShift = 28;
+constexpr int kWaveSlots = 256 * 4 * 4;   // CUs x SIMDs x resident compositing waves per SIMD
+// header words of the geometry workspace
+enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrQueueFwd = 2, kHdrNumItems = 3 };
 
 // ---- optional per-stage hipEvent timing (api.hip); no-ops unless lsr_profile_enable(1) ----
 enum Stage { kStPreprocess = 0, kStTileScan, kStScatter, kStSort, kStRenderFwd, kStRenderBwd, kStPreprocessBwd, kNumStages };

@@ -1,7 +1,15 @@
 // render_forward.hip — stage K6: front-to-back alpha compositing of the depth-sorted tile lists.
 // Outputs colour (+ bg), features (bg 0), mask = 1 - T, depth = sum alpha T z, and keeps
 // final_T / n_contrib for the backward pass.  Spec: SURVEY.md Appendix A.3 step 7 + A.4.
-// Work decomposition and the lossless quadrant culling are described in lsr_blend.h.
+//
+// Execution shape (CDNA4): persistent waves pull work items — (view, tile, set of 8x8 quadrants),
+// costliest first — from a global queue (lsr_internal.h kItem*).  A lane owns the same position
+// in each of the 4 quadrants (4 pixels per lane); quadrants outside the item's set are simply
+// never touched.  Per 64 staged list entries the wave walks, quadrant by quadrant, only the
+// entries whose alpha >= 1/255 footprint can reach that quadrant (lsr_blend.h), UNR at a time.
+// Measured on MI355X the kernel is bound by f32 VALU issue (~4 cycles per wave64 instruction),
+// so the inner loop keeps per-pixel state decisions in scalar lane masks (SALU) rather than VGPR
+// selects, and the quadrant culling + item splitting exist to cut / balance VALU work.
 #include <stdio.h>
 
 #include <vector>
@@ -22,8 +30,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 struct RenderFwdParams {
-    int H, W, gx, T, G, C, has_color, num_items;
-    const uint32_t *tile_order;   // (view*T + tile), longest list first
+    int H, W, gx, T, G, C, has_color;
+    const uint32_t *items;        // work items, costliest first
+    const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t *queue;              // work-queue head (zeroed per forward)
     unsigned long long *trace;    // debug (LSR_TRACE): per item {start clk, end clk, hw id, entries}
     int64_t vs_feat;
@@ -36,10 +45,10 @@ struct RenderFwdParams {
     uint32_t *n_contrib;
 };
 
-template <int NCHP, int PXL, int UNR>
+template <int NCHP, int UNR>
 __global__ void __launch_bounds__(LSR_WAVE * kWavesPerBlock)
 k_render_fwd(RenderFwdParams p) {
-    constexpr int NW = 4 / PXL;  // waves (= workgroups) per tile
+    constexpr int PXL = 4;
     __shared__ float4 s_q0_all[kWavesPerBlock][LSR_WAVE + 1];   // slot 64: null record (alpha == 0) pads partial groups
     __shared__ float4 s_q1_all[kWavesPerBlock][LSR_WAVE + 1];
     __shared__ float4 s_pay_all[kWavesPerBlock][LSR_WAVE + 1][NCHP / 4];
@@ -54,186 +63,168 @@ k_render_fwd(RenderFwdParams p) {
 #pragma unroll
         for (int c4 = 0; c4 < NCHP / 4; ++c4) s_pay[LSR_WAVE][c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    // Persistent wave: pulls (tile, quadrant-set) items from a global queue, longest tile lists
-    // first, until the queue is empty.  Dynamic LPT scheduling: a static one-item-per-wave launch
-    // leaves SIMDs idle for ~1/3 of the kernel because list lengths vary (measured).
-    for (;;) {
-    uint32_t item = 0;
-    if (lane == 0) item = atomicAdd(p.queue, 1u);
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= (uint32_t)p.num_items) break;
-    const unsigned long long t_begin = p.trace ? __builtin_readcyclecounter() : 0ull;
-    const uint32_t vt = p.tile_order[item / NW];
-    const int tile = (int)(vt % (uint32_t)p.T), part = (int)(item % NW);
-    const int v = (int)(vt / (uint32_t)p.T);
-    const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE;
-    const size_t vG = (size_t)v * p.G;
-    const uint32_t start = p.tile_start[(size_t)v * p.T + tile];
-    const uint32_t end = p.tile_start[(size_t)v * p.T + tile + 1];
-    const uint32_t own = owned_mask<PXL>(part);
+    const uint32_t num_items = p.header[kHdrNumItems];
     const int coff = p.has_color ? 3 : 0;
+    const size_t HW = (size_t)p.H * p.W;
 
-    float pxf[PXL], pyf[PXL], Tr[PXL], accd[PXL];
-    float acc[PXL][NCHP];
-    uint32_t stop_pos[PXL];
-    // Per-pixel "finished" flags live in scalar registers as 64-bit lane masks, so the skip /
-    // blend / stop decisions are SALU mask algebra instead of per-lane VALU selects.
-    uint64_t done[PXL];
-    bool inside[PXL];
-#pragma unroll
-    for (int k = 0; k < PXL; ++k) {
-        const int q = owned_quadrant<PXL>(part, k);
-        const int px = tx0 + 8 * (q & 1) + (lane & 7), py = ty0 + 8 * (q >> 1) + (lane >> 3);
-        pxf[k] = (float)px; pyf[k] = (float)py;
-        inside[k] = px < p.W && py < p.H;
-        done[k] = __ballot(!inside[k]);
-        Tr[k] = 1.0f; accd[k] = 0.0f; stop_pos[k] = 0;
-#pragma unroll
-        for (int c = 0; c < NCHP; ++c) acc[k][c] = 0.0f;
-    }
+    for (;;) {
+        uint32_t qi = 0;
+        if (lane == 0) qi = atomicAdd(p.queue, 1u);
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        if (qi >= num_items) break;
+        const unsigned long long t_begin = p.trace ? __builtin_readcyclecounter() : 0ull;
+        const uint32_t item = p.items[qi];
+        const uint32_t vt = item & kItemTileMask, own = item >> kItemOwnShift;
+        const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
+        const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE;
+        const size_t vG = (size_t)v * p.G;
+        const uint32_t start = p.tile_start[vt], end = p.tile_start[vt + 1];
 
-    for (uint32_t base = start; base < end; base += LSR_WAVE) {
-        uint64_t all_done = ~0ull;
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) all_done &= done[k];
-        if (all_done == ~0ull) break;
-
-        // ---- stage up to 64 list entries (one per lane) ----
-        const uint32_t e = base + lane;
-        uint32_t m = 0;
-        if (e < end) {
-            const uint32_t g = p.point_list[e];
-            const float4 a = p.q0[vG + g], b = p.q1[vG + g];  // (x,y,A,B) (C,o,z,-)
-            m = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own;
-            if (m) {
-                const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
-                s_q0[lane] = make_float4(a.x, a.y, f.a2, f.b2);
-                s_q1[lane] = make_float4(f.c2, f.l2o, b.z, __uint_as_float(m));
-                float pay[NCHP];
-#pragma unroll
-                for (int c = 0; c < NCHP; ++c) pay[c] = 0.0f;
-                if (p.has_color) {
-                    const float4 col = p.rgb[vG + g];
-                    pay[0] = col.x; pay[1] = col.y; pay[2] = col.z;
-                }
-                const float *fp = p.features + (size_t)v * p.vs_feat + (size_t)g * p.C;
-#pragma unroll
-                for (int c = 0; c < NCHP; ++c)
-                    if (c >= coff && c - coff < p.C) pay[c] = fp[c - coff];
-#pragma unroll
-                for (int c4 = 0; c4 < NCHP / 4; ++c4)
-                    s_pay[lane][c4] = make_float4(pay[4 * c4], pay[4 * c4 + 1], pay[4 * c4 + 2], pay[4 * c4 + 3]);
-            }
-        }
-        // per owned quadrant: which staged entries can touch it (wave-uniform 64-bit masks)
-        uint64_t qbits[PXL];
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) qbits[k] = __ballot((m >> owned_quadrant<PXL>(part, k)) & 1u);
-        wave_lds_fence();  // staged records are visible to this wave's reads below
-
-        // Walk each quadrant's entries front to back, UNR at a time: the alpha evaluations of the
-        // UNR entries are independent (instruction-level parallelism hides LDS / exp / compare
-        // latency); only the short transmittance update chain is serial.
+        float pxf[PXL], pyf[PXL], Tr[PXL], accd[PXL];
+        float acc[PXL][NCHP];
+        uint32_t stop_pos[PXL];
+        // Per-pixel "finished" flags live in scalar registers as 64-bit lane masks, so the skip /
+        // blend / stop decisions are SALU mask algebra instead of per-lane VALU selects.
+        uint64_t done[PXL];
+        bool inside[PXL];
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
-            uint64_t bits = qbits[k];
-            while (bits) {
-                int jj[UNR];
+            const int px = tx0 + 8 * (k & 1) + (lane & 7), py = ty0 + 8 * (k >> 1) + (lane >> 3);
+            pxf[k] = (float)px; pyf[k] = (float)py;
+            inside[k] = px < p.W && py < p.H && ((own >> k) & 1u);
+            done[k] = __ballot(!inside[k]);
+            Tr[k] = 1.0f; accd[k] = 0.0f; stop_pos[k] = 0;
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    jj[u] = bits ? __builtin_ctzll(bits) : LSR_WAVE;  // slot 64 = null record
-                    bits &= bits - 1;
-                }
-                float4 a[UNR], b[UNR];
-                float pay[UNR][NCHP];
+            for (int c = 0; c < NCHP; ++c) acc[k][c] = 0.0f;
+        }
+
+        for (uint32_t base = start; base < end; base += LSR_WAVE) {
+            uint64_t all_done = ~0ull;
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    a[u] = s_q0[jj[u]]; b[u] = s_q1[jj[u]];
+            for (int k = 0; k < PXL; ++k) all_done &= done[k];
+            if (all_done == ~0ull) break;
+
+            // ---- stage up to 64 list entries (one per lane) ----
+            const uint32_t e = base + lane;
+            uint32_t m = 0;
+            if (e < end) {
+                const uint32_t g = p.point_list[e];
+                const float4 a = p.q0[vG + g], b = p.q1[vG + g];  // (x,y,A,B) (C,o,z,-)
+                m = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own;
+                if (m) {
+                    const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
+                    s_q0[lane] = make_float4(a.x, a.y, f.a2, f.b2);
+                    s_q1[lane] = make_float4(f.c2, f.l2o, b.z, 0.0f);
+                    float pay[NCHP];
 #pragma unroll
-                    for (int c4 = 0; c4 < NCHP / 4; ++c4) {
-                        const float4 t = s_pay[jj[u]][c4];
-                        pay[u][4 * c4] = t.x; pay[u][4 * c4 + 1] = t.y; pay[u][4 * c4 + 2] = t.z; pay[u][4 * c4 + 3] = t.w;
+                    for (int c = 0; c < NCHP; ++c) pay[c] = 0.0f;
+                    if (p.has_color) {
+                        const float4 col = p.rgb[vG + g];
+                        pay[0] = col.x; pay[1] = col.y; pay[2] = col.z;
                     }
+                    const float *fp = p.features + (size_t)v * p.vs_feat + (size_t)g * p.C;
+#pragma unroll
+                    for (int c = 0; c < NCHP; ++c)
+                        if (c >= coff && c - coff < p.C) pay[c] = fp[c - coff];
+#pragma unroll
+                    for (int c4 = 0; c4 < NCHP / 4; ++c4)
+                        s_pay[lane][c4] = make_float4(pay[4 * c4], pay[4 * c4 + 1], pay[4 * c4 + 2], pay[4 * c4 + 3]);
                 }
-                float alpha[UNR];
-                uint64_t ok[UNR];
+            }
+            // per quadrant: which staged entries can touch it (wave-uniform 64-bit masks)
+            uint64_t qbits[PXL];
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const float dx = a[u].x - pxf[k], dy = a[u].y - pyf[k];
-                    const float ex = blend_exponent(dx, dy, a[u].z, a[u].w, b[u].x, b[u].y);
-                    alpha[u] = fminf(LSR_ALPHA_MAX, fast_exp2(ex));
-                    // skip if power > 0 or alpha < 1/255 (NaN-safe: comparisons are "keep" tests)
-                    ok[u] = __ballot(ex <= b[u].y) & __ballot(alpha[u] >= LSR_ALPHA_MIN);
-                }
+            for (int k = 0; k < PXL; ++k) qbits[k] = __ballot((m >> k) & 1u);
+            wave_lds_fence();  // staged records are visible to this wave's reads below
+
+            // Walk each quadrant's entries front to back, UNR at a time: the alpha evaluations of
+            // the UNR entries are independent; only the short transmittance chain is serial.
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const float aT = alpha[u] * Tr[k];
-                    const float tT = Tr[k] - aT;
-                    const uint64_t live = ok[u] & ~done[k];
-                    const uint64_t room = __ballot(tT >= LSR_T_EPS);
-                    const uint64_t blend = live & room, stop = live & ~room;
-                    const float w = __builtin_amdgcn_inverse_ballot_w64(blend) ? aT : 0.0f;
+            for (int k = 0; k < PXL; ++k) {
+                uint64_t bits = qbits[k];
+                while (bits) {
+                    int jj[UNR];
 #pragma unroll
-                    for (int c = 0; c < NCHP; ++c) acc[k][c] = __builtin_fmaf(pay[u][c], w, acc[k][c]);
-                    accd[k] = __builtin_fmaf(b[u].z, w, accd[k]);
-                    Tr[k] -= w;
-                    if (stop) {  // rare, wave-uniform: a pixel's transmittance ran out at this entry
-                        const uint32_t pos = base - start + (uint32_t)jj[u] + 1u;
-                        stop_pos[k] = __builtin_amdgcn_inverse_ballot_w64(stop) ? pos : stop_pos[k];
-                        done[k] |= stop;
+                    for (int u = 0; u < UNR; ++u) {
+                        jj[u] = bits ? __builtin_ctzll(bits) : LSR_WAVE;  // slot 64 = null record
+                        bits &= bits - 1;
+                    }
+                    float4 a[UNR], b[UNR];
+                    float pay[UNR][NCHP];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        a[u] = s_q0[jj[u]]; b[u] = s_q1[jj[u]];
+#pragma unroll
+                        for (int c4 = 0; c4 < NCHP / 4; ++c4) {
+                            const float4 t = s_pay[jj[u]][c4];
+                            pay[u][4 * c4] = t.x; pay[u][4 * c4 + 1] = t.y; pay[u][4 * c4 + 2] = t.z; pay[u][4 * c4 + 3] = t.w;
+                        }
+                    }
+                    float alpha[UNR];
+                    uint64_t ok[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const float dx = a[u].x - pxf[k], dy = a[u].y - pyf[k];
+                        const float ex = blend_exponent(dx, dy, a[u].z, a[u].w, b[u].x, b[u].y);
+                        alpha[u] = fminf(LSR_ALPHA_MAX, fast_exp2(ex));
+                        // skip if power > 0 or alpha < 1/255 (NaN-safe: comparisons are "keep" tests)
+                        ok[u] = __ballot(ex <= b[u].y) & __ballot(alpha[u] >= LSR_ALPHA_MIN);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const float aT = alpha[u] * Tr[k];
+                        const float tT = Tr[k] - aT;
+                        const uint64_t live = ok[u] & ~done[k];
+                        const uint64_t room = __ballot(tT >= LSR_T_EPS);
+                        const uint64_t blend = live & room, stop = live & ~room;
+                        const float w = __builtin_amdgcn_inverse_ballot_w64(blend) ? aT : 0.0f;
+#pragma unroll
+                        for (int c = 0; c < NCHP; ++c) acc[k][c] = __builtin_fmaf(pay[u][c], w, acc[k][c]);
+                        accd[k] = __builtin_fmaf(b[u].z, w, accd[k]);
+                        Tr[k] -= w;
+                        if (stop) {  // rare, wave-uniform: a pixel's transmittance ran out here
+                            const uint32_t pos = base - start + (uint32_t)jj[u] + 1u;
+                            stop_pos[k] = __builtin_amdgcn_inverse_ballot_w64(stop) ? pos : stop_pos[k];
+                            done[k] |= stop;
+                        }
                     }
                 }
             }
+            wave_lds_fence();  // WAR on the LDS slice before the next batch is staged
         }
-        wave_lds_fence();  // WAR on the LDS slice before the next batch is staged
-    }
 
-    const float *vw = p.views + (size_t)v * LSR_VIEW_FLOATS;
-    const size_t HW = (size_t)p.H * p.W;
+        const float *vw = p.views + (size_t)v * LSR_VIEW_FLOATS;
 #pragma unroll
-    for (int k = 0; k < PXL; ++k) {
-        if (!inside[k]) continue;
-        const size_t pix = (size_t)pyf[k] * p.W + (size_t)pxf[k];
-        const size_t vp = (size_t)v * HW + pix;
-        p.final_T[vp] = Tr[k];
-        // number of leading list entries the backward pass has to consider for this pixel: all of
-        // them, or everything before the entry at which the transmittance test stopped the pixel
-        p.n_contrib[vp] = stop_pos[k] ? stop_pos[k] - 1u : end - start;
-        p.out_mask[vp] = 1.0f - Tr[k];
-        p.out_depth[vp] = accd[k];
-        if (p.has_color) {
+        for (int k = 0; k < PXL; ++k) {
+            if (!inside[k]) continue;
+            const size_t pix = (size_t)pyf[k] * p.W + (size_t)pxf[k];
+            const size_t vp = (size_t)v * HW + pix;
+            p.final_T[vp] = Tr[k];
+            // number of leading list entries the backward pass has to consider for this pixel: all
+            // of them, or everything before the entry at which the transmittance test stopped it
+            p.n_contrib[vp] = stop_pos[k] ? stop_pos[k] - 1u : end - start;
+            p.out_mask[vp] = 1.0f - Tr[k];
+            p.out_depth[vp] = accd[k];
+            if (p.has_color) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(Tr[k], vw[37 + c], acc[k][c]);
+                for (int c = 0; c < 3; ++c)
+                    p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(Tr[k], vw[37 + c], acc[k][c]);
+            }
+#pragma unroll
+            for (int c = 0; c < NCHP; ++c)
+                if (c >= coff && c - coff < p.C)
+                    p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[k][c];
         }
-#pragma unroll
-        for (int c = 0; c < NCHP; ++c)
-            if (c >= coff && c - coff < p.C)
-                p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[k][c];
-    }
-    wave_lds_fence();
-    if (p.trace && lane == 0) {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        p.trace[4 * (size_t)item + 0] = t_begin;
-        p.trace[4 * (size_t)item + 1] = __builtin_readcyclecounter();
-        p.trace[4 * (size_t)item + 2] = ((unsigned long long)xcc << 32) | hwid;
-        p.trace[4 * (size_t)item + 3] = end - start;
-    }
+        if (p.trace && lane == 0) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            p.trace[4 * (size_t)qi + 0] = t_begin;
+            p.trace[4 * (size_t)qi + 1] = __builtin_readcyclecounter();
+            p.trace[4 * (size_t)qi + 2] = ((unsigned long long)xcc << 32) | hwid;
+            p.trace[4 * (size_t)qi + 3] = ((unsigned long long)own << 32) | (end - start);
+        }
     }  // persistent item loop
-}
-
-static int pick_pxl(int nchp, int64_t tiles_total) {
-    if (const char *e = getenv("LSR_PXL")) {
-        const int x = atoi(e);
-        if (x == 1 || x == 2 || x == 4) return (nchp > 12 && x == 4) ? 2 : x;
-    }
-    // enough independent waves to put >= 2 on every SIMD of the 256 CUs (1024 SIMDs)
-    int pxl = tiles_total >= 2048 ? 4 : (tiles_total >= 1024 ? 2 : 1);
-    if (nchp > 12 && pxl == 4) pxl = 2;  // keep accumulators within the VGPR budget
-    return pxl;
 }
 
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
@@ -245,6 +236,9 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     RenderFwdParams p;
     p.H = d.height; p.W = d.width; p.gx = tiles_x(d); p.T = (int)num_tiles(d); p.G = d.num_gaussians;
     p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE; p.vs_feat = d.vs_feat;
+    p.items = (const uint32_t *)(geom + L.tile_order);
+    p.header = (const uint32_t *)(geom + L.header);
+    p.queue = (uint32_t *)(geom + L.header) + kHdrQueueFwd;
     p.views = in.views;
     p.q0 = (const float4 *)(geom + L.q0); p.q1 = (const float4 *)(geom + L.q1);
     p.rgb = (const float4 *)(geom + L.rgb);
@@ -255,44 +249,26 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.final_T = (float *)(img + I.final_T); p.n_contrib = (uint32_t *)(img + I.n_contrib);
     const int nch = (p.has_color ? 3 : 0) + d.feat_channels;
     const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));
-    const int pxl = pick_pxl(nchp, (int64_t)p.T * d.num_views);
-    p.num_items = p.T * d.num_views * (4 / pxl);
-    p.tile_order = (const uint32_t *)(geom + L.tile_order);
-    p.queue = (uint32_t *)(geom + L.header) + 2;
-    int res = 4;   // resident waves per SIMD
-    if (const char *e = getenv("LSR_RES")) { const int x = atoi(e); if (x >= 1 && x <= 8) res = x; }
-    const int waves = p.num_items < 1024 * res ? p.num_items : 1024 * res;
+    // one wave per slot, never more waves than the most items there can be
+    const int64_t max_items = 4 * (int64_t)p.T * d.num_views;
+    const int waves = (int)(max_items < kWaveSlots ? max_items : kWaveSlots);
     dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     p.trace = nullptr;
     const char *trace_path = getenv("LSR_TRACE");
     if (trace_path) {
-        (void)hipMalloc((void **)&p.trace, (size_t)p.num_items * 32);
-        (void)hipMemsetAsync(p.trace, 0, (size_t)p.num_items * 32, s);
+        (void)hipMalloc((void **)&p.trace, (size_t)max_items * 32);
+        (void)hipMemsetAsync(p.trace, 0, (size_t)max_items * 32, s);
     }
-    int unr = 4;
-    if (const char *e = getenv("LSR_UNR")) { const int x = atoi(e); if (x == 1 || x == 2 || x == 4) unr = x; }
-#define LSR_RF(N, X)                                                                              \
-    do {                                                                                          \
-        if (unr == 4 && N <= 12) hipLaunchKernelGGL((k_render_fwd<N, X, 4>), grid, dim3(LSR_WAVE * kWavesPerBlock), 0, s, p);      \
-        else if (unr >= 2) hipLaunchKernelGGL((k_render_fwd<N, X, 2>), grid, dim3(LSR_WAVE * kWavesPerBlock), 0, s, p); \
-        else hipLaunchKernelGGL((k_render_fwd<N, X, 1>), grid, dim3(LSR_WAVE * kWavesPerBlock), 0, s, p);          \
-    } while (0)
-#define LSR_RF_N(N)                                  \
-    do {                                             \
-        if (pxl == 4) LSR_RF(N, 4);                  \
-        else if (pxl == 2) LSR_RF(N, 2);             \
-        else LSR_RF(N, 1);                           \
-    } while (0)
     prof_begin(kStRenderFwd, s);
-    if (nchp == 4) LSR_RF_N(4);
-    else if (nchp == 8) LSR_RF_N(8);
-    else if (nchp == 12) LSR_RF_N(12);
-    else { if (pxl == 2) LSR_RF(36, 2); else LSR_RF(36, 1); }
-#undef LSR_RF_N
+#define LSR_RF(N, U) hipLaunchKernelGGL((k_render_fwd<N, U>), grid, dim3(LSR_WAVE * kWavesPerBlock), 0, s, p)
+    if (nchp == 4) LSR_RF(4, 2);
+    else if (nchp == 8) LSR_RF(8, 2);
+    else if (nchp == 12) LSR_RF(12, 2);
+    else LSR_RF(36, 1);
 #undef LSR_RF
     prof_end(kStRenderFwd, s);
     if (trace_path) {  // debug only: dump per-item timing of this launch
-        std::vector<unsigned long long> host((size_t)p.num_items * 4);
+        std::vector<unsigned long long> host((size_t)max_items * 4);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(host.data(), p.trace, host.size() * 8, hipMemcpyDeviceToHost);
         if (FILE *f = fopen(trace_path, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
