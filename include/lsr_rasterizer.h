@@ -115,7 +115,9 @@ typedef struct lsr_in_grads { /* shapes follow the inputs: (G,..) when the strid
 
 /* Debug / test view of the workspaces (byte offsets from the respective workspace base). */
 typedef struct lsr_layout {
-    size_t geom_q0, geom_q1, geom_rect, geom_rgb, geom_tile_count, geom_tile_start, geom_header;
+    /* geom_rec: [V*G][geom_rec_floats] f32 = x_pix y_pix conicA conicB conicC opacity z clampbits payload...
+     * geom_bin: [V*G] {u16 rect[4]; f32 depth; i32 radius} */
+    size_t geom_rec, geom_rec_floats, geom_bin, geom_tile_count, geom_tile_start, geom_header;
     size_t bin_keys, bin_point_list;
     size_t img_final_T, img_n_contrib;
 } lsr_layout;

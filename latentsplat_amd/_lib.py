@@ -53,7 +53,7 @@ class InGrads(C.Structure):
 
 class Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
-                ("geom_q0", "geom_q1", "geom_rect", "geom_rgb", "geom_tile_count", "geom_tile_start",
+                ("geom_rec", "geom_rec_floats", "geom_bin", "geom_tile_count", "geom_tile_start",
                  "geom_header", "bin_keys", "bin_point_list", "img_final_T", "img_n_contrib")]
 
 

@@ -162,7 +162,7 @@ int lsr_get_layout(const lsr_dims *d, int64_t num_pairs, lsr_layout *out) {
     const GeomLayout L = geom_layout(*d);
     const BinLayout B = bin_layout(*d, num_pairs, 0);
     const ImgLayout I = img_layout(*d);
-    out->geom_q0 = L.q0; out->geom_q1 = L.q1; out->geom_rect = L.rect; out->geom_rgb = L.rgb;
+    out->geom_rec = L.rec; out->geom_rec_floats = (size_t)L.rec_floats; out->geom_bin = L.bin;
     out->geom_tile_count = L.tile_count; out->geom_tile_start = L.tile_start; out->geom_header = L.header;
     out->bin_keys = B.keys; out->bin_point_list = B.point_list;
     out->img_final_T = I.final_T; out->img_n_contrib = I.n_contrib;

@@ -103,7 +103,7 @@ constexpr int kScatItems = 8;
 
 template <bool LDS_RESERVE>
 __global__ void __launch_bounds__(kScatThreads)
-k_scatter(int G, int gx, int T, const ushort4 *__restrict__ rect, const float4 *__restrict__ q1,
+k_scatter(int G, int gx, int T, const BinRec *__restrict__ binrec,
           const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ tile_cursor,
           uint64_t *__restrict__ keys) {
     extern __shared__ uint32_t s_mem[];  // [T] counts, [T] bases
@@ -114,10 +114,13 @@ k_scatter(int G, int gx, int T, const ushort4 *__restrict__ rect, const float4 *
     uint32_t *cur = tile_cursor + (size_t)v * T;
     const int base = blockIdx.x * (kScatThreads * kScatItems);
     ushort4 r[kScatItems];
+    float dep[kScatItems];
 #pragma unroll
     for (int it = 0; it < kScatItems; ++it) {
         const int i = base + it * kScatThreads + threadIdx.x;
-        r[it] = i < G ? rect[vo + i] : make_ushort4(0, 0, 0, 0);
+        BinRec br; br.rect = make_ushort4(0, 0, 0, 0); br.depth = 0.0f;
+        if (i < G) br = binrec[vo + i];
+        r[it] = br.rect; dep[it] = br.depth;
     }
     if (LDS_RESERVE) {
         for (int t = threadIdx.x; t < T; t += kScatThreads) s_cnt[t] = 0;
@@ -138,7 +141,7 @@ k_scatter(int G, int gx, int T, const ushort4 *__restrict__ rect, const float4 *
     for (int it = 0; it < kScatItems; ++it) {
         const int i = base + it * kScatThreads + threadIdx.x;
         if (r[it].z <= r[it].x || r[it].w <= r[it].y) continue;
-        const uint64_t key = ((uint64_t)__float_as_uint(q1[vo + i].z) << 32) | (uint32_t)i;
+        const uint64_t key = ((uint64_t)__float_as_uint(dep[it]) << 32) | (uint32_t)i;
         for (int y = r[it].y; y < r[it].w; ++y)
             for (int x = r[it].x; x < r[it].z; ++x) {
                 const int t = y * gx + x;
@@ -318,12 +321,11 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         prof_begin(kStScatter, s);
         if (lds)
             hipLaunchKernelGGL((k_scatter<true>), grid, dim3(kScatThreads), (size_t)T * 8, s,
-                               d.num_gaussians, gx, T, (const ushort4 *)(geom + L.rect),
-                               (const float4 *)(geom + L.q1), ts, (uint32_t *)(geom + L.tile_cursor), keys);
+                               d.num_gaussians, gx, T, (const BinRec *)(geom + L.bin), ts,
+                               (uint32_t *)(geom + L.tile_cursor), keys);
         else
             hipLaunchKernelGGL((k_scatter<false>), grid, dim3(kScatThreads), 0, s, d.num_gaussians,
-                               gx, T, (const ushort4 *)(geom + L.rect), (const float4 *)(geom + L.q1),
-                               ts, (uint32_t *)(geom + L.tile_cursor), keys);
+                               gx, T, (const BinRec *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys);
         prof_end(kStScatter, s);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

@@ -17,7 +17,8 @@ namespace lsr {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t header, q0, q1, rect, rgb, tile_count, tile_start, tile_cursor, tile_order, total;
+    size_t header, rec, bin, tile_count, tile_start, tile_cursor, tile_order, total;
+    int rec_floats;
 };
 struct ImgLayout {
     size_t final_T, n_contrib, total;
@@ -28,19 +29,32 @@ struct BinLayout {
 // One packed gradient record per (view, Gaussian), accumulated by the compositing backward:
 //   [0] d/dx_pix [1] d/dy_pix [2] d/dA [3] d/dB [4] d/dC (conic) [5] d/dopacity [6] d/dz [7] -
 //   [8 + c] d/d payload channel c  (rgb first when colour is rendered, then features)
-// 16 floats (one 64-byte line) for <= 8 payload channels, 32 for <= 24, 64 beyond.
+// 16 floats (one 64-byte line) for <= 8 payload channels, 32 for <= 12, 64 beyond.
 struct GradLayout {
     size_t rec, total;
     int rec_floats;
 };
-inline int grad_rec_floats(const lsr_dims &d) {
-    const int nch = (d.color_mode != LSR_COLOR_NONE ? 3 : 0) + d.feat_channels;
-    return nch <= 8 ? 16 : (nch <= 24 ? 32 : 64);
-}
+inline int grad_rec_floats(const lsr_dims &d);
 
 inline int tiles_x(const lsr_dims &d) { return (d.width + LSR_TILE - 1) / LSR_TILE; }
 inline int tiles_y(const lsr_dims &d) { return (d.height + LSR_TILE - 1) / LSR_TILE; }
 inline int64_t num_tiles(const lsr_dims &d) { return (int64_t)tiles_x(d) * tiles_y(d); }
+
+// Screen-space record of one (view, Gaussian), written by k_preprocess and gathered (one 64-byte
+// line for <= 8 payload channels) by the compositing kernels:
+//   [0] x_pix [1] y_pix [2] conicA [3] conicB [4] conicC [5] opacity [6] view z [7] colour clamp bits
+//   [8 + c] payload channel c: rgb first when colour is rendered, then the feature channels; zero padded.
+// The packed gradient record of the backward pass (GradLayout) uses the same slot numbering.
+inline int rec_floats(const lsr_dims &d) {
+    const int nch = (d.color_mode != LSR_COLOR_NONE ? 3 : 0) + d.feat_channels;
+    return nch <= 8 ? 16 : (nch <= 12 ? 32 : 64);   // always >= 8 + the compositing kernels' padded channel count
+}
+// What the binning stage needs of a Gaussian, kept dense (16 B) so k_scatter streams it.
+struct BinRec {
+    ushort4 rect;      // tile rectangle [minx, miny, maxx, maxy)
+    float depth;       // view z (sort key bits)
+    int32_t radius;    // screen radius in pixels, 0 = culled
+};
 
 inline GeomLayout geom_layout(const lsr_dims &d) {
     GeomLayout L;
@@ -48,10 +62,9 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     const size_t VT = (size_t)d.num_views * (size_t)num_tiles(d);
     size_t o = 0;
     L.header = o; o += 256;
-    L.q0 = o; o = align_up(o + VG * 16);
-    L.q1 = o; o = align_up(o + VG * 16);
-    L.rect = o; o = align_up(o + VG * 8);
-    L.rgb = o; o = align_up(o + (d.color_mode != LSR_COLOR_NONE ? VG * 16 : 0));
+    L.rec_floats = rec_floats(d);
+    L.rec = o; o = align_up(o + VG * (size_t)L.rec_floats * 4);
+    L.bin = o; o = align_up(o + VG * sizeof(BinRec));
     L.tile_count = o; o = align_up(o + VT * 4);
     L.tile_cursor = o; o = align_up(o + VT * 4);   // adjacent to tile_count: one memset clears both
     L.tile_start = o; o = align_up(o + (VT + 1) * 4);
@@ -78,6 +91,7 @@ inline BinLayout bin_layout(const lsr_dims &d, int64_t num_pairs, int32_t max_ti
     L.total = L.tmp + (max_tile_pairs > kSortLdsMax ? align_up(P * 8) : 0);
     return L;
 }
+inline int grad_rec_floats(const lsr_dims &d) { return rec_floats(d); }
 inline GradLayout grad_layout(const lsr_dims &d) {
     GradLayout L;
     const size_t VG = (size_t)d.num_views * (size_t)d.num_gaussians;

@@ -22,10 +22,13 @@ constexpr int kPreItems = 8;  // Gaussians per thread => 2048 per block, one his
 
 template <int COLOR_MODE, bool LDS_HIST>
 __global__ void __launch_bounds__(kPreThreads)
-k_preprocess(lsr_dims d, lsr_inputs in, float4 *__restrict__ q0, float4 *__restrict__ q1,
-             ushort4 *__restrict__ rect, float4 *__restrict__ rgb, int32_t *__restrict__ radii,
-             uint32_t *__restrict__ tile_count) {
+k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec *__restrict__ binrec,
+             int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
     extern __shared__ uint32_t s_hist[];
+    // 64-byte records are staged here and stored by the whole block as one contiguous run
+    // (lane-contiguous 16-byte stores) instead of 4 strided partial-line stores per thread.
+    __shared__ float4 s_rec[kPreThreads * 4];
+    const bool staged = RF == 16;
     const int v = blockIdx.y;
     const int G = d.num_gaussians;
     const int gx = (d.width + LSR_TILE - 1) / LSR_TILE, gy = (d.height + LSR_TILE - 1) / LSR_TILE;
@@ -51,13 +54,19 @@ k_preprocess(lsr_dims d, lsr_inputs in, float4 *__restrict__ q0, float4 *__restr
     const int base = blockIdx.x * (kPreThreads * kPreItems);
 #pragma unroll 1
     for (int it = 0; it < kPreItems; ++it) {
-        const int i = base + it * kPreThreads + threadIdx.x;
-        if (i >= G) break;
-        const size_t o = (size_t)v * G + i;
-        const float p0 = means[3 * (size_t)i], p1 = means[3 * (size_t)i + 1], p2 = means[3 * (size_t)i + 2];
+        const int chunk0 = base + it * kPreThreads;
+        if (chunk0 >= G) break;   // block-uniform
+        const int i = chunk0 + threadIdx.x;
+        const bool in_range = i < G;
+        const size_t o = (size_t)v * G + (in_range ? i : 0);
+        const size_t ii = in_range ? (size_t)i : 0;
+        const float p0 = means[3 * ii], p1 = means[3 * ii + 1], p2 = means[3 * ii + 2];
+        float4 rr[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
         int32_t out_radius = 0;
+        float out_depth = 0.0f;
         ushort4 out_rect = make_ushort4(0, 0, 0, 0);
         do {
+            if (!in_range) break;
             const float t0 = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
             const float t1 = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
             const float t2 = vm[2] * p0 + vm[6] * p1 + vm[10] * p2 + vm[14];
@@ -106,6 +115,9 @@ k_preprocess(lsr_dims d, lsr_inputs in, float4 *__restrict__ q0, float4 *__restr
             const int rmaxy = imin_sel(gy, imax_sel(0, (int)((py + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
             if ((rmaxx - rminx) * (rmaxy - rminy) == 0) break;
 
+            float4 *R = (float4 *)(rec + o * (size_t)RF);
+            uint32_t clampbits = 0;
+            float pay[3] = {0.0f, 0.0f, 0.0f};
             if (COLOR_MODE == LSR_COLOR_SH) {
                 float dx = p0 - camx, dy = p1 - camy, dz = p2 - camz;
                 const float len = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -114,34 +126,64 @@ k_preprocess(lsr_dims d, lsr_inputs in, float4 *__restrict__ q0, float4 *__restr
                 sh_basis(d.sh_degree, dx, dy, dz, b);
                 const int nb = (d.sh_degree + 1) * (d.sh_degree + 1);
                 const float *sh = in.color + (size_t)v * d.vs_color + (size_t)i * d.sh_coeffs * 3;
-                float r[3];
-                uint32_t clampbits = 0;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     float acc = 0.0f;
                     for (int k = 0; k < nb; ++k) acc += b[k] * sh[3 * k + c];
                     acc += 0.5f;
                     if (acc < 0.0f) clampbits |= 1u << c;
-                    r[c] = fmax_sel(acc, 0.0f);
+                    pay[c] = fmax_sel(acc, 0.0f);
                 }
-                rgb[o] = make_float4(r[0], r[1], r[2], __uint_as_float(clampbits));
             } else if (COLOR_MODE == LSR_COLOR_PRECOMP) {
                 const float *cp = in.color + (size_t)v * d.vs_color + 3 * (size_t)i;
-                rgb[o] = make_float4(cp[0], cp[1], cp[2], 0.0f);
+                pay[0] = cp[0]; pay[1] = cp[1]; pay[2] = cp[2];
             }
             out_radius = (int32_t)my_radius;
             out_rect = make_ushort4((unsigned short)rminx, (unsigned short)rminy,
                                     (unsigned short)rmaxx, (unsigned short)rmaxy);
-            q0[o] = make_float4(px, py, conic_a, conic_b);
-            q1[o] = make_float4(conic_c, opac[i], tz, ca /* cov2D.xx, kept for diagnostics */);
+            out_depth = tz;
+            rr[0] = make_float4(px, py, conic_a, conic_b);
+            rr[1] = make_float4(conic_c, opac[i], tz, __uint_as_float(clampbits));
+            if (!staged) { R[0] = rr[0]; R[1] = rr[1]; }
+            {   // payload slots 8.. : rgb (if any) then the feature channels, zero padded
+                constexpr int coff = COLOR_MODE == LSR_COLOR_NONE ? 0 : 3;
+                const float *fp = in.features + (size_t)v * d.vs_feat + (size_t)i * d.feat_channels;
+                for (int c4 = 0; c4 < (RF - 8) / 4; ++c4) {
+                    float w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = 4 * c4 + k;
+                        w[k] = c < coff ? pay[c < 3 ? c : 0] : (c - coff < d.feat_channels ? fp[c - coff] : 0.0f);
+                    }
+                    if (staged) rr[c4 < 2 ? 2 + c4 : 2] = make_float4(w[0], w[1], w[2], w[3]);
+                    else R[2 + c4] = make_float4(w[0], w[1], w[2], w[3]);
+                }
+            }
             for (int y = rminy; y < rmaxy; ++y)
                 for (int x = rminx; x < rmaxx; ++x) {
                     if (LDS_HIST) atomicAdd(&s_hist[y * gx + x], 1u);
                     else atomicAdd(&tc[y * gx + x], 1u);
                 }
         } while (0);
-        radii[o] = out_radius;
-        rect[o] = out_rect;
+        if (in_range) {
+            radii[o] = out_radius;
+            BinRec br; br.rect = out_rect; br.depth = out_depth; br.radius = out_radius;
+            binrec[o] = br;
+        }
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_rec[threadIdx.x * 4 + k] = rr[k];
+            __syncthreads();
+            float4 *dst = (float4 *)(rec + ((size_t)v * G + chunk0) * 16);
+            const int nrec = G - chunk0 < kPreThreads ? G - chunk0 : kPreThreads;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = k * kPreThreads + threadIdx.x;      // float4 index inside the run
+                // culled Gaussians (view z == 0 in their staged record) are never read: skip them
+                if (idx < nrec * 4 && s_rec[(idx & ~3) + 1].z > 0.0f) dst[idx] = s_rec[idx];
+            }
+            __syncthreads();
+        }
     }
     if (LDS_HIST) {
         __syncthreads();
@@ -163,18 +205,18 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     if (e != hipSuccess) return e;
     if (d.num_gaussians == 0) return hipSuccess;
     dim3 grid((d.num_gaussians + kPreThreads * kPreItems - 1) / (kPreThreads * kPreItems), d.num_views);
-    float4 *q0 = (float4 *)(geom + L.q0), *q1 = (float4 *)(geom + L.q1);
-    ushort4 *rect = (ushort4 *)(geom + L.rect);
-    float4 *rgb = (float4 *)(geom + L.rgb);
+    float *rec = (float *)(geom + L.rec);
+    BinRec *binrec = (BinRec *)(geom + L.bin);
+    const int RF = L.rec_floats;
     uint32_t *tc = (uint32_t *)(geom + L.tile_count);
     const bool lds = T <= 8192;
     const size_t shm = lds ? (size_t)T * 4 : 0;
 #define LSR_PRE(CM)                                                                              \
     do {                                                                                         \
         if (lds) hipLaunchKernelGGL((k_preprocess<CM, true>), grid, dim3(kPreThreads), shm, s,   \
-                                    d, in, q0, q1, rect, rgb, radii, tc);                        \
+                                    d, in, rec, RF, binrec, radii, tc);                         \
         else hipLaunchKernelGGL((k_preprocess<CM, false>), grid, dim3(kPreThreads), 0, s, d, in, \
-                                q0, q1, rect, rgb, radii, tc);                                   \
+                                rec, RF, binrec, radii, tc);                                    \
     } while (0)
     prof_begin(kStPreprocess, s);
     if (d.color_mode == LSR_COLOR_SH) LSR_PRE(LSR_COLOR_SH);

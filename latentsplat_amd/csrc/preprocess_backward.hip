@@ -17,7 +17,8 @@ struct PreBwdParams {
     lsr_dims d;
     lsr_inputs in;
     const int32_t *radii;
-    const float4 *rgb;      // .w = clamp bits (SH mode)
+    const float *geo;       // screen-space records; slot 7 = colour clamp bits (SH mode)
+    int geo_floats;
     const float *rec;       // packed gradient records (lsr_internal.h GradLayout)
     int rec_floats;
     lsr_in_grads g;
@@ -153,8 +154,7 @@ k_preprocess_bwd(PreBwdParams p) {
                 sh_basis(d.sh_degree, x, y, z, bas);
                 sh_basis_grad(d.sh_degree, x, y, z, dbas);
                 const float *sh = p.in.color + (size_t)v * d.vs_color + (size_t)i * d.sh_coeffs * 3;
-                const float4 col = p.rgb[o];
-                const uint32_t clampbits = __float_as_uint(col.w);
+                const uint32_t clampbits = __float_as_uint(p.geo[o * (size_t)p.geo_floats + 7]);
                 const float gcol[3] = {(clampbits & 1u) ? 0.0f : rc[8], (clampbits & 2u) ? 0.0f : rc[9],
                                        (clampbits & 4u) ? 0.0f : rc[10]};
                 float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
@@ -215,7 +215,7 @@ hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, c
     const GradLayout R = grad_layout(d);
     PreBwdParams p;
     p.d = d; p.in = in; p.radii = radii;
-    p.rgb = (const float4 *)(geom + L.rgb);
+    p.geo = (const float *)(geom + L.rec); p.geo_floats = L.rec_floats;
     p.rec = (const float *)(grad + R.rec); p.rec_floats = R.rec_floats;
     p.g = gin;
     prof_begin(kStPreprocessBwd, s);

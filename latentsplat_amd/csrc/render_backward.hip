@@ -15,10 +15,9 @@ namespace lsr {
 
 struct RenderBwdParams {
     int H, W, gx, T, G, C, has_color;
-    int64_t vs_feat;
     const float *views;
-    const float4 *q0, *q1, *rgb;
-    const float *features;
+    const float4 *geo;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
+    int rec_f4;
     const uint32_t *tile_start, *point_list;
     const float *final_T;
     const uint32_t *n_contrib;
@@ -100,7 +99,8 @@ k_render_bwd(RenderBwdParams p) {
         uint32_t m = 0;
         if (rel < maxlast) {
             const uint32_t g = p.point_list[start + rel];
-            const float4 a = p.q0[vG + g], b = p.q1[vG + g];
+            const float4 *R = p.geo + (vG + g) * (size_t)p.rec_f4;
+            const float4 a = R[0], b = R[1];
             m = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own;
             if (m) {
                 const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
@@ -108,20 +108,8 @@ k_render_bwd(RenderBwdParams p) {
                 s_q1[lane] = make_float4(b.x, b.y, b.z, __uint_as_float(m));
                 s_q2[lane] = make_float4(f.a2, f.b2, f.c2, f.l2o);
                 s_gid[lane] = g;
-                float pay[NCHP];
 #pragma unroll
-                for (int c = 0; c < NCHP; ++c) pay[c] = 0.0f;
-                if (p.has_color) {
-                    const float4 col = p.rgb[vG + g];
-                    pay[0] = col.x; pay[1] = col.y; pay[2] = col.z;
-                }
-                const float *fp = p.features + (size_t)v * p.vs_feat + (size_t)g * p.C;
-#pragma unroll
-                for (int c = 0; c < NCHP; ++c)
-                    if (c >= coff && c - coff < p.C) pay[c] = fp[c - coff];
-#pragma unroll
-                for (int c4 = 0; c4 < NCHP / 4; ++c4)
-                    s_pay[lane][c4] = make_float4(pay[4 * c4], pay[4 * c4 + 1], pay[4 * c4 + 2], pay[4 * c4 + 3]);
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) s_pay[lane][c4] = R[2 + c4];
             }
         }
         uint64_t todo = __ballot(m != 0);
@@ -240,11 +228,8 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     RenderBwdParams p;
     p.H = d.height; p.W = d.width; p.gx = tiles_x(d); p.T = (int)num_tiles(d); p.G = d.num_gaussians;
     p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE;
-    p.vs_feat = d.vs_feat;
     p.views = in.views;
-    p.q0 = (const float4 *)(geom + L.q0); p.q1 = (const float4 *)(geom + L.q1);
-    p.rgb = (const float4 *)(geom + L.rgb);
-    p.features = in.features;
+    p.geo = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
     p.tile_start = (const uint32_t *)(geom + L.tile_start);
     p.point_list = (const uint32_t *)(bin + B.point_list);
     p.final_T = (const float *)(img + I.final_T); p.n_contrib = (const uint32_t *)(img + I.n_contrib);

@@ -35,10 +35,9 @@ struct RenderFwdParams {
     const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t *queue;              // work-queue head (zeroed per forward)
     unsigned long long *trace;    // debug (LSR_TRACE): per item {start clk, end clk, hw id, entries}
-    int64_t vs_feat;
     const float *views;
-    const float4 *q0, *q1, *rgb;
-    const float *features;
+    const float4 *rec;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
+    int rec_f4;
     const uint32_t *tile_start, *point_list;
     float *out_color, *out_feat, *out_mask, *out_depth;
     float *final_T;
@@ -109,26 +108,15 @@ k_render_fwd(RenderFwdParams p) {
             uint32_t m = 0;
             if (e < end) {
                 const uint32_t g = p.point_list[e];
-                const float4 a = p.q0[vG + g], b = p.q1[vG + g];  // (x,y,A,B) (C,o,z,-)
+                const float4 *R = p.rec + (vG + g) * (size_t)p.rec_f4;
+                const float4 a = R[0], b = R[1];  // (x,y,A,B) (C,o,z,-)
                 m = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own;
                 if (m) {
                     const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
                     s_q0[lane] = make_float4(a.x, a.y, f.a2, f.b2);
                     s_q1[lane] = make_float4(f.c2, f.l2o, b.z, 0.0f);
-                    float pay[NCHP];
 #pragma unroll
-                    for (int c = 0; c < NCHP; ++c) pay[c] = 0.0f;
-                    if (p.has_color) {
-                        const float4 col = p.rgb[vG + g];
-                        pay[0] = col.x; pay[1] = col.y; pay[2] = col.z;
-                    }
-                    const float *fp = p.features + (size_t)v * p.vs_feat + (size_t)g * p.C;
-#pragma unroll
-                    for (int c = 0; c < NCHP; ++c)
-                        if (c >= coff && c - coff < p.C) pay[c] = fp[c - coff];
-#pragma unroll
-                    for (int c4 = 0; c4 < NCHP / 4; ++c4)
-                        s_pay[lane][c4] = make_float4(pay[4 * c4], pay[4 * c4 + 1], pay[4 * c4 + 2], pay[4 * c4 + 3]);
+                    for (int c4 = 0; c4 < NCHP / 4; ++c4) s_pay[lane][c4] = R[2 + c4];  // payload, zero padded
                 }
             }
             // per quadrant: which staged entries can touch it (wave-uniform 64-bit masks)
@@ -235,14 +223,12 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     const BinLayout B = bin_layout(d, num_pairs, 0);
     RenderFwdParams p;
     p.H = d.height; p.W = d.width; p.gx = tiles_x(d); p.T = (int)num_tiles(d); p.G = d.num_gaussians;
-    p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE; p.vs_feat = d.vs_feat;
+    p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE;
     p.items = (const uint32_t *)(geom + L.tile_order);
     p.header = (const uint32_t *)(geom + L.header);
     p.queue = (uint32_t *)(geom + L.header) + kHdrQueueFwd;
     p.views = in.views;
-    p.q0 = (const float4 *)(geom + L.q0); p.q1 = (const float4 *)(geom + L.q1);
-    p.rgb = (const float4 *)(geom + L.rgb);
-    p.features = in.features;
+    p.rec = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
     p.tile_start = (const uint32_t *)(geom + L.tile_start);
     p.point_list = (const uint32_t *)(bin + B.point_list);
     p.out_color = out.color; p.out_feat = out.feature; p.out_mask = out.mask; p.out_depth = out.depth;

@@ -128,14 +128,17 @@ class HipRun:
 
     def rect(self):
         n = self.d.num_views * self.d.num_gaussians
-        return self._view(self.geom, self.layout.geom_rect, n * 8, torch.int16).cpu().numpy().astype(np.int32).reshape(
-            self.d.num_views, self.d.num_gaussians, 4) & 0xFFFF
+        b = self._view(self.geom, self.layout.geom_bin, n * 16, torch.int16).cpu().numpy().astype(np.int32).reshape(
+            self.d.num_views, self.d.num_gaussians, 8)
+        return b[:, :, :4] & 0xFFFF
 
     def q(self):
+        """(x,y,A,B), (C,o,z,clampbits) of every (view, Gaussian) screen-space record."""
         n = self.d.num_views * self.d.num_gaussians
-        q0 = self._view(self.geom, self.layout.geom_q0, n * 16, torch.float32).cpu().numpy().reshape(self.d.num_views, -1, 4)
-        q1 = self._view(self.geom, self.layout.geom_q1, n * 16, torch.float32).cpu().numpy().reshape(self.d.num_views, -1, 4)
-        return q0, q1
+        rf = self.layout.geom_rec_floats
+        r = self._view(self.geom, self.layout.geom_rec, n * rf * 4, torch.float32).cpu().numpy().reshape(
+            self.d.num_views, -1, rf)
+        return r[:, :, 0:4], r[:, :, 4:8]
 
     def n_contrib(self):
         n = self.d.num_views * self.d.height * self.d.width
