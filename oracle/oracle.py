@@ -103,14 +103,18 @@ def forward(view: View, means3D, cov3D, opacities, shs=None, colors_precomp=None
     final_T = np.zeros((H, W), np.float32)
     n_contrib = np.zeros((H, W), np.uint32)
     n_considered = np.zeros((H, W), np.uint32)
+    fragile = np.zeros((4096, 2), np.int32)
+    fragile_count = ctypes.c_int32(0)
     L.oracle_render(ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(C), _p(ranges), _p(plist),
                     _p(xy), _p(co), _p(depth), _p(rgb), _p(features), _p(bg), _p(out_color),
-                    _p(out_feat), _p(out_mask), _p(out_depth), _p(final_T), _p(n_contrib), _p(n_considered))
+                    _p(out_feat), _p(out_mask), _p(out_depth), _p(final_T), _p(n_contrib), _p(n_considered),
+                    _p(fragile), ctypes.c_int(4096), ctypes.byref(fragile_count))
     res = dict(color=out_color, feature=out_feat, mask=out_mask, depth=out_depth, radii=radii, P=int(P))
     if keep_intermediates:
         res.update(rect=rect, tiles_touched=tiles, gdepth=depth, xy=xy, conic_opacity=co, rgb=rgb,
                    clamped=clamped, keys=keys[:P], point_list=plist[:P], ranges=ranges,
-                   final_T=final_T, n_contrib=n_contrib, n_considered=n_considered)
+                   final_T=final_T, n_contrib=n_contrib, n_considered=n_considered,
+                   fragile=fragile[:min(fragile_count.value, 4096)], fragile_overflow=fragile_count.value > 4096)
     return res
 
 
