@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSR_ABI_VERSION 1
+#define LSR_ABI_VERSION 2
 #define LSR_TILE 16            /* tile edge in pixels (16x16 = the published algorithm's tile) */
 #define LSR_MAX_FEAT_CHANNELS 32
 #define LSR_MAX_SH_DEGREE 4
@@ -50,10 +50,15 @@ extern "C" {
  *   [16..31] projmatrix  — memory of `settings.projmatrix` (transposed world->clip, :117,140)
  *   [32..34] campos      — `settings.campos` (:142)
  *   [35]     tanfovx, [36] tanfovy   (:135-136)
- *   [37..39] bg          — `settings.bg` (3 entries; feature background is 0) (:137)          */
-#define LSR_VIEW_FLOATS 40
+ *   [37..39] bg          — `settings.bg` (3 entries; feature background is 0) (:137)
+ *   [40]     scene scale — means3D are multiplied by it and covariances by its square before
+ *                          projection (the `1/near` scale invariance of cuda_splatting.py:75-82
+ *                          applied in-kernel; 1.0 when the caller already scaled its inputs)
+ *   [41..43] reserved (0)                                                                      */
+#define LSR_VIEW_FLOATS 44
 
 enum { LSR_COLOR_NONE = 0, LSR_COLOR_SH = 1, LSR_COLOR_PRECOMP = 2 };
+enum { LSR_FEAT_DIRECT = 0, LSR_FEAT_SH = 1 };
 
 enum {
     LSR_OK = 0,
@@ -79,7 +84,19 @@ typedef struct lsr_dims {
     int64_t vs_cov;         /* cov3D_precomp (G,6): xx,xy,xz,yy,yz,zz (cuda_splatting.py:148,157) */
     int64_t vs_opac;        /* opacities (G,1)   */
     int64_t vs_color;       /* shs (G,K,3) or colors_precomp (G,3) */
-    int64_t vs_feat;        /* features  (G,C)   */
+    int64_t vs_feat;        /* features  (G,C) or feature SH coefficients (G,C,Kf) */
+    /* --- fused scene-level inputs (what the reference computes in PyTorch before the call) --- */
+    int32_t cov_elems;      /* 6: packed upper triangle (the reference boundary); 9: row-major 3x3
+                               `gaussian_covariances`, upper triangle read, gradient written to it */
+    int32_t feat_mode;      /* LSR_FEAT_DIRECT: `features` are per-Gaussian channel values (boundary);
+                               LSR_FEAT_SH: `features` holds latent SH coefficients (G,C,Kf) and the
+                               kernel evaluates 0.5 + eval_sh(dir) itself (cuda_splatting.py:94-101) */
+    int32_t feat_sh_degree; /* 0..2 when feat_mode == LSR_FEAT_SH */
+    int32_t feat_sh_coeffs; /* Kf >= (feat_sh_degree+1)^2, C*Kf <= 120 */
+    int32_t color_sh_channel_major; /* 0: shs (G,K,3) as the reference hands them to the rasterizer;
+                               1: (G,3,K) = `gaussian_color_sh_coefficients` as stored (skips the
+                               `rearrange(...).contiguous()` copy of cuda_splatting.py:91) */
+    int32_t reserved0;
 } lsr_dims;
 
 typedef struct lsr_inputs {

@@ -14,8 +14,10 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # LSR_LIB selects an alternative build of the same library (kernel A/B experiments only)
 _SO = os.environ.get("LSR_LIB") or os.path.join(_CSRC, "liblsr_hip.so")
 
-VIEW_FLOATS = 40
+VIEW_FLOATS = 44
 COLOR_NONE, COLOR_SH, COLOR_PRECOMP = 0, 1, 2
+FEAT_DIRECT, FEAT_SH = 0, 1
+MAX_SH_GROUP_FLOATS = 120   # C*Kf the fused latent-SH path supports (LDS budget of sh.hip)
 MAX_FEAT_CHANNELS = 32
 
 
@@ -28,7 +30,9 @@ class Dims(C.Structure):
                 ("width", C.c_int32), ("feat_channels", C.c_int32), ("color_mode", C.c_int32),
                 ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32), ("vs_means", C.c_int64),
                 ("vs_cov", C.c_int64), ("vs_opac", C.c_int64), ("vs_color", C.c_int64),
-                ("vs_feat", C.c_int64)]
+                ("vs_feat", C.c_int64), ("cov_elems", C.c_int32), ("feat_mode", C.c_int32),
+                ("feat_sh_degree", C.c_int32), ("feat_sh_coeffs", C.c_int32),
+                ("color_sh_channel_major", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Inputs(C.Structure):
@@ -116,7 +120,7 @@ def load():
     lib.lsr_profile_stage_name.restype = C.c_char_p
     lib.lsr_profile_stage_name.argtypes = [C.c_int]
     lib.lsr_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(I64)]
-    if lib.lsr_abi_version() != 1:
+    if lib.lsr_abi_version() != 2:
         raise LsrError("liblsr_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -84,10 +84,20 @@ static int check_dims(const lsr_dims *d) {
     const int64_t G = d->num_gaussians;
     const int64_t color_elems = d->color_mode == LSR_COLOR_SH ? (int64_t)d->sh_coeffs * 3 : 3;
     if (d->vs_means != 0 && d->vs_means != 3 * G) return LSR_EINVAL;
-    if (d->vs_cov != 0 && d->vs_cov != 6 * G) return LSR_EINVAL;
+    if (d->cov_elems != 6 && d->cov_elems != 9) return LSR_EINVAL;
+    if (d->vs_cov != 0 && d->vs_cov != (int64_t)d->cov_elems * G) return LSR_EINVAL;
     if (d->vs_opac != 0 && d->vs_opac != G) return LSR_EINVAL;
     if (d->color_mode != LSR_COLOR_NONE && d->vs_color != 0 && d->vs_color != color_elems * G) return LSR_EINVAL;
-    if (d->feat_channels > 0 && d->vs_feat != 0 && d->vs_feat != (int64_t)d->feat_channels * G) return LSR_EINVAL;
+    if (d->feat_mode != LSR_FEAT_DIRECT && d->feat_mode != LSR_FEAT_SH) return LSR_EINVAL;
+    int64_t feat_elems = d->feat_channels;
+    if (d->feat_channels > 0 && d->feat_mode == LSR_FEAT_SH) {
+        if (d->feat_sh_degree < 0 || d->feat_sh_degree > 2) return LSR_EUNSUPPORTED;
+        if (d->feat_sh_coeffs < (d->feat_sh_degree + 1) * (d->feat_sh_degree + 1)) return LSR_EINVAL;
+        feat_elems = (int64_t)d->feat_channels * d->feat_sh_coeffs;
+        if (feat_elems > 120) return LSR_EUNSUPPORTED;   // LDS budget of the SH kernels (sh.hip)
+    }
+    if (d->color_mode == LSR_COLOR_SH && d->sh_coeffs * 3 > 120) return LSR_EUNSUPPORTED;
+    if (d->feat_channels > 0 && d->vs_feat != 0 && d->vs_feat != feat_elems * G) return LSR_EINVAL;
     return LSR_OK;
 }
 static int check_inputs(const lsr_dims *d, const lsr_inputs *in) {
@@ -111,7 +121,8 @@ int lsr_profile_enable(int on) {
 int lsr_profile_num_stages(void) { return lsr::kNumStages; }
 const char *lsr_profile_stage_name(int stage) {
     static const char *names[lsr::kNumStages] = {"preprocess", "tile_scan", "scatter", "sort_tiles",
-                                                  "render_forward", "render_backward", "preprocess_backward"};
+                                                  "render_forward", "render_backward", "preprocess_backward",
+                                                  "sh_forward", "sh_backward"};
     return (stage >= 0 && stage < lsr::kNumStages) ? names[stage] : "?";
 }
 int lsr_profile_read(double *ms_out, int64_t *launches_out) {
@@ -204,6 +215,7 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
     if (num_pairs < 0 || max_tile_pairs < 0) return LSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    LSR_STAGE("sh_forward", s, launch_sh_forward(*d, *in, (char *)geom_ws, s));
     LSR_STAGE("binning", s, launch_binning(*d, (char *)geom_ws, (char *)bin_ws, num_pairs, max_tile_pairs, out->radii, s));
     LSR_STAGE("render_forward", s, launch_render_forward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs, (char *)img_ws, *out, s));
     return LSR_OK;
@@ -231,6 +243,7 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
         LSR_STAGE("render_backward", s, launch_render_backward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs,
                                        (const char *)img_ws, *gout, (char *)grad_ws, *gin, s));
     LSR_STAGE("preprocess_backward", s, launch_preprocess_backward(*d, *in, (const char *)geom_ws, radii, (const char *)grad_ws, *gin, s));
+    LSR_STAGE("sh_backward", s, launch_sh_backward(*d, *in, (const char *)geom_ws, (const char *)grad_ws, *gin, s));
     return LSR_OK;
 }
 

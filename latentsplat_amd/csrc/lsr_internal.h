@@ -124,7 +124,7 @@ constexpr int kWaveSlots = 256 * 4 * 4;   // CUs x SIMDs x resident compositing 
 enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrQueueFwd = 2, kHdrNumItems = 3 };
 
 // ---- optional per-stage hipEvent timing (api.hip); no-ops unless lsr_profile_enable(1) ----
-enum Stage { kStPreprocess = 0, kStTileScan, kStScatter, kStSort, kStRenderFwd, kStRenderBwd, kStPreprocessBwd, kNumStages };
+enum Stage { kStPreprocess = 0, kStTileScan, kStScatter, kStSort, kStRenderFwd, kStRenderBwd, kStPreprocessBwd, kStShFwd, kStShBwd, kNumStages };
 void prof_begin(int stage, hipStream_t s);
 void prof_end(int stage, hipStream_t s);
 
@@ -132,6 +132,9 @@ void prof_end(int stage, hipStream_t s);
 hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii,
                              hipStream_t s);
 hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s);
+hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s);
+hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom, const char *grad,
+                              const lsr_in_grads &gin, hipStream_t s);
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
                           int32_t max_tile_pairs, const int32_t *radii, hipStream_t s);
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,

@@ -1,11 +1,12 @@
 // preprocess.hip — stage K1: per-(view, Gaussian) projection, EWA covariance, conic, radius,
 // tile rectangle, colour from SH, plus the per-tile pair histogram (LDS-privatised).
+// View-dependent payload channels (colour from SH, latent features from SH) are filled in
+// afterwards by sh.hip for the Gaussians that survive culling.
 //
 // Build this file with -ffp-contract=off: radius / rectangle / depth bits feed the bit-exact
 // tile lists, so every float operation must be the single IEEE operation written here (the CPU
 // oracle performs the identical sequence).  Spec: SURVEY.md Appendix A.1-A.3.
 #include "lsr_internal.h"
-#include "lsr_sh.h"
 
 namespace lsr {
 
@@ -41,11 +42,12 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
     float vm[16], pm[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { vm[k] = vw[k]; pm[k] = vw[16 + k]; }
-    const float camx = vw[32], camy = vw[33], camz = vw[34];
     const float tanfovx = vw[35], tanfovy = vw[36];
     const float focal_x = d.width / (2.0f * tanfovx);
     const float focal_y = d.height / (2.0f * tanfovy);
     const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    const float scale = vw[40], scale2 = scale * scale;   // scene scale (1/near), applied like the reference does
+    const int ce = d.cov_elems;
     const float *means = in.means3D + (size_t)v * d.vs_means;
     const float *covs = in.cov3D + (size_t)v * d.vs_cov;
     const float *opac = in.opacities + (size_t)v * d.vs_opac;
@@ -60,7 +62,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
         const bool in_range = i < G;
         const size_t o = (size_t)v * G + (in_range ? i : 0);
         const size_t ii = in_range ? (size_t)i : 0;
-        const float p0 = means[3 * ii], p1 = means[3 * ii + 1], p2 = means[3 * ii + 2];
+        const float p0 = means[3 * ii] * scale, p1 = means[3 * ii + 1] * scale, p2 = means[3 * ii + 2] * scale;
         float4 rr[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
         int32_t out_radius = 0;
         float out_depth = 0.0f;
@@ -89,8 +91,9 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
             const float m10 = j11 * vm[1] + j12 * vm[2];
             const float m11 = j11 * vm[5] + j12 * vm[6];
             const float m12 = j11 * vm[9] + j12 * vm[10];
-            const float *c6 = covs + 6 * (size_t)i;
-            const float s0 = c6[0], s1 = c6[1], s2 = c6[2], s3 = c6[3], s4 = c6[4], s5 = c6[5];
+            const float *c6 = covs + (size_t)ce * (size_t)i;
+            const float s0 = c6[0] * scale2, s1 = c6[1] * scale2, s2 = c6[2] * scale2;
+            const float s3 = c6[ce == 9 ? 4 : 3] * scale2, s4 = c6[ce == 9 ? 5 : 4] * scale2, s5 = c6[ce == 9 ? 8 : 5] * scale2;
             const float v00 = s0 * m00 + s1 * m01 + s2 * m02;
             const float v01 = s1 * m00 + s3 * m01 + s4 * m02;
             const float v02 = s2 * m00 + s4 * m01 + s5 * m02;
@@ -116,24 +119,10 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
             if ((rmaxx - rminx) * (rmaxy - rminy) == 0) break;
 
             float4 *R = (float4 *)(rec + o * (size_t)RF);
-            uint32_t clampbits = 0;
+            const uint32_t clampbits = 0;
             float pay[3] = {0.0f, 0.0f, 0.0f};
             if (COLOR_MODE == LSR_COLOR_SH) {
-                float dx = p0 - camx, dy = p1 - camy, dz = p2 - camz;
-                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-                dx = dx / len; dy = dy / len; dz = dz / len;
-                float b[25];
-                sh_basis(d.sh_degree, dx, dy, dz, b);
-                const int nb = (d.sh_degree + 1) * (d.sh_degree + 1);
-                const float *sh = in.color + (size_t)v * d.vs_color + (size_t)i * d.sh_coeffs * 3;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float acc = 0.0f;
-                    for (int k = 0; k < nb; ++k) acc += b[k] * sh[3 * k + c];
-                    acc += 0.5f;
-                    if (acc < 0.0f) clampbits |= 1u << c;
-                    pay[c] = fmax_sel(acc, 0.0f);
-                }
+                // filled by k_sh (sh.hip) for visible Gaussians
             } else if (COLOR_MODE == LSR_COLOR_PRECOMP) {
                 const float *cp = in.color + (size_t)v * d.vs_color + 3 * (size_t)i;
                 pay[0] = cp[0]; pay[1] = cp[1]; pay[2] = cp[2];
@@ -147,13 +136,15 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
             if (!staged) { R[0] = rr[0]; R[1] = rr[1]; }
             {   // payload slots 8.. : rgb (if any) then the feature channels, zero padded
                 constexpr int coff = COLOR_MODE == LSR_COLOR_NONE ? 0 : 3;
+                const bool direct_feat = d.feat_mode == LSR_FEAT_DIRECT;
                 const float *fp = in.features + (size_t)v * d.vs_feat + (size_t)i * d.feat_channels;
                 for (int c4 = 0; c4 < (RF - 8) / 4; ++c4) {
                     float w[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int c = 4 * c4 + k;
-                        w[k] = c < coff ? pay[c < 3 ? c : 0] : (c - coff < d.feat_channels ? fp[c - coff] : 0.0f);
+                        w[k] = c < coff ? pay[c < 3 ? c : 0]
+                                        : ((direct_feat && c - coff < d.feat_channels) ? fp[c - coff] : 0.0f);
                     }
                     if (staged) rr[c4 < 2 ? 2 + c4 : 2] = make_float4(w[0], w[1], w[2], w[3]);
                     else R[2 + c4] = make_float4(w[0], w[1], w[2], w[3]);

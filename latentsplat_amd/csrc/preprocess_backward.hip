@@ -1,15 +1,14 @@
 // preprocess_backward.hip — stages K8+K9 fused: per Gaussian, push the screen-space gradients
 // collected by the compositing backward through
 //   conic -> 2D covariance -> 3D covariance (6 packed values) and -> view-space mean (via J),
-//   NDC mean -> world mean (perspective divide),  rgb -> SH coefficients and view direction,
-//   view z -> world mean (depth output).
+//   NDC mean -> world mean (perspective divide),  view z -> world mean (depth output),
+// and back through the in-kernel scene scale.  (SH colour / latent-SH gradients: sh.hip.)
 // Also scatters the per-(view, Gaussian) opacity / feature / precomputed-colour gradients from the
 // packed records to the caller's tensors.
 // One thread owns one Gaussian for ALL views, so inputs shared between views (stride 0) get their
 // gradients summed in registers / thread-private read-modify-write, without atomics.
 // Spec: SURVEY.md Appendix A.6.
 #include "lsr_internal.h"
-#include "lsr_sh.h"
 
 namespace lsr {
 
@@ -31,8 +30,7 @@ k_preprocess_bwd(PreBwdParams p) {
     const int G = d.num_gaussians;
     if (i >= G) return;
     const int V = d.num_views;
-    const bool sh_mode = d.color_mode == LSR_COLOR_SH;
-    const int nb = (d.sh_degree + 1) * (d.sh_degree + 1);
+    const int ce = d.cov_elems;
     float am[3] = {0, 0, 0}, ac[6] = {0, 0, 0, 0, 0, 0}, aop = 0.0f;  // accumulators for shared inputs
     const int coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
     for (int v = 0; v < V; ++v) {
@@ -41,7 +39,7 @@ k_preprocess_bwd(PreBwdParams p) {
         const float4 r0 = *(const float4 *)rc, r1 = *(const float4 *)(rc + 4);  // gx gy gA gB | gC go gz -
         // opacity / features / precomputed colours: plain pass-through of the record
         if (d.vs_opac != 0) p.g.opacities[(size_t)v * d.vs_opac + i] = r1.y; else aop += r1.y;
-        if (d.feat_channels > 0) {
+        if (d.feat_channels > 0 && d.feat_mode == LSR_FEAT_DIRECT) {
             float *gf = p.g.features + (size_t)v * d.vs_feat + (size_t)i * d.feat_channels;
             const bool first = d.vs_feat != 0 || v == 0;
             for (int c = 0; c < d.feat_channels; ++c) gf[c] = first ? rc[8 + coff + c] : gf[c] + rc[8 + coff + c];
@@ -54,15 +52,14 @@ k_preprocess_bwd(PreBwdParams p) {
         float gm[3] = {0, 0, 0}, gc[6] = {0, 0, 0, 0, 0, 0};
         float m2x = 0.0f, m2y = 0.0f;
         const bool vis = p.radii[o] > 0;
-        float *gsh = sh_mode ? p.g.color + (size_t)v * d.vs_color + (size_t)i * d.sh_coeffs * 3 : nullptr;
-        const bool sh_first = sh_mode && (d.vs_color != 0 || v == 0);
         if (vis) {
             const float *vw = p.in.views + (size_t)v * LSR_VIEW_FLOATS;
             const float *vm = vw, *pm = vw + 16;
             const float tanfovx = vw[35], tanfovy = vw[36];
             const float focal_x = d.width / (2.0f * tanfovx), focal_y = d.height / (2.0f * tanfovy);
+            const float scale = vw[40], scale2 = scale * scale;
             const float *mp = p.in.means3D + (size_t)v * d.vs_means + 3 * (size_t)i;
-            const float p0 = mp[0], p1 = mp[1], p2 = mp[2];
+            const float p0 = mp[0] * scale, p1 = mp[1] * scale, p2 = mp[2] * scale;
             // ---- covariance path ----
             const float t0 = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
             const float t1 = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
@@ -83,8 +80,10 @@ k_preprocess_bwd(PreBwdParams p) {
                 M[0][c] = j00 * vm[4 * c + 0] + j02 * vm[4 * c + 2];
                 M[1][c] = j11 * vm[4 * c + 1] + j12 * vm[4 * c + 2];
             }
-            const float *c6 = p.in.cov3D + (size_t)v * d.vs_cov + 6 * (size_t)i;
-            const float S[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+            const float *c6 = p.in.cov3D + (size_t)v * d.vs_cov + (size_t)ce * (size_t)i;
+            const float sxx = c6[0] * scale2, sxy = c6[1] * scale2, sxz = c6[2] * scale2;
+            const float syy = c6[ce == 9 ? 4 : 3] * scale2, syz = c6[ce == 9 ? 5 : 4] * scale2, szz = c6[ce == 9 ? 8 : 5] * scale2;
+            const float S[3][3] = {{sxx, sxy, sxz}, {sxy, syy, syz}, {sxz, syz, szz}};
             float MS[2][3];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -143,49 +142,25 @@ k_preprocess_bwd(PreBwdParams p) {
             for (int cc = 0; cc < 3; ++cc)
                 gm[cc] += (pm[4 * cc + 0] * m_w - pm[4 * cc + 3] * mul1) * m2x +
                           (pm[4 * cc + 1] * m_w - pm[4 * cc + 3] * mul2) * m2y;
-            // ---- colour path (SH) ----
-            if (sh_mode) {
-                const float dxr = p0 - vw[32], dyr = p1 - vw[33], dzr = p2 - vw[34];
-                const float len = sqrtf(dxr * dxr + dyr * dyr + dzr * dzr);
-                const float ilen = 1.0f / len;
-                const float x = dxr * ilen, y = dyr * ilen, z = dzr * ilen;
-                float bas[25];
-                float dbas[25][3];
-                sh_basis(d.sh_degree, x, y, z, bas);
-                sh_basis_grad(d.sh_degree, x, y, z, dbas);
-                const float *sh = p.in.color + (size_t)v * d.vs_color + (size_t)i * d.sh_coeffs * 3;
-                const uint32_t clampbits = __float_as_uint(p.geo[o * (size_t)p.geo_floats + 7]);
-                const float gcol[3] = {(clampbits & 1u) ? 0.0f : rc[8], (clampbits & 2u) ? 0.0f : rc[9],
-                                       (clampbits & 4u) ? 0.0f : rc[10]};
-                float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;
-                for (int k = 0; k < nb; ++k) {
+            // gradients are w.r.t. the UNSCALED inputs: mean_scaled = s * mean, cov_scaled = s^2 * cov
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
-                        const float gval = bas[k] * gcol[ch];
-                        float *dst = gsh + 3 * k + ch;
-                        *dst = sh_first ? gval : *dst + gval;
-                        const float sg = sh[3 * k + ch] * gcol[ch];
-                        ddx += dbas[k][0] * sg; ddy += dbas[k][1] * sg; ddz += dbas[k][2] * sg;
-                    }
-                }
-                if (sh_first)
-                    for (int k = nb * 3; k < d.sh_coeffs * 3; ++k) gsh[k] = 0.0f;
-                const float dot = ddx * x + ddy * y + ddz * z;
-                gm[0] += (ddx - x * dot) * ilen;
-                gm[1] += (ddy - y * dot) * ilen;
-                gm[2] += (ddz - z * dot) * ilen;
-            }
-        } else if (sh_first) {
-            for (int k = 0; k < d.sh_coeffs * 3; ++k) gsh[k] = 0.0f;
+            for (int cc = 0; cc < 3; ++cc) gm[cc] *= scale;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gc[k] *= scale2;
         }
         if (d.vs_means != 0) {
             float *o3 = p.g.means3D + (size_t)v * d.vs_means + 3 * (size_t)i;
             o3[0] = gm[0]; o3[1] = gm[1]; o3[2] = gm[2];
         } else { am[0] += gm[0]; am[1] += gm[1]; am[2] += gm[2]; }
         if (d.vs_cov != 0) {
-            float *o6 = p.g.cov3D + (size_t)v * d.vs_cov + 6 * (size_t)i;
+            float *o6 = p.g.cov3D + (size_t)v * d.vs_cov + (size_t)ce * (size_t)i;
+            if (ce == 9) {   // upper triangle carries the gradient (that is what the packing reads)
+                o6[0] = gc[0]; o6[1] = gc[1]; o6[2] = gc[2]; o6[3] = 0.0f; o6[4] = gc[3]; o6[5] = gc[4];
+                o6[6] = 0.0f; o6[7] = 0.0f; o6[8] = gc[5];
+            } else {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) o6[k] = gc[k];
+                for (int k = 0; k < 6; ++k) o6[k] = gc[k];
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 6; ++k) ac[k] += gc[k];
@@ -200,9 +175,14 @@ k_preprocess_bwd(PreBwdParams p) {
         o3[0] = am[0]; o3[1] = am[1]; o3[2] = am[2];
     }
     if (d.vs_cov == 0) {
-        float *o6 = p.g.cov3D + 6 * (size_t)i;
+        float *o6 = p.g.cov3D + (size_t)ce * (size_t)i;
+        if (ce == 9) {
+            o6[0] = ac[0]; o6[1] = ac[1]; o6[2] = ac[2]; o6[3] = 0.0f; o6[4] = ac[3]; o6[5] = ac[4];
+            o6[6] = 0.0f; o6[7] = 0.0f; o6[8] = ac[5];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) o6[k] = ac[k];
+            for (int k = 0; k < 6; ++k) o6[k] = ac[k];
+        }
     }
     if (d.vs_opac == 0) p.g.opacities[i] = aop;
 }

@@ -8,7 +8,14 @@ into the MI355X rasterizer.  Same public names, arguments and return types as th
     (the reference loops ``for i in range(b)`` with two ``.item()`` syncs per view, :124-162);
   * nothing is synchronised with the host here (tan(fov) stays on the device);
   * ``render_scenes`` (new) takes scene-major inputs so Gaussians are NOT replicated per view
-    (the reference ``repeat``s every tensor v times, decoder_splatting_cuda.py:71-87).
+    (the reference ``repeat``s every tensor v times, decoder_splatting_cuda.py:71-87);
+  * the per-view pre-pass the reference runs in PyTorch — ``1/near`` scaling of means and
+    covariances (:75-82), packing the covariance triangle (:148,157), the ``(g,3,n)->(g,n,3)``
+    copy of the colour SH (:91) and the latent-feature SH evaluation (:94-101) — happens inside
+    the kernels (scene scale in the view table, 3x3 covariances, channel-major SH, ``feature_sh``).
+    ``_scale_scene`` / ``_payload`` / ``_pack_covariances`` remain as the host-side statement of
+    that math (fallback for SH shapes the kernel does not fuse, and what the tests pin against
+    the reference).
 """
 from __future__ import annotations
 
@@ -19,7 +26,7 @@ from typing import Literal, Optional
 import torch
 from torch import Tensor
 
-from ..rasterizer import make_view_table, rasterize_views
+from ..rasterizer import fused_feature_sh_supported, make_view_table, rasterize_views
 from .geometry import depth_to_relative_disparity, eval_sh, get_fov, homogenize_points
 
 
@@ -96,18 +103,45 @@ def _squeeze_shared(t: Optional[Tensor]) -> Optional[Tensor]:
     return t[0] if (t is not None and t.shape[0] == 1) else t
 
 
-def _render_views(cams: _Cameras, image_shape, background: Tensor, means: Tensor, covariances: Tensor,
-                  opacities: Tensor, color_sh, feature_sh, use_sh: bool) -> RenderOutput:
-    """means (B,G,3) per view; covariances (B,G,3,3); opacities (B|1,G); *_sh (B|1,G,.,.)."""
+def _render_views(cams: _Cameras, scale: Optional[Tensor], image_shape, background: Tensor, means: Tensor,
+                  covariances: Tensor, opacities: Tensor, color_sh, feature_sh, use_sh: bool) -> RenderOutput:
+    """UNSCALED means (B|1,G,3) / covariances (B|1,G,3,3); opacities (B|1,G); *_sh (B|1,G,.,.).
+    ``scale`` (B,) is the scene scale the cameras were built for (None = 1)."""
     h, w = image_shape
-    degree, shs, colors_precomp, features = _payload(means, cams.campos, color_sh, feature_sh, use_sh)
     views = make_view_table(cams.view_matrix, cams.full_projection, cams.campos,
-                            cams.tan_fov_x, cams.tan_fov_y, background)
+                            cams.tan_fov_x, cams.tan_fov_y, background, scale)
+    degree, kw = 0, {}
+    if use_sh:
+        if color_sh is not None:
+            degree = isqrt(color_sh.shape[-1]) - 1
+            kw.update(shs=_squeeze_shared(color_sh), shs_channel_major=True)   # stored (.., 3, n) layout
+        if feature_sh is not None:
+            if fused_feature_sh_supported(feature_sh):
+                kw.update(feature_sh=_squeeze_shared(feature_sh))
+            else:   # evaluate on the host like the reference does
+                scaled = means if scale is None else means * scale[:, None, None]
+                kw.update(features=_payload(scaled, cams.campos, None, feature_sh, True)[3])
+    else:
+        if color_sh is not None:
+            kw.update(colors_precomp=_squeeze_shared(color_sh[..., 0]))
+        if feature_sh is not None:
+            kw.update(features=_squeeze_shared(feature_sh[..., 0]))
     color, feature, mask, depth, _ = rasterize_views(
-        views, h, w, degree, means, _pack_covariances(covariances),
-        _squeeze_shared(opacities[..., None]), shs=_squeeze_shared(shs),
-        colors_precomp=_squeeze_shared(colors_precomp), features=features)
+        views, h, w, degree, _squeeze_shared(means), _squeeze_shared(covariances),
+        _squeeze_shared(opacities[..., None]), **kw)
     return RenderOutput(color, feature, mask, depth)
+
+
+def _scaled_cameras(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, scale_invariant: bool):
+    """Cameras of the scene rescaled so that near == 1 (reference :75-82), plus that scale."""
+    scale = None
+    if scale_invariant:
+        scale = 1 / near
+        extrinsics = extrinsics.clone()
+        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[:, None]
+        near, far = near * scale, far * scale
+    fov_x, fov_y = get_fov(intrinsics).unbind(dim=-1)
+    return _cameras(extrinsics, near, far, fov_x, fov_y), scale
 
 
 def _scale_scene(extrinsics: Tensor, near: Tensor, far: Tensor, means: Tensor, covariances: Tensor):
@@ -136,12 +170,8 @@ def render_cuda(
 ) -> RenderOutput:
     assert gaussian_color_sh_coefficients is not None or gaussian_feature_sh_coefficients is not None
     assert use_sh or gaussian_color_sh_coefficients.shape[-1] == 1
-    if scale_invariant:
-        extrinsics, near, far, gaussian_means, gaussian_covariances = _scale_scene(
-            extrinsics, near, far, gaussian_means, gaussian_covariances)
-    fov_x, fov_y = get_fov(intrinsics).unbind(dim=-1)
-    cams = _cameras(extrinsics, near, far, fov_x, fov_y)
-    return _render_views(cams, image_shape, background_color, gaussian_means, gaussian_covariances,
+    cams, scale = _scaled_cameras(extrinsics, intrinsics, near, far, scale_invariant)
+    return _render_views(cams, scale, image_shape, background_color, gaussian_means, gaussian_covariances,
                          gaussian_opacities, gaussian_color_sh_coefficients,
                          gaussian_feature_sh_coefficients, use_sh)
 
@@ -168,16 +198,11 @@ def render_scenes(
     b, v = extrinsics.shape[:2]
     outs = []
     for s in range(b):
-        ext, nr, fr = extrinsics[s], near[s], far[s]
-        means = gaussian_means[s][None].expand(v, -1, -1)
-        covs = gaussian_covariances[s][None].expand(v, -1, -1, -1)
-        if scale_invariant:
-            ext, nr, fr, means, covs = _scale_scene(ext, nr, fr, means, covs)
-        fov_x, fov_y = get_fov(intrinsics[s]).unbind(dim=-1)
-        cams = _cameras(ext, nr, fr, fov_x, fov_y)
+        cams, scale = _scaled_cameras(extrinsics[s], intrinsics[s], near[s], far[s], scale_invariant)
         csh = None if gaussian_color_sh_coefficients is None else gaussian_color_sh_coefficients[s][None]
         fsh = None if gaussian_feature_sh_coefficients is None else gaussian_feature_sh_coefficients[s][None]
-        outs.append(_render_views(cams, image_shape, background_color[None].expand(v, 3), means, covs,
+        outs.append(_render_views(cams, scale, image_shape, background_color[None].expand(v, 3),
+                                  gaussian_means[s][None], gaussian_covariances[s][None],
                                   gaussian_opacities[s][None], csh, fsh, use_sh))
     cat = lambda xs: None if xs[0] is None else torch.cat(xs, dim=0)
     return RenderOutput(cat([o.color for o in outs]), cat([o.feature for o in outs]),

@@ -39,9 +39,11 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 def make_view_table(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx, tanfovy,
-                    bg: Tensor) -> Tensor:
-    """(V,40) device table: viewmatrix(16) projmatrix(16) campos(3) tanfovx tanfovy bg(3).
-    All arguments batched over V; tanfov may be python floats or tensors (no host sync)."""
+                    bg: Tensor, scene_scale=None) -> Tensor:
+    """(V,44) device table: viewmatrix(16) projmatrix(16) campos(3) tanfovx tanfovy bg(3)
+    scene_scale(1) reserved(3).  All arguments batched over V; tanfov / scene_scale may be python
+    floats or tensors (no host sync).  ``scene_scale`` (default 1) is applied to the Gaussians'
+    means (and squared to their covariances) inside the kernel."""
     V = viewmatrix.shape[0]
     dev, dt = viewmatrix.device, torch.float32
 
@@ -52,7 +54,8 @@ def make_view_table(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanf
 
     return torch.cat([viewmatrix.reshape(V, 16).to(dt), projmatrix.reshape(V, 16).to(dt),
                       campos.reshape(V, 3).to(dt), col(tanfovx), col(tanfovy),
-                      bg.reshape(-1, 3).to(dt).expand(V, 3)], dim=1).contiguous()
+                      bg.reshape(-1, 3).to(dt).expand(V, 3), col(1.0 if scene_scale is None else scene_scale),
+                      torch.zeros((V, 3), dtype=dt, device=dev)], dim=1).contiguous()
 
 
 def _ptr(t: Optional[Tensor]):
@@ -91,7 +94,8 @@ class _Plan:
 class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, views, means3D, means2D, cov3D, opacities, shs, colors_precomp, features,
-                H: int, W: int, sh_degree: int, debug: bool):
+                H: int, W: int, sh_degree: int, debug: bool, feat_sh_degree: int = -1,
+                shs_channel_major: bool = False):
         lib = _lib.load()
         ctx.set_materialize_grads(False)  # unused outputs (mask / depth ...) arrive as None, not zeros
         dev = means3D.device
@@ -111,18 +115,24 @@ class _RasterizeViews(torch.autograd.Function):
         colors_precomp = _prep(colors_precomp, "colors_precomp", dev)
         features = _prep(features, "features", dev)
         G = means3D.shape[-2]
+        cov_elems = 9 if cov3D.shape[-2:] == (3, 3) else 6
+        cov_base = 3 if cov_elems == 9 else 2
+        feat_sh = features is not None and feat_sh_degree >= 0
         color = shs if shs is not None else colors_precomp
         color_mode = _lib.COLOR_SH if shs is not None else (
             _lib.COLOR_PRECOMP if colors_precomp is not None else _lib.COLOR_NONE)
-        Cf = 0 if features is None else features.shape[-1]
+        Cf = 0 if features is None else (features.shape[-2] if feat_sh else features.shape[-1])
+        Kf = features.shape[-1] if feat_sh else 0
         if Cf > _lib.MAX_FEAT_CHANNELS:
             raise LsrError(f"features has {Cf} channels; at most {_lib.MAX_FEAT_CHANNELS} are supported")
-        K = shs.shape[-2] if shs is not None else 0
+        K = 0 if shs is None else (shs.shape[-1] if shs_channel_major else shs.shape[-2])
         d = Dims(V, G, H, W, Cf, color_mode, int(sh_degree), K,
-                 _stride(means3D, 2, V, "means3D"), _stride(cov3D, 2, V, "cov3D_precomp"),
+                 _stride(means3D, 2, V, "means3D"), _stride(cov3D, cov_base, V, "cov3D_precomp"),
                  _stride(opacities, 2, V, "opacities"),
                  _stride(color, 3 if shs is not None else 2, V, "shs/colors_precomp"),
-                 _stride(features, 2, V, "features"))
+                 _stride(features, 3 if feat_sh else 2, V, "features"),
+                 cov_elems, _lib.FEAT_SH if feat_sh else _lib.FEAT_DIRECT, max(int(feat_sh_degree), 0), Kf,
+                 1 if (shs is not None and shs_channel_major) else 0, 0)
         inp = Inputs(_ptr(views), _ptr(means3D), _ptr(cov3D), _ptr(opacities), _ptr(color), _ptr(features))
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         u8 = dict(dtype=torch.uint8, device=dev)
@@ -205,26 +215,50 @@ class _RasterizeViews(torch.autograd.Function):
             d_m2d = None
         elif len(ctx.m2d_shape) == 2:  # one (G,3) tensor shared by the views
             d_m2d = d_m2d.sum(0) if V > 1 else d_m2d[0]
-        # order: views, means3D, means2D, cov3D, opacities, shs, colors_precomp, features, H, W, deg, debug
+        # order: views, means3D, means2D, cov3D, opacities, shs, colors_precomp, features, H, W, deg,
+        #        debug, feat_sh_degree, shs_channel_major
         return (None, d_means, d_m2d, d_cov, d_opac, d_color if has_shs else None,
-                d_color if has_cp else None, d_feat, None, None, None, None)
+                d_color if has_cp else None, d_feat, None, None, None, None, None, None)
 
 
 def rasterize_views(views: Tensor, image_height: int, image_width: int, sh_degree: int, means3D: Tensor,
                     cov3D_precomp: Tensor, opacities: Tensor, shs: Optional[Tensor] = None,
                     colors_precomp: Optional[Tensor] = None, features: Optional[Tensor] = None,
-                    means2D: Optional[Tensor] = None, debug: bool = False):
-    """Render V views in one call.  ``views`` is the (V,40) table of :func:`make_view_table`; every
+                    means2D: Optional[Tensor] = None, debug: bool = False,
+                    feature_sh: Optional[Tensor] = None, shs_channel_major: bool = False):
+    """Render V views in one call.  ``views`` is the (V,44) table of :func:`make_view_table`; every
     per-Gaussian tensor is either shared ``(G,...)`` or per view ``(V,G,...)``.
     Returns ``(color (V,3,H,W)|None, feature (V,C,H,W)|None, mask (V,H,W), depth (V,H,W), radii (V,G))``.
-    ``means2D`` (optional, ``(V,G,3)``) only exists to receive the NDC-space mean gradient."""
+    ``means2D`` (optional, ``(V,G,3)``) only exists to receive the NDC-space mean gradient.
+
+    Scene-level (fused) inputs, all optional: ``cov3D_precomp`` may be full ``(...,3,3)`` matrices;
+    ``feature_sh (..., C, Kf)`` (instead of ``features``) makes the kernel evaluate the latent
+    features ``0.5 + eval_sh(dir)`` itself (degree <= 2, C*Kf <= 120); ``shs`` may be passed in
+    the stored ``(...,3,K)`` layout with ``shs_channel_major=True``; the per-view scene scale
+    lives in the view table."""
     V = views.shape[0]
+    feat_sh_degree = -1
+    if feature_sh is not None:
+        if features is not None:
+            raise LsrError("provide at most one of features / feature_sh")
+        from math import isqrt
+        feat_sh_degree = isqrt(feature_sh.shape[-1]) - 1
+        features = feature_sh
     if means2D is None:
         means2D = torch.zeros((V, means3D.shape[-2], 3), dtype=torch.float32, device=means3D.device)
     color, feat, mask, depth, radii = _RasterizeViews.apply(
         views, means3D, means2D, cov3D_precomp, opacities, shs, colors_precomp, features,
-        int(image_height), int(image_width), int(sh_degree), bool(debug))
+        int(image_height), int(image_width), int(sh_degree), bool(debug), int(feat_sh_degree),
+        bool(shs_channel_major))
     return (color if color.numel() else None, feat if feat.numel() else None, mask, depth, radii)
+
+
+def fused_feature_sh_supported(feature_sh: Optional[Tensor]) -> bool:
+    """True when the kernel can evaluate these latent SH coefficients itself."""
+    if feature_sh is None:
+        return False
+    from math import isqrt
+    return isqrt(feature_sh.shape[-1]) - 1 <= 2 and feature_sh.shape[-2] * feature_sh.shape[-1] <= _lib.MAX_SH_GROUP_FLOATS
 
 
 def _covariance_from_scale_rotation(scales: Tensor, rotations: Tensor, modifier: float) -> Tensor:
@@ -261,6 +295,6 @@ class GaussianRasterizer(nn.Module):
                                 rs.tanfovx, rs.tanfovy, rs.bg[None])
         color, feat, mask, depth, radii = _RasterizeViews.apply(
             views, means3D, means2D, cov3D_precomp, opacities, shs, colors_precomp, features,
-            int(rs.image_height), int(rs.image_width), int(rs.sh_degree), bool(rs.debug))
+            int(rs.image_height), int(rs.image_width), int(rs.sh_degree), bool(rs.debug), -1, False)
         return (color[0] if color.numel() else None, feat[0] if feat.numel() else None,
                 mask, depth, radii[0])

@@ -25,12 +25,13 @@ def test_header_symbols_are_exported():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert set(names) == set(_lib.EXPORTS)
-    assert lib.lsr_abi_version() == 1
+    assert lib.lsr_abi_version() == 2
 
 
 def _dims(**kw):
     base = dict(num_views=2, num_gaussians=1000, height=64, width=64, feat_channels=4, color_mode=0,
-                sh_degree=0, sh_coeffs=0, vs_means=0, vs_cov=0, vs_opac=0, vs_color=0, vs_feat=0)
+                sh_degree=0, sh_coeffs=0, vs_means=0, vs_cov=0, vs_opac=0, vs_color=0, vs_feat=0,
+                cov_elems=6, feat_mode=0, feat_sh_degree=0, feat_sh_coeffs=0)
     base.update(kw)
     return Dims(**base)
 
@@ -51,7 +52,8 @@ def test_workspace_sizes():
 @pytest.mark.parametrize("bad", [
     dict(num_views=0), dict(height=0), dict(feat_channels=33), dict(feat_channels=0, color_mode=0),
     dict(color_mode=1, sh_degree=5, sh_coeffs=36), dict(color_mode=1, sh_degree=2, sh_coeffs=4),
-    dict(vs_means=7), dict(vs_feat=5),
+    dict(vs_means=7), dict(vs_feat=5), dict(cov_elems=7), dict(feat_mode=2),
+    dict(feat_mode=1, feat_sh_degree=1, feat_sh_coeffs=3),
 ])
 def test_invalid_dims_are_rejected(bad):
     lib = _lib.load()
@@ -60,6 +62,14 @@ def test_invalid_dims_are_rejected(bad):
     npairs, maxtile = C.c_int64(0), C.c_int32(0)
     rc = lib.lsr_forward_prepare(C.byref(d), C.byref(Inputs()), None, None, C.byref(npairs), C.byref(maxtile), None)
     assert rc == -1 and b"invalid" in lib.lsr_error_string(rc)
+
+
+def test_unsupported_fused_sh_shapes_are_reported():
+    lib = _lib.load()
+    for bad in (dict(feat_mode=1, feat_sh_degree=3, feat_sh_coeffs=16), dict(feat_channels=32, feat_mode=1, feat_sh_degree=2, feat_sh_coeffs=9)):
+        d = _dims(**bad)
+        npairs, maxtile = C.c_int64(0), C.c_int32(0)
+        assert lib.lsr_forward_prepare(C.byref(d), C.byref(Inputs()), None, None, C.byref(npairs), C.byref(maxtile), None) == -5
 
 
 def test_null_pointers_are_rejected_before_any_gpu_work():

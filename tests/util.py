@@ -14,6 +14,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from latentsplat_amd.decoder import cuda_splatting as cs  # noqa: E402
+from latentsplat_amd.decoder import geometry  # noqa: E402
 from latentsplat_amd.decoder.geometry import get_fov  # noqa: E402
 from latentsplat_amd.synthetic import Scene, make_scene  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
@@ -90,7 +91,7 @@ class HipRun:
         mode = 1 if bi["shs"] is not None else (2 if bi["colors_precomp"] is not None else 0)
         K = bi["shs"].shape[1] if bi["shs"] is not None else 0
         self.d = d = Dims(V, G, H, W, Cf, mode, bi["sh_degree"], K, 0 if shared_means else 3 * G,
-                          0 if shared_means else 6 * G, 0, 0, Cf * G if Cf else 0)
+                          0 if shared_means else 6 * G, 0, 0, Cf * G if Cf else 0, 6, 0, 0, 0, 0, 0)
         p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
         self.inp = Inputs(p(self.views), p(self.means), p(self.cov6), p(self.opac), p(self.color), p(self.features))
         u8 = dict(dtype=torch.uint8, device=dev)
@@ -151,21 +152,95 @@ class HipRun:
             self.d.num_views, self.d.height, self.d.width)
 
 
+def assert_close_except_fragile(got, want, oracle_fwd, atol, what=""):
+    """|got - want| <= atol on every pixel except those where the oracle saw an evaluation within
+    float rounding of one of the algorithm's discontinuities (alpha == 1/255 skip, T == 1e-4 stop):
+    there two correct float implementations may legitimately take different branches, which moves
+    the pixel by up to alpha*T*c ~ 4e-3.  At most a handful of pixels may be exempt."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    err = np.abs(got - want).reshape(-1, got.shape[-2], got.shape[-1]).max(0)
+    frag = np.unique(oracle_fwd["fragile"][:, 0]) if len(oracle_fwd["fragile"]) else np.zeros(0, np.int64)
+    assert not oracle_fwd["fragile_overflow"] and len(frag) <= max(8, err.size // 50), f"{what}: too many fragile pixels"
+    if len(frag):
+        assert err.reshape(-1)[frag].max() <= 2e-2, f"{what}: fragile pixel moved more than one alpha step"
+        err.reshape(-1)[frag] = 0
+    assert err.max() <= atol, f"{what}: max abs err {err.max():.3e} > {atol:.1e}"
+
+
+def fragile_gaussians(oracle_fwd, W):
+    """(direct, behind): Gaussians of near-discontinuity evaluations, and every member of the tile
+    lists of the affected pixels (their transmittance changes if the decision flips)."""
+    fr = oracle_fwd["fragile"]
+    if len(fr) == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    gx = (W + 15) // 16
+    behind = []
+    for pix in np.unique(fr[:, 0]):
+        tile = (pix // W // 16) * gx + (pix % W) // 16
+        s0, s1 = oracle_fwd["ranges"][tile]
+        behind.append(oracle_fwd["point_list"][s0:s1].astype(np.int64))
+    return np.unique(fr[:, 1]).astype(np.int64), np.unique(np.concatenate(behind))
+
+
+def assert_grad_close_except_fragile(got, want, direct, behind, tol, what=""):
+    """Per-Gaussian gradient rows within tol * scale, except rows of fragile evaluations (exempt)
+    and rows that share a pixel with one (bounded by a flip-sized 5e-3 * scale)."""
+    got = np.asarray(got, np.float64).reshape(np.shape(want)[0], -1)
+    want = np.asarray(want, np.float64).reshape(got.shape)
+    scale = max(1.0, np.abs(want).max())
+    err = np.abs(got - want).max(1)
+    assert len(direct) <= max(8, err.size // 100), f"{what}: too many fragile Gaussians"
+    err[direct] = 0
+    assert err[behind].max(initial=0) <= 5e-3 * scale, f"{what}: {err[behind].max():.3e} next to a fragile evaluation"
+    err[behind] = 0
+    assert err.max() <= tol * scale, f"{what}: max err {err.max():.3e} (scale {scale:.3e}, row {err.argmax()})"
+
+
+def to_boundary(views, v, means3D, cov3D_precomp, opacities, shs, colors_precomp, features, feature_sh,
+                shs_channel_major):
+    """Host statement of what the kernels fuse: (scene-level inputs of view v) -> the tensors the
+    reference hands to its rasterizer (scaled means, packed scaled covariance, (G,K,3) colour SH,
+    evaluated latent features).  Pure torch, differentiable; used by the CPU stand-in below and by
+    the gradient tests to chain oracle gradients back to scene-level inputs."""
+    pv = lambda t, base: None if t is None else (t[v] if t.dim() == base + 1 else t)
+    vw = views[v]
+    scale = vw[40]
+    means = pv(means3D, 2) * scale
+    cov = cov3D_precomp
+    full = cov.shape[-2:] == (3, 3)
+    cov = pv(cov, 3 if full else 2)
+    cov6 = (cs._pack_covariances(cov) if full else cov) * (scale * scale)   # same rounding as the kernel / reference
+    sh = pv(shs, 3)
+    if sh is not None and shs_channel_major:
+        sh = sh.transpose(-1, -2)
+    feats = pv(features, 2)
+    if feature_sh is not None:
+        fsh = pv(feature_sh, 3)
+        from math import isqrt
+        d = means - vw[32:35][None]
+        d = d / d.norm(dim=-1, keepdim=True)
+        feats = 0.5 + geometry.eval_sh(isqrt(fsh.shape[-1]) - 1, fsh, d)
+    return means, cov6, pv(opacities, 2), sh, pv(colors_precomp, 2), feats
+
+
 def oracle_rasterize_views(views, image_height, image_width, sh_degree, means3D, cov3D_precomp, opacities,
-                           shs=None, colors_precomp=None, features=None, means2D=None, debug=False):
+                           shs=None, colors_precomp=None, features=None, means2D=None, debug=False,
+                           feature_sh=None, shs_channel_major=False):
     """CPU stand-in with the signature of latentsplat_amd.rasterizer.rasterize_views, served by the
     oracle.  TESTS ONLY: lets the not-gpu suite pin the host-side wrapper logic."""
     V = views.shape[0]
-    n = lambda t: None if t is None else t.detach().cpu().float().numpy()
-    per_view = lambda t, base, v: None if t is None else (t[v] if t.dim() == base + 1 else t)
+    n = lambda t: None if t is None else t.detach().cpu().float().contiguous().numpy()
     cols, feats, masks, depths, radii = [], [], [], [], []
     for v in range(V):
         vw = views[v].detach().cpu()
         view = orc.View(image_height, image_width, float(vw[35]), float(vw[36]), vw[37:40].numpy(),
                         vw[0:16].numpy().reshape(4, 4), vw[16:32].numpy().reshape(4, 4), vw[32:35].numpy(), sh_degree)
-        o = orc.forward(view, n(per_view(means3D, 2, v)), n(per_view(cov3D_precomp, 2, v)),
-                        n(per_view(opacities, 2, v)), n(per_view(shs, 3, v)), n(per_view(colors_precomp, 2, v)),
-                        n(per_view(features, 2, v)), keep_intermediates=False)
+        m, c6, op, sh, cp, ft = to_boundary(views.detach().cpu(), v, means3D.detach().cpu(), cov3D_precomp.detach().cpu(),
+                                            opacities.detach().cpu(), None if shs is None else shs.detach().cpu(),
+                                            None if colors_precomp is None else colors_precomp.detach().cpu(),
+                                            None if features is None else features.detach().cpu(),
+                                            None if feature_sh is None else feature_sh.detach().cpu(), shs_channel_major)
+        o = orc.forward(view, n(m), n(c6), n(op), n(sh), n(cp), n(ft), keep_intermediates=False)
         cols.append(o["color"]); feats.append(o["feature"]); masks.append(o["mask"]); depths.append(o["depth"])
         radii.append(o["radii"])
     st = lambda xs: None if xs[0] is None else torch.from_numpy(np.stack(xs))
