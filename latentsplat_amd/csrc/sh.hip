@@ -67,16 +67,13 @@ k_sh(ShParams p) {
     const int ks = K * nch, ps = padded_stride(ks);
     const int64_t vs = group == 0 ? d.vs_color : d.vs_feat;
     const float *coef_base = group == 0 ? p.in.color : p.in.features;
-    float *gcoef_base = BACKWARD ? (group == 0 ? p.g.color : p.g.features) : nullptr;
-    float *s_coef = s_lds, *s_grad = s_lds + LSR_WAVE * ps;
+    float *s_coef = s_lds;
     const float *my = s_coef + lane * ps;
-    float *myg = s_grad + lane * ps;
     const int slot0 = 8 + (group == 0 ? 0 : coff);                        // first payload slot of the group
     const bool cmaj = group == 1 || d.color_sh_channel_major != 0;       // coefficient layout [c][k] vs [k][c]
 
     if (vs == 0) {
         stage_in(s_coef, coef_base + (size_t)g0 * ks, ks, rows, lane);
-        if (BACKWARD) for (int t = lane; t < LSR_WAVE * ps; t += LSR_WAVE) s_grad[t] = 0.0f;
         __syncthreads();
     }
     float gmean_acc[3] = {0.0f, 0.0f, 0.0f};
@@ -84,7 +81,6 @@ k_sh(ShParams p) {
         if (vs != 0) {
             __syncthreads();
             stage_in(s_coef, coef_base + (size_t)v * vs + (size_t)g0 * ks, ks, rows, lane);
-            if (BACKWARD) for (int t = lane; t < LSR_WAVE * ps; t += LSR_WAVE) s_grad[t] = 0.0f;
             __syncthreads();
         }
         const size_t o = (size_t)v * G + (active ? i : 0);
@@ -116,20 +112,25 @@ k_sh(ShParams p) {
                 }
                 if (group == 0) R[7] = __uint_as_float(clampbits);
             } else {
+                // direction gradient only (coefficient gradients: k_sh_coef_backward below):
+                //   sg[k] = sum_c coef[k][c] * dL/dchannel_c ;  dL/d(b) = sum_k dB_k/d(b) * sg[k]
                 const float *gr = p.grec + o * (size_t)p.RF;
                 const uint32_t clampbits = group == 0 ? __float_as_uint(p.rec[o * (size_t)p.RF + 7]) : 0u;
+                float sg[25];
+#pragma unroll
+                for (int k = 0; k < 25; ++k) sg[k] = 0.0f;
+                for (int c = 0; c < nch; ++c) {
+                    const float gc = (clampbits >> c & 1u) ? 0.0f : gr[slot0 + c];
+#pragma unroll
+                    for (int k = 0; k < 25; ++k)
+                        if (k < nb) sg[k] = __builtin_fmaf(my[coef_index(cmaj, k, c, K)], gc, sg[k]);
+                }
                 float dbas[25][3];
                 sh_basis_grad(deg, bx, by, bz, dbas);
                 float dd[3] = {0.0f, 0.0f, 0.0f};   // dL / d(bx,by,bz)
-                for (int c = 0; c < nch; ++c) {
-                    const float gc = (clampbits >> c & 1u) ? 0.0f : gr[slot0 + c];
-                    for (int k = 0; k < nb; ++k) {
-                        const int ci = coef_index(cmaj, k, c, K);
-                        myg[ci] += bas[k] * gc;
-                        const float sg = my[ci] * gc;
-                        dd[0] += dbas[k][0] * sg; dd[1] += dbas[k][1] * sg; dd[2] += dbas[k][2] * sg;
-                    }
-                }
+#pragma unroll
+                for (int k = 0; k < 25; ++k)
+                    if (k < nb) { dd[0] += dbas[k][0] * sg[k]; dd[1] += dbas[k][1] * sg[k]; dd[2] += dbas[k][2] * sg[k]; }
                 // back to (dx,dy,dz) naming, then through the normalisation and the scene scale
                 const float ddx = group == 0 ? dd[0] : dd[1], ddy = group == 0 ? dd[1] : dd[2], ddz = group == 0 ? dd[2] : dd[0];
                 const float dot = ddx * dx + ddy * dy + ddz * dz;
@@ -144,10 +145,6 @@ k_sh(ShParams p) {
                     o3[0] += gm[0]; o3[1] += gm[1]; o3[2] += gm[2];
                 }
             } else { gmean_acc[0] += gm[0]; gmean_acc[1] += gm[1]; gmean_acc[2] += gm[2]; }
-            if (vs != 0) {
-                __syncthreads();
-                stage_out(gcoef_base + (size_t)v * vs + (size_t)g0 * ks, s_grad, ks, rows, lane, false);
-            }
         }
     }
     if (BACKWARD) {
@@ -155,9 +152,102 @@ k_sh(ShParams p) {
             float *o3 = p.g.means3D + 3 * (size_t)i;
             o3[0] += gmean_acc[0]; o3[1] += gmean_acc[1]; o3[2] += gmean_acc[2];
         }
-        if (vs == 0) {
-            __syncthreads();
-            stage_out(gcoef_base + (size_t)g0 * ks, s_grad, ks, rows, lane, false);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Coefficient gradients.  Those of a 64-Gaussian block are ONE contiguous run of 64*ks floats
+// (ks = K*channels).  Phase A (lane = Gaussian) leaves the SH basis and the (clamp-masked) channel
+// gradients of the current view in LDS; phase B (lane = element of the run) accumulates
+// grad[t] += basis[g][k] * gch[g][c] in REGISTERS over the views — the element -> (g,k,c) mapping
+// does not depend on the view, so it is decoded once — and finally stores the run
+// lane-contiguously.  No read-modify-write of LDS or global memory anywhere.
+template <int KS_MAX>
+__global__ void __launch_bounds__(LSR_WAVE)
+k_sh_coef_backward(ShParams p) {
+    extern __shared__ float s_lds[];
+    const lsr_dims &d = p.d;
+    const int lane = threadIdx.x, G = d.num_gaussians, V = d.num_views;
+    const int g0 = blockIdx.x * LSR_WAVE, i = g0 + lane;
+    const int rows = G - g0 < LSR_WAVE ? G - g0 : LSR_WAVE;
+    const bool active = i < G;
+    const int group = p.group;
+    const int coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
+    const int deg = group == 0 ? d.sh_degree : d.feat_sh_degree;
+    const int K = group == 0 ? d.sh_coeffs : d.feat_sh_coeffs;
+    const int nch = group == 0 ? 3 : d.feat_channels;
+    const int nb = (deg + 1) * (deg + 1);
+    const int ks = K * nch;
+    const int64_t vs = group == 0 ? d.vs_color : d.vs_feat;
+    float *gcoef_base = group == 0 ? p.g.color : p.g.features;
+    const int slot0 = 8 + (group == 0 ? 0 : coff);
+    const bool cmaj = group == 1 || d.color_sh_channel_major != 0;
+    constexpr int BS = 27;                      // basis row: 25 values + a zero slot, odd stride
+    const int cs = nch | 1;
+    float *s_bas = s_lds, *s_gch = s_lds + LSR_WAVE * BS;
+
+    // element t = it*64 + lane of the run -> packed LDS addresses of its basis value / channel grad
+    uint32_t addr[KS_MAX];
+    float acc[KS_MAX];
+#pragma unroll
+    for (int it = 0; it < KS_MAX; ++it) {
+        acc[it] = 0.0f;
+        const int t = it * LSR_WAVE + lane;
+        const int g = t / ks, rem = t - g * ks;
+        const int k = cmaj ? rem % K : rem / 3, c = cmaj ? rem / K : rem % 3;
+        // coefficients beyond the evaluated bands (k >= nb) read the zero slot
+        addr[it] = (it < ks && g < LSR_WAVE) ? ((uint32_t)(g * BS + (k < nb ? k : 25)) | ((uint32_t)(g * cs + c) << 16)) : 0xFFFFFFFFu;
+    }
+    for (int v = 0; v < V; ++v) {
+        __syncthreads();   // previous view's phase B is done with s_bas / s_gch
+        if (vs != 0) {
+#pragma unroll
+            for (int it = 0; it < KS_MAX; ++it) acc[it] = 0.0f;
+        }
+        // ---- phase A: lane = Gaussian ----
+        const size_t o = (size_t)v * G + (active ? i : 0);
+        const bool vis = active && p.binrec[o].radius > 0;
+        float *mb = s_bas + lane * BS, *mg = s_gch + lane * cs;
+        float bas[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) bas[k] = 0.0f;
+        if (vis) {
+            const float *vw = p.in.views + (size_t)v * LSR_VIEW_FLOATS;
+            const float sc = vw[40];
+            const float *mp = p.in.means3D + (size_t)v * d.vs_means + 3 * (size_t)i;
+            float dx = mp[0] * sc - vw[32], dy = mp[1] * sc - vw[33], dz = mp[2] * sc - vw[34];
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            dx = dx / len; dy = dy / len; dz = dz / len;
+            sh_basis(deg, group == 0 ? dx : dz, group == 0 ? dy : dx, group == 0 ? dz : dy, bas);
+        }
+#pragma unroll
+        for (int k = 0; k < 25; ++k) mb[k] = (vis && k < nb) ? bas[k] : 0.0f;
+        mb[25] = 0.0f;
+        {
+            const float *gr = p.grec + o * (size_t)p.RF;
+            const uint32_t clampbits = (vis && group == 0) ? __float_as_uint(p.rec[o * (size_t)p.RF + 7]) : 0u;
+            for (int c = 0; c < nch; ++c) mg[c] = (vis && !(clampbits >> c & 1u)) ? gr[slot0 + c] : 0.0f;
+        }
+        __syncthreads();
+        // ---- phase B: lane = element of the contiguous coefficient-gradient run ----
+#pragma unroll
+        for (int it = 0; it < KS_MAX; ++it)
+            if (addr[it] != 0xFFFFFFFFu) acc[it] = __builtin_fmaf(s_bas[addr[it] & 0xFFFFu], s_gch[addr[it] >> 16], acc[it]);
+        if (vs != 0) {
+            float *dst = gcoef_base + (size_t)v * vs + (size_t)g0 * ks;
+#pragma unroll
+            for (int it = 0; it < KS_MAX; ++it) {
+                const int t = it * LSR_WAVE + lane;
+                if (it < ks && t < rows * ks) dst[t] = acc[it];
+            }
+        }
+    }
+    if (vs == 0) {
+        float *dst = gcoef_base + (size_t)g0 * ks;
+#pragma unroll
+        for (int it = 0; it < KS_MAX; ++it) {
+            const int t = it * LSR_WAVE + lane;
+            if (it < ks && t < rows * ks) dst[t] = acc[it];
         }
     }
 }
@@ -168,6 +258,7 @@ static bool group_enabled(const lsr_dims &d, int group) {
 
 hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s) {
     if (d.num_gaussians == 0) return hipSuccess;
+    if (!group_enabled(d, 0) && !group_enabled(d, 1)) return hipSuccess;
     const GeomLayout L = geom_layout(d);
     prof_begin(kStShFwd, s);
     for (int group = 0; group < 2; ++group) {
@@ -186,6 +277,7 @@ hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom
 hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom, const char *grad,
                               const lsr_in_grads &gin, hipStream_t s) {
     if (d.num_gaussians == 0) return hipSuccess;
+    if (!group_enabled(d, 0) && !group_enabled(d, 1)) return hipSuccess;
     const GeomLayout L = geom_layout(d);
     const GradLayout R = grad_layout(d);
     prof_begin(kStShBwd, s);
@@ -194,9 +286,17 @@ hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const cha
         ShParams p;
         p.d = d; p.in = in; p.binrec = (const BinRec *)(geom + L.bin);
         p.rec = (float *)const_cast<char *>(geom + L.rec); p.grec = (const float *)(grad + R.rec); p.RF = L.rec_floats; p.g = gin; p.group = group;
+        const int nch = group == 0 ? 3 : d.feat_channels;
         const int ks = group == 0 ? d.sh_coeffs * 3 : d.feat_sh_coeffs * d.feat_channels;
-        const size_t shm = (size_t)LSR_WAVE * (ks | 1) * 4 * 2;
-        hipLaunchKernelGGL((k_sh<true>), dim3((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), dim3(LSR_WAVE), shm, s, p);
+        const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), block(LSR_WAVE);
+        // (1) direction -> mean gradient (needs the coefficients, staged through LDS)
+        hipLaunchKernelGGL((k_sh<true>), grid, block, (size_t)LSR_WAVE * (ks | 1) * 4, s, p);
+        // (2) coefficient gradients
+        const size_t shm = (size_t)LSR_WAVE * (27 + (nch | 1)) * 4;
+        if (ks <= 12) hipLaunchKernelGGL((k_sh_coef_backward<12>), grid, block, shm, s, p);
+        else if (ks <= 36) hipLaunchKernelGGL((k_sh_coef_backward<36>), grid, block, shm, s, p);
+        else if (ks <= 76) hipLaunchKernelGGL((k_sh_coef_backward<76>), grid, block, shm, s, p);
+        else hipLaunchKernelGGL((k_sh_coef_backward<120>), grid, block, shm, s, p);
     }
     prof_end(kStShBwd, s);
     return hipGetLastError();
