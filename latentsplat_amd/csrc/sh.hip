@@ -158,19 +158,20 @@ k_sh(ShParams p) {
 // ------------------------------------------------------------------------------------------
 // Coefficient gradients.  Those of a 64-Gaussian block are ONE contiguous run of 64*ks floats
 // (ks = K*channels).  Phase A (lane = Gaussian) leaves the SH basis and the (clamp-masked) channel
-// gradients of the current view in LDS; phase B (lane = element of the run) accumulates
-// grad[t] += basis[g][k] * gch[g][c] in REGISTERS over the views — the element -> (g,k,c) mapping
-// does not depend on the view, so it is decoded once — and finally stores the run
-// lane-contiguously.  No read-modify-write of LDS or global memory anywhere.
-template <int KS_MAX>
-__global__ void __launch_bounds__(LSR_WAVE)
+// gradients of up to kShViewChunk views in LDS; phase B (lane = element of the run) sums
+// basis[v][g][k] * gch[v][g][c] over those views and stores the run lane-contiguously.
+// Few registers (no per-element state), coalesced stores, no read-modify-write except when a
+// shared scene has more views than one chunk.
+constexpr int kShViewChunk = 4;
+constexpr int kShBasisStride = 27;   // 25 basis values + a zero slot, odd stride
+
+__global__ void __launch_bounds__(256)
 k_sh_coef_backward(ShParams p) {
     extern __shared__ float s_lds[];
     const lsr_dims &d = p.d;
-    const int lane = threadIdx.x, G = d.num_gaussians, V = d.num_views;
-    const int g0 = blockIdx.x * LSR_WAVE, i = g0 + lane;
+    const int tid = threadIdx.x, G = d.num_gaussians, V = d.num_views;
+    const int g0 = blockIdx.x * LSR_WAVE;
     const int rows = G - g0 < LSR_WAVE ? G - g0 : LSR_WAVE;
-    const bool active = i < G;
     const int group = p.group;
     const int coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
     const int deg = group == 0 ? d.sh_degree : d.feat_sh_degree;
@@ -182,72 +183,51 @@ k_sh_coef_backward(ShParams p) {
     float *gcoef_base = group == 0 ? p.g.color : p.g.features;
     const int slot0 = 8 + (group == 0 ? 0 : coff);
     const bool cmaj = group == 1 || d.color_sh_channel_major != 0;
-    constexpr int BS = 27;                      // basis row: 25 values + a zero slot, odd stride
+    constexpr int BS = kShBasisStride;
     const int cs = nch | 1;
-    float *s_bas = s_lds, *s_gch = s_lds + LSR_WAVE * BS;
+    const int chunk = vs != 0 ? 1 : kShViewChunk;            // per-view outputs: one view at a time
+    float *s_bas = s_lds, *s_gch = s_lds + kShViewChunk * LSR_WAVE * BS;
 
-    // element t = it*64 + lane of the run -> packed LDS addresses of its basis value / channel grad
-    uint32_t addr[KS_MAX];
-    float acc[KS_MAX];
+    for (int v0 = 0; v0 < V; v0 += chunk) {
+        const int nv = V - v0 < chunk ? V - v0 : chunk;
+        __syncthreads();   // previous chunk's phase B is done with the LDS arrays
+        // ---- phase A: thread = (view of the chunk, Gaussian) ----
+        if (tid < nv * LSR_WAVE) {
+            const int vi = tid / LSR_WAVE, lane = tid % LSR_WAVE, v = v0 + vi, i = g0 + lane;
+            const bool active = i < G;
+            const size_t o = (size_t)v * G + (active ? i : 0);
+            const bool vis = active && p.binrec[o].radius > 0;
+            float *mb = s_bas + (vi * LSR_WAVE + lane) * BS, *mg = s_gch + (vi * LSR_WAVE + lane) * cs;
+            float bas[25];
 #pragma unroll
-    for (int it = 0; it < KS_MAX; ++it) {
-        acc[it] = 0.0f;
-        const int t = it * LSR_WAVE + lane;
-        const int g = t / ks, rem = t - g * ks;
-        const int k = cmaj ? rem % K : rem / 3, c = cmaj ? rem / K : rem % 3;
-        // coefficients beyond the evaluated bands (k >= nb) read the zero slot
-        addr[it] = (it < ks && g < LSR_WAVE) ? ((uint32_t)(g * BS + (k < nb ? k : 25)) | ((uint32_t)(g * cs + c) << 16)) : 0xFFFFFFFFu;
-    }
-    for (int v = 0; v < V; ++v) {
-        __syncthreads();   // previous view's phase B is done with s_bas / s_gch
-        if (vs != 0) {
+            for (int k = 0; k < 25; ++k) bas[k] = 0.0f;
+            if (vis) {
+                const float *vw = p.in.views + (size_t)v * LSR_VIEW_FLOATS;
+                const float sc = vw[40];
+                const float *mp = p.in.means3D + (size_t)v * d.vs_means + 3 * (size_t)i;
+                float dx = mp[0] * sc - vw[32], dy = mp[1] * sc - vw[33], dz = mp[2] * sc - vw[34];
+                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                dx = dx / len; dy = dy / len; dz = dz / len;
+                sh_basis(deg, group == 0 ? dx : dz, group == 0 ? dy : dx, group == 0 ? dz : dy, bas);
+            }
 #pragma unroll
-            for (int it = 0; it < KS_MAX; ++it) acc[it] = 0.0f;
-        }
-        // ---- phase A: lane = Gaussian ----
-        const size_t o = (size_t)v * G + (active ? i : 0);
-        const bool vis = active && p.binrec[o].radius > 0;
-        float *mb = s_bas + lane * BS, *mg = s_gch + lane * cs;
-        float bas[25];
-#pragma unroll
-        for (int k = 0; k < 25; ++k) bas[k] = 0.0f;
-        if (vis) {
-            const float *vw = p.in.views + (size_t)v * LSR_VIEW_FLOATS;
-            const float sc = vw[40];
-            const float *mp = p.in.means3D + (size_t)v * d.vs_means + 3 * (size_t)i;
-            float dx = mp[0] * sc - vw[32], dy = mp[1] * sc - vw[33], dz = mp[2] * sc - vw[34];
-            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-            dx = dx / len; dy = dy / len; dz = dz / len;
-            sh_basis(deg, group == 0 ? dx : dz, group == 0 ? dy : dx, group == 0 ? dz : dy, bas);
-        }
-#pragma unroll
-        for (int k = 0; k < 25; ++k) mb[k] = (vis && k < nb) ? bas[k] : 0.0f;
-        mb[25] = 0.0f;
-        {
+            for (int k = 0; k < 25; ++k) mb[k] = (vis && k < nb) ? bas[k] : 0.0f;
+            mb[25] = 0.0f;
             const float *gr = p.grec + o * (size_t)p.RF;
             const uint32_t clampbits = (vis && group == 0) ? __float_as_uint(p.rec[o * (size_t)p.RF + 7]) : 0u;
             for (int c = 0; c < nch; ++c) mg[c] = (vis && !(clampbits >> c & 1u)) ? gr[slot0 + c] : 0.0f;
         }
         __syncthreads();
-        // ---- phase B: lane = element of the contiguous coefficient-gradient run ----
-#pragma unroll
-        for (int it = 0; it < KS_MAX; ++it)
-            if (addr[it] != 0xFFFFFFFFu) acc[it] = __builtin_fmaf(s_bas[addr[it] & 0xFFFFu], s_gch[addr[it] >> 16], acc[it]);
-        if (vs != 0) {
-            float *dst = gcoef_base + (size_t)v * vs + (size_t)g0 * ks;
-#pragma unroll
-            for (int it = 0; it < KS_MAX; ++it) {
-                const int t = it * LSR_WAVE + lane;
-                if (it < ks && t < rows * ks) dst[t] = acc[it];
-            }
-        }
-    }
-    if (vs == 0) {
-        float *dst = gcoef_base + (size_t)g0 * ks;
-#pragma unroll
-        for (int it = 0; it < KS_MAX; ++it) {
-            const int t = it * LSR_WAVE + lane;
-            if (it < ks && t < rows * ks) dst[t] = acc[it];
+        // ---- phase B: thread = element of the contiguous coefficient-gradient run ----
+        float *dst = gcoef_base + (vs != 0 ? (size_t)v0 * vs : 0) + (size_t)g0 * ks;
+        for (int t = tid; t < rows * ks; t += 256) {
+            const int g = t / ks, rem = t - g * ks;
+            const int k = cmaj ? rem % K : rem / 3, c = cmaj ? rem / K : rem % 3;
+            const int kb = k < nb ? k : 25;   // coefficients beyond the evaluated bands: zero slot
+            float a = (vs == 0 && v0 > 0) ? dst[t] : 0.0f;
+            for (int vi = 0; vi < nv; ++vi)
+                a = __builtin_fmaf(s_bas[(vi * LSR_WAVE + g) * BS + kb], s_gch[(vi * LSR_WAVE + g) * cs + c], a);
+            dst[t] = a;
         }
     }
 }
@@ -292,11 +272,8 @@ hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const cha
         // (1) direction -> mean gradient (needs the coefficients, staged through LDS)
         hipLaunchKernelGGL((k_sh<true>), grid, block, (size_t)LSR_WAVE * (ks | 1) * 4, s, p);
         // (2) coefficient gradients
-        const size_t shm = (size_t)LSR_WAVE * (27 + (nch | 1)) * 4;
-        if (ks <= 12) hipLaunchKernelGGL((k_sh_coef_backward<12>), grid, block, shm, s, p);
-        else if (ks <= 36) hipLaunchKernelGGL((k_sh_coef_backward<36>), grid, block, shm, s, p);
-        else if (ks <= 76) hipLaunchKernelGGL((k_sh_coef_backward<76>), grid, block, shm, s, p);
-        else hipLaunchKernelGGL((k_sh_coef_backward<120>), grid, block, shm, s, p);
+        const size_t shm = (size_t)kShViewChunk * LSR_WAVE * (kShBasisStride + (nch | 1)) * 4;
+        hipLaunchKernelGGL(k_sh_coef_backward, grid, dim3(256), shm, s, p);
     }
     prof_end(kStShBwd, s);
     return hipGetLastError();

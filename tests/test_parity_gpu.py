@@ -201,6 +201,7 @@ def test_backward_parity_all_wave_shapes(hip_device, monkeypatch, pxl):
     dict(G=3000, size=64, views=3, color_sh_degree=4, feature_channels=4, feature_sh_degree=2),
     dict(G=2000, size=48, views=2, color_sh_degree=None, feature_channels=8, feature_sh_degree=1),
     dict(G=2000, size=48, views=2, color_sh_degree=2, feature_channels=4, feature_sh_degree=0),
+    dict(G=1500, size=32, views=6, color_sh_degree=3, feature_channels=4, feature_sh_degree=2),   # > 1 view chunk in sh.hip
 ])
 def test_fused_scene_inputs_match_oracle(hip_device, cfg, shared):
     from latentsplat_amd.decoder import cuda_splatting as cs
