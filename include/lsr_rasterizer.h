@@ -150,6 +150,17 @@ size_t lsr_binning_workspace_bytes(const lsr_dims *d, int64_t num_pairs, int32_t
 size_t lsr_grad_workspace_bytes(const lsr_dims *d);
 int lsr_get_layout(const lsr_dims *d, int64_t num_pairs, lsr_layout *out);
 
+/* ---- camera table.  Fills views_out[num_views][LSR_VIEW_FLOATS] on the device from what the
+ * reference's render_cuda receives (cuda_splatting.py:56-63): camera-to-world `extrinsics` [V][4][4],
+ * normalised `intrinsics` [V][3][3], `near` / `far` [V], background [3] (bg_view_stride 0) or [V][3]
+ * (stride 3).  With scale_invariant != 0 the scene scale 1/near is applied to the camera
+ * translation and near/far and stored in slot [40] for the kernels to apply to the Gaussians
+ * (cuda_splatting.py:75-82).  Replaces get_fov / get_projection_matrix / inverse / matmul
+ * (:111-118) — one launch instead of ~40 host-bound PyTorch ops.  Async. */
+int lsr_build_views(int32_t num_views, const float *extrinsics, const float *intrinsics, const float *near,
+                    const float *far, const float *bg, int32_t bg_view_stride, int32_t scale_invariant,
+                    float *views_out, lsr_stream_t stream);
+
 /* ---- forward, phase 1: per-Gaussian preprocess + per-tile counting + tile offset scan.
  * Writes radii.  Synchronises `stream` once to return the pair count and the longest tile list
  * through the two host pointers (both required). */

@@ -64,7 +64,7 @@ class Layout(C.Structure):
 EXPORTS = (
     "lsr_abi_version", "lsr_error_string", "lsr_last_hip_error", "lsr_geom_workspace_bytes",
     "lsr_image_workspace_bytes", "lsr_binning_workspace_bytes", "lsr_grad_workspace_bytes",
-    "lsr_get_layout", "lsr_forward_prepare", "lsr_forward_render", "lsr_backward",
+    "lsr_get_layout", "lsr_build_views", "lsr_forward_prepare", "lsr_forward_render", "lsr_backward",
     "lsr_profile_enable", "lsr_profile_num_stages", "lsr_profile_stage_name", "lsr_profile_read",
 )
 
@@ -107,6 +107,8 @@ def load():
     lib.lsr_binning_workspace_bytes.argtypes = [C.POINTER(Dims), I64, I32]
     lib.lsr_get_layout.restype = C.c_int
     lib.lsr_get_layout.argtypes = [C.POINTER(Dims), I64, C.POINTER(Layout)]
+    lib.lsr_build_views.restype = C.c_int
+    lib.lsr_build_views.argtypes = [I32, P, P, P, P, P, I32, I32, P, P]
     lib.lsr_forward_prepare.restype = C.c_int
     lib.lsr_forward_prepare.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, C.POINTER(I64),
                                         C.POINTER(I32), P]

@@ -180,6 +180,17 @@ int lsr_get_layout(const lsr_dims *d, int64_t num_pairs, lsr_layout *out) {
     return LSR_OK;
 }
 
+int lsr_build_views(int32_t num_views, const float *extrinsics, const float *intrinsics, const float *near,
+                    const float *far, const float *bg, int32_t bg_view_stride, int32_t scale_invariant,
+                    float *views_out, lsr_stream_t stream) {
+    g_last_hip_error = 0;
+    if (num_views < 1 || (bg_view_stride != 0 && bg_view_stride != 3)) return LSR_EINVAL;
+    if (!extrinsics || !intrinsics || !near || !far || !bg || !views_out) return LSR_ENULL;
+    LSR_HIP(launch_build_views(num_views, extrinsics, intrinsics, near, far, bg, bg_view_stride,
+                               scale_invariant != 0, views_out, (hipStream_t)stream));
+    return LSR_OK;
+}
+
 int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii,
                         int64_t *num_pairs_host, int32_t *max_tile_pairs_host, lsr_stream_t stream) {
     g_last_hip_error = 0;

@@ -132,6 +132,9 @@ void prof_end(int stage, hipStream_t s);
 hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii,
                              hipStream_t s);
 hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s);
+hipError_t launch_build_views(int V, const float *extrinsics, const float *intrinsics, const float *near,
+                              const float *far, const float *bg, int bg_stride, int scale_invariant,
+                              float *out, hipStream_t s);
 hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s);
 hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom, const char *grad,
                               const lsr_in_grads &gin, hipStream_t s);

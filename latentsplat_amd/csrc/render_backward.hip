@@ -211,7 +211,8 @@ static int pick_pxl_bwd(int nchp, int64_t tiles_total) {
         const int x = atoi(e);
         if (x == 1 || x == 2 || x == 4) return nchp > 12 ? 1 : ((nchp > 4 && x == 4) ? 2 : x);
     }
-    int pxl = tiles_total >= 2048 ? 4 : (tiles_total >= 1024 ? 2 : 1);
+    // aim for >= 4 waves on each of the 1024 SIMDs (the kernel is VALU bound and needs them)
+    int pxl = tiles_total >= 4096 ? 4 : (tiles_total >= 2048 ? 2 : 1);
     if (nchp > 4 && pxl == 4) pxl = 2;  // dpix + accum double the per-pixel register cost
     if (nchp > 12) pxl = 1;
     return pxl;

@@ -1,0 +1,96 @@
+// views.hip — builds the per-view camera table (LSR_VIEW_FLOATS floats per view) on the device in
+// one tiny launch.  Replaces ~40 launch-bound PyTorch ops per render call (measured 0.66 ms per
+// call on MI355X, more than the rasterizer's own forward at 4 views) that the reference performs
+// in /root/reference/src/model/decoder/cuda_splatting.py:75-82 (1/near scale invariance),
+// :111-113 (get_fov, tan), :115-118 (projection, inverse extrinsics, full projection) and
+// src/geometry/projection.py:233-247 (get_fov).  One thread per view, double precision inside.
+#include "lsr_internal.h"
+
+namespace lsr {
+
+__device__ static void inv3(const double m[9], double o[9]) {
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + c * C, id = 1.0 / det;
+    o[0] = A * id; o[1] = -(b * i - c * h) * id; o[2] = (b * f - c * e) * id;
+    o[3] = B * id; o[4] = (a * i - c * g) * id;  o[5] = -(a * f - c * d) * id;
+    o[6] = C * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
+}
+
+// general 4x4 inverse by cofactors (camera-to-world matrices are affine, but keep it general)
+__device__ static void inv4(const double m[16], double inv[16]) {
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12], id = 1.0 / det;
+    for (int k = 0; k < 16; ++k) inv[k] *= id;
+}
+
+__global__ void k_build_views(int V, const float *__restrict__ extrinsics, const float *__restrict__ intrinsics,
+                              const float *__restrict__ near, const float *__restrict__ far,
+                              const float *__restrict__ bg, int bg_stride, int scale_invariant,
+                              float *__restrict__ out) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    double E[16], K[9], Ki[9], Vw[16];
+    for (int k = 0; k < 16; ++k) E[k] = extrinsics[16 * v + k];
+    for (int k = 0; k < 9; ++k) K[k] = intrinsics[9 * v + k];
+    const float scale_f = scale_invariant ? 1.0f / near[v] : 1.0f;   // float, as the reference computes it
+    const double scale = scale_f;
+    E[3] *= scale; E[7] *= scale; E[11] *= scale;
+    const double nr = (double)(near[v] * scale_f), fr = (double)(far[v] * scale_f);
+    // field of view: angle between the rays through opposite image-edge midpoints
+    inv3(K, Ki);
+    const double pts[4][3] = {{0, 0.5, 1}, {1, 0.5, 1}, {0.5, 0, 1}, {0.5, 1, 1}};
+    double ray[4][3];
+    for (int e = 0; e < 4; ++e) {
+        double r[3], n = 0;
+        for (int i = 0; i < 3; ++i) { r[i] = Ki[3 * i] * pts[e][0] + Ki[3 * i + 1] * pts[e][1] + Ki[3 * i + 2] * pts[e][2]; n += r[i] * r[i]; }
+        n = sqrt(n);
+        for (int i = 0; i < 3; ++i) ray[e][i] = r[i] / n;
+    }
+    auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    const double tan_x = tan(0.5 * acos(fmin(1.0, fmax(-1.0, dot(ray[0], ray[1])))));
+    const double tan_y = tan(0.5 * acos(fmin(1.0, fmax(-1.0, dot(ray[2], ray[3])))));
+    // perspective matrix (x,y -> (-1,1), z -> (0,1), +z forward)
+    double P[16] = {0};
+    const double right = tan_x * nr, top = tan_y * nr;
+    P[0] = 2 * nr / (2 * right); P[5] = 2 * nr / (2 * top);
+    P[10] = fr / (fr - nr); P[11] = -(fr * nr) / (fr - nr); P[14] = 1;
+    inv4(E, Vw);   // world -> view
+    float *o = out + (size_t)v * LSR_VIEW_FLOATS;
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            o[4 * c + r] = (float)Vw[4 * r + c];                    // memory = transposed matrix
+            double f = 0;
+            for (int k = 0; k < 4; ++k) f += P[4 * r + k] * Vw[4 * k + c];   // (P * view)[r][c]
+            o[16 + 4 * c + r] = (float)f;
+        }
+    o[32] = (float)E[3]; o[33] = (float)E[7]; o[34] = (float)E[11];
+    o[35] = (float)tan_x; o[36] = (float)tan_y;
+    o[37] = bg[(size_t)v * bg_stride]; o[38] = bg[(size_t)v * bg_stride + 1]; o[39] = bg[(size_t)v * bg_stride + 2];
+    o[40] = scale_f; o[41] = o[42] = o[43] = 0.0f;
+}
+
+hipError_t launch_build_views(int V, const float *extrinsics, const float *intrinsics, const float *near,
+                              const float *far, const float *bg, int bg_stride, int scale_invariant,
+                              float *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_views, dim3((V + 63) / 64), dim3(64), 0, s, V, extrinsics, intrinsics, near, far,
+                       bg, bg_stride, scale_invariant, out);
+    return hipGetLastError();
+}
+
+}  // namespace lsr

@@ -26,7 +26,7 @@ from typing import Literal, Optional
 import torch
 from torch import Tensor
 
-from ..rasterizer import fused_feature_sh_supported, make_view_table, rasterize_views
+from ..rasterizer import build_view_table, fused_feature_sh_supported, make_view_table, rasterize_views
 from .geometry import depth_to_relative_disparity, eval_sh, get_fov, homogenize_points
 
 
@@ -103,13 +103,22 @@ def _squeeze_shared(t: Optional[Tensor]) -> Optional[Tensor]:
     return t[0] if (t is not None and t.shape[0] == 1) else t
 
 
-def _render_views(cams: _Cameras, scale: Optional[Tensor], image_shape, background: Tensor, means: Tensor,
-                  covariances: Tensor, opacities: Tensor, color_sh, feature_sh, use_sh: bool) -> RenderOutput:
-    """UNSCALED means (B|1,G,3) / covariances (B|1,G,3,3); opacities (B|1,G); *_sh (B|1,G,.,.).
-    ``scale`` (B,) is the scene scale the cameras were built for (None = 1)."""
+def _view_table(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, background: Tensor,
+                scale_invariant: bool) -> Tensor:
+    """(B,44) camera table + scene scale.  On the MI355X: one kernel; for host tensors (the
+    not-gpu tests, which substitute the rasterizer) the same math in PyTorch."""
+    if extrinsics.is_cuda:
+        return build_view_table(extrinsics, intrinsics, near, far, background, scale_invariant)
+    cams, scale = _scaled_cameras(extrinsics, intrinsics, near, far, scale_invariant)
+    return make_view_table(cams.view_matrix, cams.full_projection, cams.campos, cams.tan_fov_x,
+                           cams.tan_fov_y, background, scale)
+
+
+def _render_views(views: Tensor, image_shape, means: Tensor, covariances: Tensor, opacities: Tensor,
+                  color_sh, feature_sh, use_sh: bool) -> RenderOutput:
+    """``views`` (B,44); UNSCALED means (B|1,G,3) / covariances (B|1,G,3,3); opacities (B|1,G);
+    *_sh (B|1,G,.,.)."""
     h, w = image_shape
-    views = make_view_table(cams.view_matrix, cams.full_projection, cams.campos,
-                            cams.tan_fov_x, cams.tan_fov_y, background, scale)
     degree, kw = 0, {}
     if use_sh:
         if color_sh is not None:
@@ -119,8 +128,8 @@ def _render_views(cams: _Cameras, scale: Optional[Tensor], image_shape, backgrou
             if fused_feature_sh_supported(feature_sh):
                 kw.update(feature_sh=_squeeze_shared(feature_sh))
             else:   # evaluate on the host like the reference does
-                scaled = means if scale is None else means * scale[:, None, None]
-                kw.update(features=_payload(scaled, cams.campos, None, feature_sh, True)[3])
+                scaled = means * views[:, 40, None, None]
+                kw.update(features=_payload(scaled, views[:, 32:35], None, feature_sh, True)[3])
     else:
         if color_sh is not None:
             kw.update(colors_precomp=_squeeze_shared(color_sh[..., 0]))
@@ -170,10 +179,9 @@ def render_cuda(
 ) -> RenderOutput:
     assert gaussian_color_sh_coefficients is not None or gaussian_feature_sh_coefficients is not None
     assert use_sh or gaussian_color_sh_coefficients.shape[-1] == 1
-    cams, scale = _scaled_cameras(extrinsics, intrinsics, near, far, scale_invariant)
-    return _render_views(cams, scale, image_shape, background_color, gaussian_means, gaussian_covariances,
-                         gaussian_opacities, gaussian_color_sh_coefficients,
-                         gaussian_feature_sh_coefficients, use_sh)
+    views = _view_table(extrinsics, intrinsics, near, far, background_color, scale_invariant)
+    return _render_views(views, image_shape, gaussian_means, gaussian_covariances, gaussian_opacities,
+                         gaussian_color_sh_coefficients, gaussian_feature_sh_coefficients, use_sh)
 
 
 def render_scenes(
@@ -197,13 +205,14 @@ def render_scenes(
     assert gaussian_color_sh_coefficients is not None or gaussian_feature_sh_coefficients is not None
     b, v = extrinsics.shape[:2]
     outs = []
+    # one camera-table launch for all b*v views
+    views = _view_table(extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(0, 1), far.flatten(0, 1),
+                        background_color, scale_invariant)
     for s in range(b):
-        cams, scale = _scaled_cameras(extrinsics[s], intrinsics[s], near[s], far[s], scale_invariant)
         csh = None if gaussian_color_sh_coefficients is None else gaussian_color_sh_coefficients[s][None]
         fsh = None if gaussian_feature_sh_coefficients is None else gaussian_feature_sh_coefficients[s][None]
-        outs.append(_render_views(cams, scale, image_shape, background_color[None].expand(v, 3),
-                                  gaussian_means[s][None], gaussian_covariances[s][None],
-                                  gaussian_opacities[s][None], csh, fsh, use_sh))
+        outs.append(_render_views(views[s * v:(s + 1) * v], image_shape, gaussian_means[s][None],
+                                  gaussian_covariances[s][None], gaussian_opacities[s][None], csh, fsh, use_sh))
     cat = lambda xs: None if xs[0] is None else torch.cat(xs, dim=0)
     return RenderOutput(cat([o.color for o in outs]), cat([o.feature for o in outs]),
                         cat([o.mask for o in outs]), cat([o.depth for o in outs]))

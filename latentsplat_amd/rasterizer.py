@@ -58,6 +58,28 @@ def make_view_table(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanf
                       torch.zeros((V, 3), dtype=dt, device=dev)], dim=1).contiguous()
 
 
+def build_view_table(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, background: Tensor,
+                     scale_invariant: bool = True) -> Tensor:
+    """(V,44) camera table computed on the device by one kernel (``lsr_build_views``): what the
+    reference derives per call with get_fov / get_projection_matrix / inverse / matmul
+    (cuda_splatting.py:75-82,111-118).  ``background`` is ``(3,)`` or ``(V,3)``.  No gradient flows
+    to the cameras (the reference's rasterizer has none either)."""
+    lib = _lib.load()
+    dev = extrinsics.device
+    if dev.type != "cuda":
+        raise LsrError("build_view_table runs on the MI355X; use make_view_table for host tensors")
+    V = extrinsics.shape[0]
+    f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    ext, intr, nr, fr, bg = f(extrinsics), f(intrinsics), f(near), f(far), f(background)
+    out = torch.empty((V, _lib.VIEW_FLOATS), dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        _lib.check(lib.lsr_build_views(V, _ptr(ext), _ptr(intr), _ptr(nr), _ptr(fr), _ptr(bg),
+                                       0 if bg.dim() == 1 else 3, 1 if scale_invariant else 0, _ptr(out), stream),
+                   "lsr_build_views")
+    return out
+
+
 def _ptr(t: Optional[Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 

@@ -299,3 +299,26 @@ def test_full_size_backward_against_oracle(hip_device, full_run):
         err[behind] = 0
         assert err.max() <= 1e-4 * scale, f"{name}: {err.max():.3e} vs scale {scale:.3e} (row {err.argmax()})"
         assert np.median(err) <= 1e-6 * scale
+
+
+def test_device_camera_table_matches_host_math(hip_device):
+    """lsr_build_views == the reference's per-call camera math (restated in cuda_splatting._scaled_cameras)."""
+    from latentsplat_amd.decoder import cuda_splatting as cs
+    from latentsplat_amd.rasterizer import build_view_table, make_view_table
+    sc = util.make_scene(10, image_size=64, views=7, color_sh_degree=0)
+    near = sc.near * torch.linspace(0.8, 1.7, 7)
+    far = sc.far * torch.linspace(1.0, 0.5, 7)
+    intr = sc.intrinsics.clone()
+    intr[:, 0, 0] = torch.linspace(0.6, 1.4, 7); intr[:, 1, 1] = torch.linspace(1.3, 0.7, 7)
+    intr[:, 0, 2] = torch.linspace(0.45, 0.55, 7)
+    bg = torch.rand(7, 3)
+    for si in (True, False):
+        cams, scale = cs._scaled_cameras(sc.extrinsics, intr, near, far, si)   # float32, as the reference
+        want = make_view_table(cams.view_matrix, cams.full_projection, cams.campos, cams.tan_fov_x, cams.tan_fov_y, bg, scale)
+        got = build_view_table(sc.extrinsics.to(hip_device), intr.to(hip_device), near.to(hip_device), far.to(hip_device),
+                               bg.to(hip_device), si).cpu()
+        assert got.shape == (7, 44)
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+    got1 = build_view_table(sc.extrinsics.to(hip_device), intr.to(hip_device), near.to(hip_device), far.to(hip_device),
+                            bg[0].to(hip_device), True).cpu()
+    assert torch.equal(got1[:, 37:40], bg[0][None].expand(7, 3))
