@@ -6,7 +6,8 @@
 A *step* is one pass of the hot path (preprocess -> bin -> per-tile sort -> composite) over one
 batch of synthetic input: ``--views`` target views (default 16) of one seeded random-init scene of
 ``--gaussians`` latent Gaussians (default 300 000; 4 feature channels + opacity, no colour) at
-256x256 — BASELINE.json configs[1].  Inputs are resident in HBM before the timed region.
+256x256 — BASELINE.json configs[1].  Inputs are resident in HBM before the timed region; the scene
+is shared by the views (scene-level inputs, per-view cameras), as in the decoder's training use.
 ``value`` = views rendered per second by the whole job (all ranks).  With N > 1 every rank renders
 its own scene (disjoint seeds), there is no data-path collective: weak scaling.
 
@@ -36,24 +37,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 
 
 def build_inputs(G, V, size, device, seed):
-    """Rasterizer-boundary tensors for one scene / V views, produced by the package's wrapper math."""
-    from latentsplat_amd.decoder import cuda_splatting as cs
-    from latentsplat_amd.decoder.geometry import get_fov
-    from latentsplat_amd.rasterizer import make_view_table
+    """Scene-level inputs of one scene / V views, resident on the device: shared means (G,3),
+    3x3 covariances, opacities and 4-channel latent features; per-view cameras in the (V,44) view
+    table (built by the library's own kernel, scene scale 1/near included)."""
+    from latentsplat_amd.rasterizer import build_view_table
     from latentsplat_amd.synthetic import make_scene
     sc = make_scene(G, image_size=size, views=V, color_sh_degree=None, feature_channels=4,
                     feature_sh_degree=0, seed=seed).to(device)
-    means = sc.means[None].expand(V, -1, -1)
-    covs = sc.covariances[None].expand(V, -1, -1, -1)
-    ext, nr, fr, means, covs = cs._scale_scene(sc.extrinsics, sc.near, sc.far, means, covs)
-    fov_x, fov_y = get_fov(sc.intrinsics).unbind(-1)
-    cams = cs._cameras(ext, nr, fr, fov_x, fov_y)
-    _, _, _, features = cs._payload(means, cams.campos, None, sc.feature_sh[None], True)
-    bg = torch.zeros((V, 3), device=device)
-    views = make_view_table(cams.view_matrix, cams.full_projection, cams.campos, cams.tan_fov_x,
-                            cams.tan_fov_y, bg)
-    return dict(views=views, means=means.contiguous(), cov6=cs._pack_covariances(covs).contiguous(),
-                opac=sc.opacities[:, None].contiguous(), features=features.contiguous(), cams=cams)
+    views = build_view_table(sc.extrinsics, sc.intrinsics, sc.near, sc.far, torch.zeros(3, device=device), True)
+    features = (0.5 + 0.28209479177387814 * sc.feature_sh[..., 0]).contiguous()   # degree-0 latent SH
+    return dict(views=views, means=sc.means.contiguous(), cov=sc.covariances.contiguous(),
+                opac=sc.opacities[:, None].contiguous(), features=features)
 
 
 def cpu_baseline(G, size, seed, budget_s=12.0):
@@ -110,6 +104,41 @@ def rank_seed(base, rank):
     return base + rank
 
 
+def decoder_step_timing(dev, steps=10):
+    """BASELINE configs[3] shape through the decoder surface: DecoderSplattingCUDA.forward
+    (+ backward of an MSE-like loss on colour and latent mean) for batch_size 1 x 4 target views,
+    G = 393 216 Gaussians (2 context views x 256^2 x 3), colour SH degree 4 + 4-channel latent SH
+    degree 2 — the call the reference's training_step makes (model_wrapper.py:361-371)."""
+    from latentsplat_amd import decoder as dec
+    from latentsplat_amd.synthetic import make_scene
+    sc = make_scene(393_216, image_size=256, views=4, color_sh_degree=4, feature_channels=4,
+                    feature_sh_degree=2, seed=4321).to(dev)
+    leaf = lambda t: t[None].contiguous().requires_grad_(True)
+    gauss = dec.Gaussians(leaf(sc.means), leaf(sc.covariances), leaf(sc.opacities), leaf(sc.color_sh), leaf(sc.feature_sh))
+    d = dec.get_decoder(dec.DecoderSplattingCUDACfg(name="splatting_cuda"), [0.0, 0.0, 0.0]).to(dev)
+    args = (gauss, sc.extrinsics[None], sc.intrinsics[None], sc.near[None], sc.far[None], (256, 256))
+    gc = torch.randn((1, 4, 3, 256, 256), device=dev)
+    gf = torch.randn((1, 4, 4, 256, 256), device=dev)
+    leaves = (gauss.means, gauss.covariances, gauss.opacities, gauss.color_harmonics, gauss.feature_harmonics)
+
+    def fwd():
+        with torch.no_grad():
+            d.forward(*args)
+
+    def fwdbwd():
+        out = d.forward(*args)
+        torch.autograd.backward([out.color, out.feature_posterior.mean], [gc, gf])
+        for t in leaves:
+            t.grad = None
+
+    res = {}
+    for name, fn in (("forward", fwd), ("forward_backward", fwdbwd)):
+        el = timed_region(fn, steps, 3, None, lambda: torch.cuda.synchronize(dev))
+        res[name] = dict(ms_per_step=1e3 * el / steps, views_per_s=4 * steps / el)
+    res["config"] = "configs[3] shape: 1 scene x 4 views, 393216 Gaussians, colour SH deg 4 + 4-ch latent SH deg 2, 256x256"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +171,7 @@ def main():
     inp = build_inputs(G, V, S, dev, seed=rank_seed(1234, rank))
 
     def fwd(need_grad=False):
-        m, c, o, f = inp["means"], inp["cov6"], inp["opac"], inp["features"]
+        m, c, o, f = inp["means"], inp["cov"], inp["opac"], inp["features"]
         if need_grad:
             m, c, o, f = (t.detach().requires_grad_(True) for t in (m, c, o, f))
         out = rasterize_views(inp["views"], S, S, 0, m, c, o, features=f)
@@ -216,6 +245,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(G, S, 1234)
+    dec_step = None
+    if rank == 0 and world == 1 and not args.no_bwd:
+        del inp
+        torch.cuda.empty_cache()
+        dec_step = decoder_step_timing(dev)
 
     if rank == 0:
         line = {
@@ -229,7 +263,7 @@ def main():
                        "parallelism": f"replicas x{world} (one scene per rank, no data-path collective)"},
             "ms_per_view_fwd": 1e3 * el_fwd / (V * args.steps),
             "kernel_ms_per_launch": {k: (ms / n if n else None) for k, (ms, n) in prof.items()},
-            "fwdbwd": fb, "roofline": roofline, "roofline_path": path, "cpu_baseline": cpu,
+            "fwdbwd": fb, "decoder_step": dec_step, "roofline": roofline, "roofline_path": path, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if dist is not None:
