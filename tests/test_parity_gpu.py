@@ -86,9 +86,10 @@ def test_forward_parity(hip_device, name):
     _check_forward(bi, run)
 
 
-@pytest.mark.parametrize("pxl", ["1", "2", "4"])
-def test_forward_parity_all_wave_shapes(hip_device, monkeypatch, pxl):
-    monkeypatch.setenv("LSR_PXL", pxl)
+@pytest.mark.parametrize("split", ["1", "2", "4"])
+def test_forward_parity_all_item_splits(hip_device, monkeypatch, split):
+    """Work items of 4 / 2 / 1 quadrants per (view, tile) must all give the same render."""
+    monkeypatch.setenv("LSR_SPLIT", split)
     sc, H, W = _scene(CASES["rgb_deg4_feat4_deg2_v3"])
     bi = util.boundary_inputs(sc, H, W, bg=(0.2, 0.4, 0.6))
     run = util.HipRun(bi, hip_device)
@@ -113,7 +114,7 @@ def _grad_case(hip_device, case, with_aux, pxl_env=None, monkeypatch=None):
     from latentsplat_amd.rasterizer import rasterize_views
     if pxl_env is not None:
         monkeypatch.setenv("LSR_PXL_BWD", pxl_env)
-        monkeypatch.setenv("LSR_PXL", pxl_env)
+        monkeypatch.setenv("LSR_SPLIT", {"1": "4", "2": "2", "4": "1"}[pxl_env])
     sc, H, W = _scene(case)
     bi = util.boundary_inputs(sc, H, W, bg=(0.3, 0.1, 0.5))
     V = bi["V"]
