@@ -20,7 +20,7 @@ namespace lsr {
 constexpr int kScanThreads = 1024;
 
 __global__ void __launch_bounds__(kScanThreads)
-k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *header,
+k_tile_scan(const uint32_t *__restrict__ count, const uint32_t *__restrict__ cost, uint32_t *__restrict__ start, uint32_t *header,
             uint32_t *__restrict__ order, int N, int force_base, int limit_pct) {
     __shared__ uint32_t s_sum[kScanThreads];
     __shared__ uint32_t s_max[kScanThreads];
@@ -41,8 +41,20 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
     uint32_t run = s_sum[tid] - sum;  // exclusive prefix of this thread's chunk
     for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
     if (tid == kScanThreads - 1) { start[N] = s_sum[tid]; header[kHdrPairs] = s_sum[tid]; header[kHdrMaxTile] = s_max[tid]; }
-    // ---- work items, costliest first: counting sort on kScanThreads cost classes ----
+    // ---- work items, costliest first: counting sort on kScanThreads classes of the per-tile work
+    // estimate accumulated by k_preprocess (list length is a poor proxy: the work per entry depends
+    // on how many quadrants its footprint reaches) ----
     const uint32_t maxc = s_max[kScanThreads - 1], total = s_sum[kScanThreads - 1];
+    __syncthreads();
+    uint32_t wmax = 0;
+    for (int i = lo; i < hi; ++i) wmax = max(wmax, cost[i]);
+    s_max[tid] = wmax;
+    __syncthreads();
+    for (int off = kScanThreads / 2; off > 0; off >>= 1) {
+        if (tid < off) s_max[tid] = max(s_max[tid], s_max[tid + off]);
+        __syncthreads();
+    }
+    const uint64_t scale = (uint64_t)s_max[0] + 1u;
     __syncthreads();
     s_sum[tid] = 0;
     __syncthreads();
@@ -50,18 +62,18 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
     if (force_base) base = (uint32_t)force_base;
     const uint32_t mean = total / (uint32_t)N + 1u;
     const uint32_t limit = (uint32_t)((uint64_t)mean * (uint32_t)limit_pct / 100u) / base + 1u;   // longest list one item may walk
-    const uint64_t scale = maxc + 1u;
+    (void)maxc;
     auto nsplit = [&](uint32_t c) -> uint32_t {
         uint32_t sp = base;
         while (sp < 4u && c / sp > limit) sp <<= 1;
         return sp;
     };
-    auto cls = [&](uint32_t c, uint32_t sp) -> uint32_t {
-        return kScanThreads - 1 - (uint32_t)(((uint64_t)(c / sp) * kScanThreads) / scale);
+    auto cls = [&](uint32_t w, uint32_t sp) -> uint32_t {
+        return kScanThreads - 1 - (uint32_t)(((uint64_t)(w / sp) * kScanThreads) / scale);
     };
     for (int i = lo; i < hi; ++i) {
-        const uint32_t c = count[i], sp = nsplit(c);
-        atomicAdd(&s_sum[cls(c, sp)], sp);
+        const uint32_t sp = nsplit(count[i]);
+        atomicAdd(&s_sum[cls(cost[i], sp)], sp);
     }
     __syncthreads();
     const uint32_t mine = s_sum[tid];
@@ -76,8 +88,8 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
     if (tid == kScanThreads - 1) header[kHdrNumItems] = s_sum[tid];
     __syncthreads();
     for (int i = lo; i < hi; ++i) {
-        const uint32_t c = count[i], sp = nsplit(c);
-        const uint32_t at = atomicAdd(&s_max[cls(c, sp)], sp);
+        const uint32_t sp = nsplit(count[i]);
+        const uint32_t at = atomicAdd(&s_max[cls(cost[i], sp)], sp);
         if (sp == 1) order[at] = (uint32_t)i | (0xFu << kItemOwnShift);
         else if (sp == 2) { order[at] = (uint32_t)i | (0x3u << kItemOwnShift); order[at + 1] = (uint32_t)i | (0xCu << kItemOwnShift); }
         else for (uint32_t q = 0; q < 4; ++q) order[at + q] = (uint32_t)i | ((1u << q) << kItemOwnShift);
@@ -89,7 +101,7 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s) {
     const int N = d.num_views * (int)num_tiles(d);
     prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
-                       (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
+                       (const uint32_t *)(geom + L.tile_count), (const uint32_t *)(geom + L.tile_cost), (uint32_t *)(geom + L.tile_start),
                        (uint32_t *)(geom + L.header), (uint32_t *)(geom + L.tile_order), N,
                        getenv("LSR_SPLIT") ? atoi(getenv("LSR_SPLIT")) : 0,
                        getenv("LSR_LIMIT") ? atoi(getenv("LSR_LIMIT")) : 100000);

@@ -2,8 +2,9 @@
 // Outputs colour (+ bg), features (bg 0), mask = 1 - T, depth = sum alpha T z, and keeps
 // final_T / n_contrib for the backward pass.  Spec: SURVEY.md Appendix A.3 step 7 + A.4.
 //
-// Execution shape (CDNA4): persistent waves pull work items — (view, tile, set of 8x8 quadrants),
-// costliest first — from a global queue (lsr_internal.h kItem*).  A lane owns the same position
+// Execution shape (CDNA4): persistent waves process work items — (view, tile, set of 8x8
+// quadrants), sorted by estimated work (lsr_internal.h kItem*): the first one per wave by a static
+// balanced assignment, further ones from a global queue.  A lane owns the same position
 // in each of the 4 quadrants (4 pixels per lane); quadrants outside the item's set are simply
 // never touched.  Per 64 staged list entries the wave walks, quadrant by quadrant, only the
 // entries whose alpha >= 1/255 footprint can reach that quadrant (lsr_blend.h), UNR at a time.
@@ -18,9 +19,15 @@
 
 namespace lsr {
 
-// Workgroups are 4 independent waves (one per SIMD of a CU): the waves never synchronise with each
-// other, the grouping only makes the dispatcher spread them evenly over the SIMDs.
-constexpr int kWavesPerBlock = 4;
+// One workgroup of 16 independent waves per CU (4 per SIMD; the waves never synchronise with each
+// other).  Waves w, w+4, w+8, w+12 of a workgroup share a SIMD, which lets the kernel decide
+// WHICH work items share a SIMD: items arrive sorted by cost, and SIMD-bin b takes items
+// b, 2B-1-b, 2B+b, 4B-1-b, ... (B = number of bins) — pairing expensive with cheap tiles so every
+// SIMD gets nearly the same total.  The kernel is VALU-throughput bound, so the makespan is the
+// largest per-SIMD total; with one item per wave and no control over placement it was ~1.4x the
+// mean (measured).
+constexpr int kSimdBins = kWaveSlots / 4;
+constexpr int kCUs = kSimdBins / 4;
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave execute in order; this only stops the compiler from moving LDS
     // accesses across the staging / consuming phases and drains the wave's own LDS queue.
@@ -44,13 +51,15 @@ struct RenderFwdParams {
     uint32_t *n_contrib;
 };
 
-template <int NCHP, int UNR>
-__global__ void __launch_bounds__(LSR_WAVE * kWavesPerBlock)
+// WPB = waves per workgroup: 16 (one workgroup per CU) unless the LDS slices do not fit, then 4
+// workgroups of 4 waves stand in for it (same bins, placement then up to the dispatcher).
+template <int NCHP, int UNR, int WPB>
+__global__ void __launch_bounds__(LSR_WAVE * WPB)
 k_render_fwd(RenderFwdParams p) {
     constexpr int PXL = 4;
-    __shared__ float4 s_q0_all[kWavesPerBlock][LSR_WAVE + 1];   // slot 64: null record (alpha == 0) pads partial groups
-    __shared__ float4 s_q1_all[kWavesPerBlock][LSR_WAVE + 1];
-    __shared__ float4 s_pay_all[kWavesPerBlock][LSR_WAVE + 1][NCHP / 4];
+    __shared__ float4 s_q0_all[WPB][LSR_WAVE + 1];   // slot 64: null record (alpha == 0) pads partial groups
+    __shared__ float4 s_q1_all[WPB][LSR_WAVE + 1];
+    __shared__ float4 s_pay_all[WPB][LSR_WAVE + 1][NCHP / 4];
 
     const int lane = threadIdx.x & (LSR_WAVE - 1);
     const int wid = threadIdx.x / LSR_WAVE;
@@ -66,11 +75,26 @@ k_render_fwd(RenderFwdParams p) {
     const int coff = p.has_color ? 3 : 0;
     const size_t HW = (size_t)p.H * p.W;
 
+    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)kCUs);   // 0..15
+    const uint32_t bin = (blockIdx.x % (uint32_t)kCUs) * 4u + (vwave & 3u);
+    // First item of every wave: static, folded (boustrophedon) over the cost-sorted list, so the 4
+    // waves of a SIMD start with a balanced total.  Everything beyond the first kWaveSlots items
+    // is pulled from a global queue (costliest first) as waves become free.
+    const uint32_t j0 = vwave >> 2;
+    bool first = true;
     for (;;) {
-        uint32_t qi = 0;
-        if (lane == 0) qi = atomicAdd(p.queue, 1u);
-        qi = __builtin_amdgcn_readfirstlane(qi);
-        if (qi >= num_items) break;
+        uint32_t qi;
+        if (first) {
+            qi = (j0 & 1u) ? (j0 + 1u) * (uint32_t)kSimdBins - 1u - bin : j0 * (uint32_t)kSimdBins + bin;
+            first = false;
+            if (qi >= num_items) continue;   // fewer items than wave slots: go straight to the queue (empty)
+        } else {
+            if (num_items <= (uint32_t)kWaveSlots) break;
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(p.queue, 1u);
+            qi = (uint32_t)kWaveSlots + __builtin_amdgcn_readfirstlane(t);
+            if (qi >= num_items) break;
+        }
         const unsigned long long t_begin = p.trace ? __builtin_readcyclecounter() : 0ull;
         const uint32_t item = p.items[qi];
         const uint32_t vt = item & kItemTileMask, own = item >> kItemOwnShift;
@@ -235,10 +259,8 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.final_T = (float *)(img + I.final_T); p.n_contrib = (uint32_t *)(img + I.n_contrib);
     const int nch = (p.has_color ? 3 : 0) + d.feat_channels;
     const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));
-    // one wave per slot, never more waves than the most items there can be
     const int64_t max_items = 4 * (int64_t)p.T * d.num_views;
-    const int waves = (int)(max_items < kWaveSlots ? max_items : kWaveSlots);
-    dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+
     p.trace = nullptr;
     const char *trace_path = getenv("LSR_TRACE");
     if (trace_path) {
@@ -246,11 +268,11 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
         (void)hipMemsetAsync(p.trace, 0, (size_t)max_items * 32, s);
     }
     prof_begin(kStRenderFwd, s);
-#define LSR_RF(N, U) hipLaunchKernelGGL((k_render_fwd<N, U>), grid, dim3(LSR_WAVE * kWavesPerBlock), 0, s, p)
-    if (nchp == 4) LSR_RF(4, 2);
-    else if (nchp == 8) LSR_RF(8, 2);
-    else if (nchp == 12) LSR_RF(12, 2);
-    else LSR_RF(36, 1);
+#define LSR_RF(N, U, WPB) hipLaunchKernelGGL((k_render_fwd<N, U, WPB>), dim3(kCUs * (16 / WPB)), dim3(LSR_WAVE * WPB), 0, s, p)
+    if (nchp == 4) LSR_RF(4, 2, 16);
+    else if (nchp == 8) LSR_RF(8, 2, 16);
+    else if (nchp == 12) LSR_RF(12, 2, 16);
+    else LSR_RF(36, 1, 4);
 #undef LSR_RF
     prof_end(kStRenderFwd, s);
     if (trace_path) {  // debug only: dump per-item timing of this launch
