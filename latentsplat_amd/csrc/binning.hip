@@ -21,7 +21,7 @@ constexpr int kScanThreads = 1024;
 
 __global__ void __launch_bounds__(kScanThreads)
 k_tile_scan(const uint32_t *__restrict__ count, const uint32_t *__restrict__ cost, uint32_t *__restrict__ start, uint32_t *header,
-            uint32_t *__restrict__ order, int N, int force_base, int limit_pct) {
+            uint32_t *__restrict__ order, uint32_t *__restrict__ lpt, int N, int force_base, int limit_pct) {
     __shared__ uint32_t s_sum[kScanThreads];
     __shared__ uint32_t s_max[kScanThreads];
     const int tid = threadIdx.x;
@@ -55,44 +55,50 @@ k_tile_scan(const uint32_t *__restrict__ count, const uint32_t *__restrict__ cos
         __syncthreads();
     }
     const uint64_t scale = (uint64_t)s_max[0] + 1u;
-    __syncthreads();
-    s_sum[tid] = 0;
-    __syncthreads();
     uint32_t base = (uint32_t)N >= (uint32_t)kWaveSlots ? 1u : (2u * (uint32_t)N >= (uint32_t)kWaveSlots ? 2u : 4u);
     if (force_base) base = (uint32_t)force_base;
     const uint32_t mean = total / (uint32_t)N + 1u;
     const uint32_t limit = (uint32_t)((uint64_t)mean * (uint32_t)limit_pct / 100u) / base + 1u;   // longest list one item may walk
     (void)maxc;
-    auto nsplit = [&](uint32_t c) -> uint32_t {
-        uint32_t sp = base;
-        while (sp < 4u && c / sp > limit) sp <<= 1;
-        return sp;
-    };
-    auto cls = [&](uint32_t w, uint32_t sp) -> uint32_t {
-        return kScanThreads - 1 - (uint32_t)(((uint64_t)(w / sp) * kScanThreads) / scale);
-    };
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t sp = nsplit(count[i]);
-        atomicAdd(&s_sum[cls(cost[i], sp)], sp);
-    }
-    __syncthreads();
-    const uint32_t mine = s_sum[tid];
-    for (int off = 1; off < kScanThreads; off <<= 1) {
-        uint32_t a = 0;
-        if (tid >= off) a = s_sum[tid - off];
+    // pass 0: work items of the forward (tiles possibly split into quadrant sets) -> order[]
+    // pass 1: plain tiles, costliest first -> lpt[]   (unit order of the backward)
+    for (int pass = 0; pass < 2; ++pass) {
+        auto nsplit = [&](uint32_t c) -> uint32_t {
+            if (pass == 1) return 1u;
+            uint32_t sp = base;
+            while (sp < 4u && c / sp > limit) sp <<= 1;
+            return sp;
+        };
+        auto cls = [&](uint32_t w, uint32_t sp) -> uint32_t {
+            return kScanThreads - 1 - (uint32_t)(((uint64_t)(w / sp) * kScanThreads) / scale);
+        };
         __syncthreads();
-        s_sum[tid] += a;
+        s_sum[tid] = 0;
         __syncthreads();
-    }
-    s_max[tid] = s_sum[tid] - mine;  // exclusive start of class tid
-    if (tid == kScanThreads - 1) header[kHdrNumItems] = s_sum[tid];
-    __syncthreads();
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t sp = nsplit(count[i]);
-        const uint32_t at = atomicAdd(&s_max[cls(cost[i], sp)], sp);
-        if (sp == 1) order[at] = (uint32_t)i | (0xFu << kItemOwnShift);
-        else if (sp == 2) { order[at] = (uint32_t)i | (0x3u << kItemOwnShift); order[at + 1] = (uint32_t)i | (0xCu << kItemOwnShift); }
-        else for (uint32_t q = 0; q < 4; ++q) order[at + q] = (uint32_t)i | ((1u << q) << kItemOwnShift);
+        for (int i = lo; i < hi; ++i) {
+            const uint32_t sp = nsplit(count[i]);
+            atomicAdd(&s_sum[cls(cost[i], sp)], sp);
+        }
+        __syncthreads();
+        const uint32_t mine = s_sum[tid];
+        for (int off = 1; off < kScanThreads; off <<= 1) {
+            uint32_t a = 0;
+            if (tid >= off) a = s_sum[tid - off];
+            __syncthreads();
+            s_sum[tid] += a;
+            __syncthreads();
+        }
+        s_max[tid] = s_sum[tid] - mine;  // exclusive start of class tid
+        if (pass == 0 && tid == kScanThreads - 1) header[kHdrNumItems] = s_sum[tid];
+        __syncthreads();
+        for (int i = lo; i < hi; ++i) {
+            const uint32_t sp = nsplit(count[i]);
+            const uint32_t at = atomicAdd(&s_max[cls(cost[i], sp)], sp);
+            if (pass == 1) lpt[at] = (uint32_t)i;
+            else if (sp == 1) order[at] = (uint32_t)i | (0xFu << kItemOwnShift);
+            else if (sp == 2) { order[at] = (uint32_t)i | (0x3u << kItemOwnShift); order[at + 1] = (uint32_t)i | (0xCu << kItemOwnShift); }
+            else for (uint32_t q = 0; q < 4; ++q) order[at + q] = (uint32_t)i | ((1u << q) << kItemOwnShift);
+        }
     }
 }
 
@@ -102,7 +108,7 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s) {
     prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
                        (const uint32_t *)(geom + L.tile_count), (const uint32_t *)(geom + L.tile_cost), (uint32_t *)(geom + L.tile_start),
-                       (uint32_t *)(geom + L.header), (uint32_t *)(geom + L.tile_order), N,
+                       (uint32_t *)(geom + L.header), (uint32_t *)(geom + L.tile_order), (uint32_t *)(geom + L.tile_lpt), N,
                        getenv("LSR_SPLIT") ? atoi(getenv("LSR_SPLIT")) : 0,
                        getenv("LSR_LIMIT") ? atoi(getenv("LSR_LIMIT")) : 100000);
     prof_end(kStTileScan, s);

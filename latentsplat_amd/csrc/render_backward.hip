@@ -1,20 +1,39 @@
 // render_backward.hip — stage K7: per-pixel back-to-front gradient of the compositing, with the
-// same wave/quadrant decomposition and culling as the forward (lsr_blend.h).
+// same quadrant decomposition and culling as the forward (lsr_blend.h).
 //
 // Per (entry, pixel): recompute alpha with the forward's exact arithmetic, divide it out of the
 // running transmittance, form dL/dalpha from the colour accumulated behind the entry, and emit
 //   dL/d(x,y)_pixel, dL/d(A,B,C) conic, dL/d opacity, dL/d payload (rgb / features), dL/d z.
+// The per-lane arithmetic is branch-free: an invalid (pixel, entry) simply has alpha = G = 0, which
+// leaves the transmittance, the accumulated colour and every gradient sum unchanged.
 // Per (entry, wave): contributions of the wave's 64*PXL pixels are summed with the transposed
 // butterfly of lsr_blend.h (permlane swaps + DPP, no LDS traffic), which leaves the total of
 // gradient slot s in lane 4s; ONE atomic instruction then adds the whole 64-byte gradient record
 // of the (view, Gaussian) (lsr_internal.h GradLayout).
+//
+// Scheduling as in the forward: one 16-wave workgroup per CU; a unit of work is (tile, part) where
+// `part` selects the wave's PXL of the tile's 4 quadrants; units are ordered by the tile work
+// estimate, the first unit of every wave is assigned statically (folded over the sorted list so the
+// 4 waves of a SIMD get a balanced total), the rest comes from a global queue.
 // Spec: SURVEY.md Appendix A.6.
 #include "lsr_blend.h"
 
 namespace lsr {
 
+constexpr int kBwdBins = kWaveSlots / 4;
+constexpr int kBwdCUs = kBwdBins / 4;
+
+__device__ __forceinline__ void wave_lds_fence_bwd() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 struct RenderBwdParams {
     int H, W, gx, T, G, C, has_color;
+    uint32_t num_units;           // V * T * (4 / PXL)
+    const uint32_t *tile_lpt;     // (view*T + tile), costliest first
+    uint32_t *queue;              // work-queue head (zeroed with the gradient workspace)
     const float *views;
     const float4 *geo;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
     int rec_f4;
@@ -28,182 +47,197 @@ struct RenderBwdParams {
 
 __device__ __forceinline__ void atomic_add_f32(float *addr, float v) { unsafeAtomicAdd(addr, v); }
 
-template <int NCHP, int PXL, bool DEPTH_GRAD>
-__global__ void __launch_bounds__(LSR_WAVE)
+template <int NCHP, int PXL, bool DEPTH_GRAD, int WPB>
+__global__ void __launch_bounds__(LSR_WAVE * WPB)
 k_render_bwd(RenderBwdParams p) {
     constexpr int NW = 4 / PXL;
-    __shared__ float4 s_q0[LSR_WAVE];  // x, y, A, B
-    __shared__ float4 s_q1[LSR_WAVE];  // C, o, z, mask bits
-    __shared__ float4 s_q2[LSR_WAVE];  // a2, b2, c2, log2(o)
-    __shared__ float4 s_pay[LSR_WAVE][NCHP / 4];
-    __shared__ uint32_t s_gid[LSR_WAVE];
-
-    const int lane = threadIdx.x;
-    const int tile = blockIdx.x / NW, part = blockIdx.x % NW;
-    const int v = blockIdx.y;
-    const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE;
-    const size_t vG = (size_t)v * p.G;
-    const uint32_t start = p.tile_start[(size_t)v * p.T + tile];
-    const uint32_t own = owned_mask<PXL>(part);
+    extern __shared__ float4 s_dyn[];
+    const int lane = threadIdx.x & (LSR_WAVE - 1);
+    const int wid = threadIdx.x / LSR_WAVE;
+    // per-wave LDS slice: [64] (x,y,A,B) | [64] (C,o,z,gid) | [64][NCHP/4] payload
+    constexpr int SLICE = LSR_WAVE * (2 + NCHP / 4);
+    float4 *s_q0 = s_dyn + (size_t)wid * SLICE, *s_q1 = s_q0 + LSR_WAVE;
+    float4 (*s_pay)[NCHP / 4] = (float4 (*)[NCHP / 4])(s_q1 + LSR_WAVE);
     const int coff = p.has_color ? 3 : 0;
-    const float *vw = p.views + (size_t)v * LSR_VIEW_FLOATS;
     const size_t HW = (size_t)p.H * p.W;
 
-    float pxf[PXL], pyf[PXL], Tr[PXL], Tfin[PXL], bgdot[PXL], ddep[PXL], accd[PXL];
-    float dpix[PXL][NCHP], accum[PXL][NCHP];
-    uint32_t last[PXL];
-    uint32_t maxlast = 0;
-#pragma unroll
-    for (int k = 0; k < PXL; ++k) {
-        const int q = owned_quadrant<PXL>(part, k);
-        const int px = tx0 + 8 * (q & 1) + (lane & 7), py = ty0 + 8 * (q >> 1) + (lane >> 3);
-        pxf[k] = (float)px; pyf[k] = (float)py;
-        const bool inside = px < p.W && py < p.H;
-        const size_t pix = (size_t)py * p.W + px, vp = (size_t)v * HW + pix;
-        Tfin[k] = inside ? p.final_T[vp] : 1.0f;
-        Tr[k] = Tfin[k];
-        last[k] = inside ? p.n_contrib[vp] : 0u;
-        maxlast = max(maxlast, last[k]);
-        float bd = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NCHP; ++c) { dpix[k][c] = 0.0f; accum[k][c] = 0.0f; }
-        if (inside) {
-            if (p.has_color && p.g_color) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    dpix[k][c] = p.g_color[((size_t)v * 3 + c) * HW + pix];
-                    bd = __builtin_fmaf(vw[37 + c], dpix[k][c], bd);
-                }
-            }
-            if (p.g_feat) {
-#pragma unroll
-                for (int c = 0; c < NCHP; ++c)
-                    if (c >= coff && c - coff < p.C) dpix[k][c] = p.g_feat[((size_t)v * p.C + (c - coff)) * HW + pix];
-            }
-            if (p.g_mask) bd -= p.g_mask[vp];  // mask = 1 - T_final
+    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)kBwdCUs);   // 0..15
+    const uint32_t bin = (blockIdx.x % (uint32_t)kBwdCUs) * 4u + (vwave & 3u);
+    const uint32_t j0 = vwave >> 2;
+    bool first = true;
+    for (;;) {
+        uint32_t ui;
+        if (first) {
+            ui = (j0 & 1u) ? (j0 + 1u) * (uint32_t)kBwdBins - 1u - bin : j0 * (uint32_t)kBwdBins + bin;
+            first = false;
+            if (ui >= p.num_units) continue;
+        } else {
+            if (p.num_units <= (uint32_t)kWaveSlots) break;
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(p.queue, 1u);
+            ui = (uint32_t)kWaveSlots + __builtin_amdgcn_readfirstlane(t);
+            if (ui >= p.num_units) break;
         }
-        bgdot[k] = bd;
-        ddep[k] = (DEPTH_GRAD && inside) ? p.g_depth[vp] : 0.0f;
-        accd[k] = 0.0f;
-    }
-    // wave-uniform upper bound of the entries any owned pixel blended
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxlast = max(maxlast, (uint32_t)__shfl_xor((int)maxlast, off));
-    maxlast = __builtin_amdgcn_readfirstlane(maxlast);
-    if (maxlast == 0) return;
+        const uint32_t vt = p.tile_lpt[ui / NW];
+        const int part = (int)(ui % NW);
+        const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
+        const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE;
+        const size_t vG = (size_t)v * p.G;
+        const uint32_t start = p.tile_start[vt];
+        const uint32_t own = owned_mask<PXL>(part);
+        const float *vw = p.views + (size_t)v * LSR_VIEW_FLOATS;
 
-    const float half_w = 0.5f * p.W, half_h = 0.5f * p.H;
-    (void)half_w; (void)half_h;
-    for (int chunk = (int)((maxlast - 1) / LSR_WAVE); chunk >= 0; --chunk) {
-        const uint32_t rel = (uint32_t)chunk * LSR_WAVE + lane;  // 0-based position in the list
-        uint32_t m = 0;
-        if (rel < maxlast) {
-            const uint32_t g = p.point_list[start + rel];
-            const float4 *R = p.geo + (vG + g) * (size_t)p.rec_f4;
-            const float4 a = R[0], b = R[1];
-            m = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own;
-            if (m) {
-                const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
-                s_q0[lane] = a;
-                s_q1[lane] = make_float4(b.x, b.y, b.z, __uint_as_float(m));
-                s_q2[lane] = make_float4(f.a2, f.b2, f.c2, f.l2o);
-                s_gid[lane] = g;
+        float pxf[PXL], pyf[PXL], Tr[PXL], tb[PXL], ddep[PXL], accd[PXL];
+        float dpix[PXL][NCHP], accum[PXL][NCHP];
+        uint32_t last[PXL];
+        uint32_t maxlast = 0;
 #pragma unroll
-                for (int c4 = 0; c4 < NCHP / 4; ++c4) s_pay[lane][c4] = R[2 + c4];
+        for (int k = 0; k < PXL; ++k) {
+            const int q = owned_quadrant<PXL>(part, k);
+            const int px = tx0 + 8 * (q & 1) + (lane & 7), py = ty0 + 8 * (q >> 1) + (lane >> 3);
+            pxf[k] = (float)px; pyf[k] = (float)py;
+            const bool inside = px < p.W && py < p.H;
+            const size_t pix = (size_t)py * p.W + px, vp = (size_t)v * HW + pix;
+            const float Tfin = inside ? p.final_T[vp] : 1.0f;
+            Tr[k] = Tfin;
+            last[k] = inside ? p.n_contrib[vp] : 0u;
+            maxlast = max(maxlast, last[k]);
+            float bd = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCHP; ++c) { dpix[k][c] = 0.0f; accum[k][c] = 0.0f; }
+            if (inside) {
+                if (p.has_color && p.g_color) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        dpix[k][c] = p.g_color[((size_t)v * 3 + c) * HW + pix];
+                        bd = __builtin_fmaf(vw[37 + c], dpix[k][c], bd);
+                    }
+                }
+                if (p.g_feat) {
+#pragma unroll
+                    for (int c = 0; c < NCHP; ++c)
+                        if (c >= coff && c - coff < p.C) dpix[k][c] = p.g_feat[((size_t)v * p.C + (c - coff)) * HW + pix];
+                }
+                if (p.g_mask) bd -= p.g_mask[vp];  // mask = 1 - T_final
             }
+            tb[k] = Tfin * bd;   // T_final * (bg . dL/dcolour - dL/dmask)
+            ddep[k] = (DEPTH_GRAD && inside) ? p.g_depth[vp] : 0.0f;
+            accd[k] = 0.0f;
         }
-        uint64_t todo = __ballot(m != 0);
-        __syncthreads();
+        // wave-uniform upper bound of the entries any owned pixel has to consider
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) maxlast = max(maxlast, (uint32_t)__shfl_xor((int)maxlast, off));
+        maxlast = __builtin_amdgcn_readfirstlane(maxlast);
 
-        while (todo) {
-            const int j = 63 - __builtin_clzll(todo);  // back to front
-            todo &= ~(1ull << j);
-            const float4 a = s_q0[j], b = s_q1[j], f2 = s_q2[j];
-            const uint32_t mj = __builtin_amdgcn_readfirstlane(__float_as_uint(b.w));
-            const uint32_t pos = (uint32_t)chunk * LSR_WAVE + (uint32_t)j + 1u;
-            float pay[NCHP];
+        for (int chunk = maxlast ? (int)((maxlast - 1) / LSR_WAVE) : -1; chunk >= 0; --chunk) {
+            const uint32_t rel = (uint32_t)chunk * LSR_WAVE + lane;  // 0-based position in the list
+            uint32_t m = 0;
+            if (rel < maxlast) {
+                const uint32_t g = p.point_list[start + rel];
+                const float4 *R = p.geo + (vG + g) * (size_t)p.rec_f4;
+                const float4 a = R[0], b = R[1];
+                m = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own;
+                if (m) {
+                    s_q0[lane] = a;
+                    s_q1[lane] = make_float4(b.x, b.y, b.z, __uint_as_float(g));
 #pragma unroll
-            for (int c4 = 0; c4 < NCHP / 4; ++c4) {
-                const float4 t = s_pay[j][c4];
-                pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
-            }
-            const float inv_o = __builtin_amdgcn_rcpf(b.y);
-            float gx = 0.0f, gy = 0.0f, gA = 0.0f, gB = 0.0f, gC = 0.0f, go = 0.0f, gz = 0.0f;
-            float gpay[NCHP];
-#pragma unroll
-            for (int c = 0; c < NCHP; ++c) gpay[c] = 0.0f;
-            bool any_valid = false;
-#pragma unroll
-            for (int k = 0; k < PXL; ++k) {
-                if (!(mj & (1u << owned_quadrant<PXL>(part, k)))) continue;  // wave-uniform
-                const float dx = a.x - pxf[k], dy = a.y - pyf[k];
-                const float ex = blend_exponent(dx, dy, f2.x, f2.y, f2.z, f2.w);
-                const float araw = fast_exp2(ex);
-                const float alpha = fminf(LSR_ALPHA_MAX, araw);
-                const bool valid = (pos <= last[k]) && (ex <= f2.w) && (alpha >= LSR_ALPHA_MIN);
-                if (!valid) continue;
-                any_valid = true;
-                const float one_m = 1.0f - alpha;
-                const float rcp1m = __builtin_amdgcn_rcpf(one_m);
-                const float Tk = Tr[k] * rcp1m;  // transmittance in front of this entry
-                Tr[k] = Tk;
-                const float w = alpha * Tk;
-                float dL_dalpha = 0.0f;
-#pragma unroll
-                for (int c = 0; c < NCHP; ++c) {
-                    const float diff = pay[c] - accum[k][c];
-                    dL_dalpha = __builtin_fmaf(diff, dpix[k][c], dL_dalpha);
-                    accum[k][c] = __builtin_fmaf(alpha, diff, accum[k][c]);
-                    gpay[c] = __builtin_fmaf(w, dpix[k][c], gpay[c]);
-                }
-                if (DEPTH_GRAD) {
-                    const float diff = b.z - accd[k];
-                    dL_dalpha = __builtin_fmaf(diff, ddep[k], dL_dalpha);
-                    accd[k] = __builtin_fmaf(alpha, diff, accd[k]);
-                    gz = __builtin_fmaf(w, ddep[k], gz);
-                }
-                dL_dalpha *= Tk;
-                dL_dalpha = __builtin_fmaf(-Tfin[k] * rcp1m, bgdot[k], dL_dalpha);
-                const float Gv = araw * inv_o;          // exp(power)
-                const float dL_dG = b.y * dL_dalpha;    // straight through the 0.99 clamp (A.6)
-                const float gdx = Gv * dx, gdy = Gv * dy;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * b.x - gdx * a.w;
-                gx = __builtin_fmaf(dL_dG, dG_ddelx, gx);
-                gy = __builtin_fmaf(dL_dG, dG_ddely, gy);
-                gA = __builtin_fmaf(-0.5f * gdx * dx, dL_dG, gA);
-                gB = __builtin_fmaf(-gdx * dy, dL_dG, gB);
-                gC = __builtin_fmaf(-0.5f * gdy * dy, dL_dG, gC);
-                go = __builtin_fmaf(Gv, dL_dalpha, go);
-            }
-            if (!__any(any_valid)) continue;
-            // ---- wave-wide sums, 16 record slots at a time; lane 4s ends up with slot s ----
-            float *rec = p.rec + (size_t)(vG + s_gid[j]) * p.rec_floats;
-            {
-                constexpr uint32_t LIVE = 0x3Fu | (DEPTH_GRAD ? 0x40u : 0u) | (((1u << (NCHP < 8 ? NCHP : 8)) - 1u) << 8);
-                const float v16[16] = {gx, gy, gA, gB, gC, go, DEPTH_GRAD ? gz : 0.0f, 0.0f,
-                                       gpay[0], gpay[1], gpay[2], gpay[3],
-                                       NCHP > 4 ? gpay[4 % NCHP] : 0.0f, NCHP > 4 ? gpay[5 % NCHP] : 0.0f,
-                                       NCHP > 4 ? gpay[6 % NCHP] : 0.0f, NCHP > 4 ? gpay[7 % NCHP] : 0.0f};
-                const float tot = wave_reduce16_transposed<LIVE>(v16, lane);
-                const int slot = lane >> 2;
-                if ((lane & 3) == 0 && (LIVE >> slot & 1u) && (slot < 8 || slot - 8 < coff + p.C))
-                    atomic_add_f32(rec + slot, tot);
-            }
-            if (NCHP > 8) {
-#pragma unroll
-                for (int grp = 1; grp * 16 - 8 < NCHP; ++grp) {   // payload channels 16*grp-8 .. 16*grp+7
-                    float v16[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) v16[i] = (16 * grp - 8 + i) < NCHP ? gpay[(16 * grp - 8 + i) % NCHP] : 0.0f;
-                    const float tot = wave_reduce16_transposed<0xFFFFu>(v16, lane);
-                    const int ch = 16 * grp - 8 + (lane >> 2);
-                    if ((lane & 3) == 0 && ch < coff + p.C) atomic_add_f32(rec + 8 + ch, tot);
+                    for (int c4 = 0; c4 < NCHP / 4; ++c4) s_pay[lane][c4] = R[2 + c4];
                 }
             }
+            uint64_t qbits[PXL];
+#pragma unroll
+            for (int k = 0; k < PXL; ++k) qbits[k] = __ballot((m >> owned_quadrant<PXL>(part, k)) & 1u);
+            uint64_t todo = __ballot(m != 0);
+            wave_lds_fence_bwd();
+
+            while (todo) {
+                const int j = 63 - __builtin_clzll(todo);  // back to front
+                todo &= ~(1ull << j);
+                const float4 a = s_q0[j], b = s_q1[j];
+                const uint32_t pos = (uint32_t)chunk * LSR_WAVE + (uint32_t)j + 1u;
+                float pay[NCHP];
+#pragma unroll
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) {
+                    const float4 t = s_pay[j][c4];
+                    pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
+                }
+                const FoldedConic f2 = fold_conic(a.z, a.w, b.x, b.y);   // same folding as the forward
+                const float inv_o = __builtin_amdgcn_rcpf(b.y);
+                // sums over this wave's pixels (sign / 0.5 factors applied once, after the pixel loop)
+                float sx = 0.0f, sy = 0.0f, sA = 0.0f, sB = 0.0f, sC = 0.0f, go = 0.0f, gz = 0.0f;
+                float gpay[NCHP];
+#pragma unroll
+                for (int c = 0; c < NCHP; ++c) gpay[c] = 0.0f;
+                uint64_t any_valid = 0;
+#pragma unroll
+                for (int k = 0; k < PXL; ++k) {
+                    if (!(qbits[k] >> j & 1ull)) continue;  // wave-uniform
+                    const float dx = a.x - pxf[k], dy = a.y - pyf[k];
+                    const float ex = blend_exponent(dx, dy, f2.a2, f2.b2, f2.c2, f2.l2o);
+                    const float araw = fast_exp2(ex);
+                    const float aclamp = fminf(LSR_ALPHA_MAX, araw);
+                    const uint64_t valid = __ballot(pos <= last[k]) & __ballot(ex <= f2.l2o) & __ballot(aclamp >= LSR_ALPHA_MIN);
+                    any_valid |= valid;
+                    const bool vb = __builtin_amdgcn_inverse_ballot_w64(valid);
+                    const float alpha = vb ? aclamp : 0.0f;
+                    const float Gv = vb ? araw * inv_o : 0.0f;      // exp(power)
+                    const float rcp1m = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    const float Tk = Tr[k] * rcp1m;  // transmittance in front of this entry
+                    Tr[k] = Tk;
+                    const float w = alpha * Tk;
+                    float dL_dalpha = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < NCHP; ++c) {
+                        const float diff = pay[c] - accum[k][c];
+                        dL_dalpha = __builtin_fmaf(diff, dpix[k][c], dL_dalpha);
+                        accum[k][c] = __builtin_fmaf(alpha, diff, accum[k][c]);
+                        gpay[c] = __builtin_fmaf(w, dpix[k][c], gpay[c]);
+                    }
+                    if (DEPTH_GRAD) {
+                        const float diff = b.z - accd[k];
+                        dL_dalpha = __builtin_fmaf(diff, ddep[k], dL_dalpha);
+                        accd[k] = __builtin_fmaf(alpha, diff, accd[k]);
+                        gz = __builtin_fmaf(w, ddep[k], gz);
+                    }
+                    dL_dalpha = __builtin_fmaf(dL_dalpha, Tk, -tb[k] * rcp1m);
+                    const float dL_dG = b.y * dL_dalpha;    // straight through the 0.99 clamp (A.6)
+                    const float tA = Gv * dx * dL_dG, tC = Gv * dy * dL_dG;
+                    sx = __builtin_fmaf(tA, a.z, __builtin_fmaf(tC, a.w, sx));     // -(dL/dx)
+                    sy = __builtin_fmaf(tC, b.x, __builtin_fmaf(tA, a.w, sy));     // -(dL/dy)
+                    sA = __builtin_fmaf(tA, dx, sA);                               // -2 dL/dA
+                    sB = __builtin_fmaf(tA, dy, sB);                               // -  dL/dB
+                    sC = __builtin_fmaf(tC, dy, sC);                               // -2 dL/dC
+                    go = __builtin_fmaf(Gv, dL_dalpha, go);
+                }
+                if (!any_valid) continue;
+                // ---- wave-wide sums, 16 record slots at a time; lane 4s ends up with slot s ----
+                float *rec = p.rec + (size_t)(vG + __float_as_uint(b.w)) * p.rec_floats;
+                {
+                    constexpr uint32_t LIVE = 0x3Fu | (DEPTH_GRAD ? 0x40u : 0u) | (((1u << (NCHP < 8 ? NCHP : 8)) - 1u) << 8);
+                    const float v16[16] = {-sx, -sy, -0.5f * sA, -sB, -0.5f * sC, go, DEPTH_GRAD ? gz : 0.0f, 0.0f,
+                                           gpay[0], gpay[1], gpay[2], gpay[3],
+                                           NCHP > 4 ? gpay[4 % NCHP] : 0.0f, NCHP > 4 ? gpay[5 % NCHP] : 0.0f,
+                                           NCHP > 4 ? gpay[6 % NCHP] : 0.0f, NCHP > 4 ? gpay[7 % NCHP] : 0.0f};
+                    const float tot = wave_reduce16_transposed<LIVE>(v16, lane);
+                    const int slot = lane >> 2;
+                    if ((lane & 3) == 0 && (LIVE >> slot & 1u) && (slot < 8 || slot - 8 < coff + p.C))
+                        atomic_add_f32(rec + slot, tot);
+                }
+                if (NCHP > 8) {
+#pragma unroll
+                    for (int grp = 1; grp * 16 - 8 < NCHP; ++grp) {   // payload channels 16*grp-8 .. 16*grp+7
+                        float v16[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v16[i] = (16 * grp - 8 + i) < NCHP ? gpay[(16 * grp - 8 + i) % NCHP] : 0.0f;
+                        const float tot = wave_reduce16_transposed<0xFFFFu>(v16, lane);
+                        const int ch = 16 * grp - 8 + (lane >> 2);
+                        if ((lane & 3) == 0 && ch < coff + p.C) atomic_add_f32(rec + 8 + ch, tot);
+                    }
+                }
+            }
+            wave_lds_fence_bwd();
         }
-        __syncthreads();
-    }
+    }  // unit loop
 }
 
 static int pick_pxl_bwd(int nchp, int64_t tiles_total) {
@@ -216,6 +250,17 @@ static int pick_pxl_bwd(int nchp, int64_t tiles_total) {
     if (nchp > 4 && pxl == 4) pxl = 2;  // dpix + accum double the per-pixel register cost
     if (nchp > 12) pxl = 1;
     return pxl;
+}
+
+template <int NCHP, int PXL, bool DG, int WPB>
+static void launch_variant(const RenderBwdParams &p, hipStream_t s) {
+    const size_t shm = (size_t)WPB * LSR_WAVE * (2 + NCHP / 4) * sizeof(float4);
+    static bool attr_set = false;
+    if (!attr_set && shm > 65536) {
+        (void)hipFuncSetAttribute((const void *)k_render_bwd<NCHP, PXL, DG, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_render_bwd<NCHP, PXL, DG, WPB>), dim3(kBwdCUs * (16 / WPB)), dim3(LSR_WAVE * WPB), shm, s, p);
 }
 
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
@@ -232,26 +277,28 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     p.views = in.views;
     p.geo = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
     p.tile_start = (const uint32_t *)(geom + L.tile_start);
+    p.tile_lpt = (const uint32_t *)(geom + L.tile_lpt);
     p.point_list = (const uint32_t *)(bin + B.point_list);
     p.final_T = (const float *)(img + I.final_T); p.n_contrib = (const uint32_t *)(img + I.n_contrib);
     p.g_color = gout.color; p.g_feat = gout.feature; p.g_mask = gout.mask; p.g_depth = gout.depth;
     p.rec = (float *)(grad + R.rec); p.rec_floats = R.rec_floats;
+    p.queue = (uint32_t *)(grad + R.total - 256);   // inside the zeroed tail of the gradient workspace
     (void)gin;
     const int nch = (p.has_color ? 3 : 0) + d.feat_channels;
     const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));
     const int pxl = pick_pxl_bwd(nchp, (int64_t)p.T * d.num_views);
+    p.num_units = (uint32_t)((int64_t)p.T * d.num_views * (4 / pxl));
     const bool dg = gout.depth != nullptr;
-    dim3 grid(p.T * (4 / pxl), d.num_views);
-#define LSR_RB(N, X)                                                                              \
-    do {                                                                                          \
-        if (dg) hipLaunchKernelGGL((k_render_bwd<N, X, true>), grid, dim3(LSR_WAVE), 0, s, p);    \
-        else hipLaunchKernelGGL((k_render_bwd<N, X, false>), grid, dim3(LSR_WAVE), 0, s, p);      \
-    } while (0)
     prof_begin(kStRenderBwd, s);
-    if (nchp == 4) { if (pxl == 4) LSR_RB(4, 4); else if (pxl == 2) LSR_RB(4, 2); else LSR_RB(4, 1); }
-    else if (nchp == 8) { if (pxl == 2) LSR_RB(8, 2); else LSR_RB(8, 1); }
-    else if (nchp == 12) { if (pxl == 2) LSR_RB(12, 2); else LSR_RB(12, 1); }
-    else LSR_RB(36, 1);
+#define LSR_RB(N, X, W)                                             \
+    do {                                                            \
+        if (dg) launch_variant<N, X, true, W>(p, s);                \
+        else launch_variant<N, X, false, W>(p, s);                  \
+    } while (0)
+    if (nchp == 4) { if (pxl == 4) LSR_RB(4, 4, 16); else if (pxl == 2) LSR_RB(4, 2, 16); else LSR_RB(4, 1, 16); }
+    else if (nchp == 8) { if (pxl == 2) LSR_RB(8, 2, 16); else LSR_RB(8, 1, 16); }
+    else if (nchp == 12) { if (pxl == 2) LSR_RB(12, 2, 16); else LSR_RB(12, 1, 16); }
+    else LSR_RB(36, 1, 4);
 #undef LSR_RB
     prof_end(kStRenderBwd, s);
     return hipGetLastError();
