@@ -33,6 +33,7 @@ k_preprocess_bwd(PreBwdParams p) {
     const int ce = d.cov_elems;
     float am[3] = {0, 0, 0}, ac[6] = {0, 0, 0, 0, 0, 0}, aop = 0.0f;  // accumulators for shared inputs
     const int coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
+#pragma unroll 4
     for (int v = 0; v < V; ++v) {
         const size_t o = (size_t)v * G + i;
         const float *rc = p.rec + o * p.rec_floats;

@@ -31,21 +31,18 @@ struct ShParams {
     int group;                // 0 = colour (G,K,3), 1 = features (G,C,Kf)
 };
 
-__device__ __forceinline__ int padded_stride(int ks) { return ks | 1; }   // odd => conflict-free
+__device__ __forceinline__ int padded_stride(int ks) { return ks; }   // rows are staged unpadded (see stage_in)
 
-// Stage `n` = 64*ks floats (fewer at the tail) into LDS rows of odd stride.
+// Stage `rows`*ks floats (a contiguous, 16-byte aligned run: 64 Gaussians x ks coefficients) into
+// LDS unchanged, with lane-contiguous 16-byte loads.  Lane l later reads its row at word stride
+// ks: conflict-free when ks is odd (colour: 3*K with K = 1,9,25 ...), a few-way conflict otherwise.
 __device__ __forceinline__ void stage_in(float *lds, const float *src, int ks, int rows, int lane) {
-    const int ps = padded_stride(ks), n = rows * ks;
-    for (int t = lane; t < n; t += LSR_WAVE) lds[(t / ks) * ps + (t % ks)] = src[t];
+    const int n = rows * ks, n4 = n >> 2;
+    const float4 *src4 = (const float4 *)src;
+    float4 *lds4 = (float4 *)lds;
+    for (int t = lane; t < n4; t += LSR_WAVE) lds4[t] = src4[t];
+    for (int t = (n4 << 2) + lane; t < n; t += LSR_WAVE) lds[t] = src[t];
 }
-__device__ __forceinline__ void stage_out(float *dst, const float *lds, int ks, int rows, int lane, bool accumulate) {
-    const int ps = padded_stride(ks), n = rows * ks;
-    for (int t = lane; t < n; t += LSR_WAVE) {
-        const float v = lds[(t / ks) * ps + (t % ks)];
-        dst[t] = accumulate ? dst[t] + v : v;
-    }
-}
-
 // coefficient (k, c) of this lane's Gaussian inside its LDS row
 __device__ __forceinline__ int coef_index(bool channel_major, int k, int c, int K) { return channel_major ? c * K + k : 3 * k + c; }
 
@@ -247,7 +244,7 @@ hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom
         p.d = d; p.in = in; p.binrec = (const BinRec *)(geom + L.bin);
         p.rec = (float *)(geom + L.rec); p.grec = nullptr; p.RF = L.rec_floats; p.g = lsr_in_grads{}; p.group = group;
         const int ks = group == 0 ? d.sh_coeffs * 3 : d.feat_sh_coeffs * d.feat_channels;
-        const size_t shm = (size_t)LSR_WAVE * (ks | 1) * 4;
+        const size_t shm = (size_t)LSR_WAVE * ks * 4 + 16;
         hipLaunchKernelGGL((k_sh<false>), dim3((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), dim3(LSR_WAVE), shm, s, p);
     }
     prof_end(kStShFwd, s);
@@ -270,7 +267,7 @@ hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const cha
         const int ks = group == 0 ? d.sh_coeffs * 3 : d.feat_sh_coeffs * d.feat_channels;
         const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), block(LSR_WAVE);
         // (1) direction -> mean gradient (needs the coefficients, staged through LDS)
-        hipLaunchKernelGGL((k_sh<true>), grid, block, (size_t)LSR_WAVE * (ks | 1) * 4, s, p);
+        hipLaunchKernelGGL((k_sh<true>), grid, block, (size_t)LSR_WAVE * ks * 4 + 16, s, p);
         // (2) coefficient gradients
         const size_t shm = (size_t)kShViewChunk * LSR_WAVE * (kShBasisStride + (nch | 1)) * 4;
         hipLaunchKernelGGL(k_sh_coef_backward, grid, dim3(256), shm, s, p);

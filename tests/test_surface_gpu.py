@@ -322,3 +322,34 @@ def test_device_camera_table_matches_host_math(hip_device):
     got1 = build_view_table(sc.extrinsics.to(hip_device), intr.to(hip_device), near.to(hip_device), far.to(hip_device),
                             bg[0].to(hip_device), True).cpu()
     assert torch.equal(got1[:, 37:40], bg[0][None].expand(7, 3))
+
+
+def test_large_image_uses_global_histogram_paths(hip_device):
+    """More than 4096 / 8192 tiles: the LDS-privatised tile histograms of k_preprocess / k_scatter
+    fall back to global atomics; results must not change."""
+    for H, W in ((1040, 1024), (1552, 1408)):       # 65*64 = 4160 tiles, 97*88 = 8536 tiles
+        sc = util.make_scene(1500, image_size=max(H, W), views=1, color_sh_degree=1, feature_channels=4,
+                             sigma_px=(2.0, 40.0), opacity_scale=1.0)
+        bi = util.boundary_inputs(sc, H, W, bg=(0.1, 0.2, 0.3))
+        run = util.HipRun(bi, hip_device)
+        o = util.oracle_forward(bi, 0)
+        np.testing.assert_array_equal(run.radii[0].cpu().numpy(), o["radii"])
+        ts = run.tile_start()
+        np.testing.assert_array_equal(np.diff(ts), o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0])
+        np.testing.assert_array_equal(run.point_list()[:o["P"]], o["point_list"])
+        util.assert_close_except_fragile(run.color_out[0].cpu().numpy(), o["color"], o, 1e-4, "colour")
+        util.assert_close_except_fragile(run.feat_out[0].cpu().numpy(), o["feature"], o, 1e-4, "feature")
+
+
+def test_single_gaussian_and_single_pixel_images(hip_device):
+    from latentsplat_amd.rasterizer import rasterize_views
+    dev = hip_device
+    sc = util.make_scene(1, image_size=16, views=1, color_sh_degree=0, feature_channels=4, sigma_px=(2.0, 2.0), opacity_scale=3.0)
+    sc.means[:] = torch.tensor([[0.0, 0.0, 2.0]])
+    for H, W in ((16, 16), (1, 1), (3, 40)):
+        bi = util.boundary_inputs(sc, H, W)
+        run = util.HipRun(bi, dev)
+        o = util.oracle_forward(bi, 0)
+        np.testing.assert_array_equal(run.radii[0].cpu().numpy(), o["radii"])
+        np.testing.assert_allclose(run.feat_out[0].cpu().numpy(), o["feature"], atol=1e-4)
+        np.testing.assert_allclose(run.mask_out[0].cpu().numpy(), o["mask"], atol=1e-4)
