@@ -36,6 +36,8 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
 struct RenderFwdParams {
     int H, W, gx, T, G, C, has_color;
     const uint32_t *items;        // work items, costliest first
@@ -192,8 +194,9 @@ k_render_fwd(RenderFwdParams p) {
                         const float w = __builtin_amdgcn_inverse_ballot_w64(blend) ? aT : 0.0f;
 #pragma unroll
                         for (int c = 0; c < NCHP; ++c) acc[k][c] = __builtin_fmaf(pay[u][c], w, acc[k][c]);
-                        accd[k] = __builtin_fmaf(b[u].z, w, accd[k]);
-                        Tr[k] -= w;
+                        // (accd, T) += w * (z, -1) as one packed FMA
+                        const float2_t td = __builtin_elementwise_fma(float2_t{b[u].z, -1.0f}, float2_t{w, w}, float2_t{accd[k], Tr[k]});
+                        accd[k] = td.x; Tr[k] = td.y;
                         if (stop) {  // rare, wave-uniform: a pixel's transmittance ran out here
                             const uint32_t pos = base - start + (uint32_t)jj[u] + 1u;
                             stop_pos[k] = __builtin_amdgcn_inverse_ballot_w64(stop) ? pos : stop_pos[k];
