@@ -139,6 +139,58 @@ def decoder_step_timing(dev, steps=10):
     return res
 
 
+def adapter_step_timing(dev, steps=20):
+    """the Gaussian adapter tail at the configs[3] shape (2 context cameras x 256^2
+    rays x 3 depth samples = 393 216 Gaussians), raw parameters read as a strided view of the
+    encoder's 156-float Linear output.  HBM roofline of the two kernels from their algorithmic
+    bytes (inputs read once, outputs written once) and the hipEvent times inside the library."""
+    from latentsplat_amd import _lib
+    from latentsplat_amd.gaussian_adapter import adapter_geometry
+    cams, rays, S, width = 2, 65536, 3, 156
+    g = torch.Generator(device="cpu").manual_seed(99)
+    E = torch.eye(4).repeat(cams, 1, 1)
+    E[:, :3, 3] = torch.randn(cams, 3, generator=g)
+    K = torch.tensor([[0.8, 0, 0.5], [0, 0.8, 0.5], [0, 0, 1.0]]).repeat(cams, 1, 1)
+    coords = torch.rand(cams, rays, 2, generator=g).to(dev).requires_grad_()
+    depths = (0.5 + 20 * torch.rand(cams, rays, S, generator=g)).to(dev).requires_grad_()
+    full = torch.randn(cams, rays, width, generator=g).to(dev).requires_grad_()
+    E, K = E.to(dev), K.to(dev)
+    gm = torch.randn(cams, rays, S, 3, device=dev)
+    gc = torch.randn(cams, rays, S, 6, device=dev)
+
+    def fwd():
+        with torch.no_grad():
+            adapter_geometry(E, K, coords, depths, full[..., 2:], (256, 256), 0.5, 15.0, packed_covariance=True)
+
+    def fwdbwd():
+        m, c, _, _ = adapter_geometry(E, K, coords, depths, full[..., 2:], (256, 256), 0.5, 15.0, packed_covariance=True)
+        torch.autograd.backward([m, c], [gm, gc])
+        coords.grad = depths.grad = full.grad = None
+
+    res = {}
+    for name, fn in (("forward", fwd), ("forward_backward", fwdbwd)):
+        el = timed_region(fn, steps, 3, None, lambda: torch.cuda.synchronize(dev))
+        res[name] = dict(ms_per_step=1e3 * el / steps)
+    _lib.profile_read()
+    _lib.profile_enable(True)
+    for _ in range(5):
+        fwdbwd()
+    torch.cuda.synchronize(dev)
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+    rows = cams * rays
+    # 64-byte lines actually touched for the 7 strided raw floats: 28 B straddle <= 2 lines
+    bytes_fwd = rows * (4 * (7 + 2 + S) + 4 * (S * (3 + 6 + 3) + 4))
+    bytes_bwd = rows * (4 * (7 + 2 + S) + 4 * S * (3 + 6) + 4 * (2 + S + 7))
+    for key, nbytes in (("adapter_forward", bytes_fwd), ("adapter_backward", bytes_bwd)):
+        ms, n = prof.get(key, (0.0, 0))
+        if n:
+            res[key] = dict(kernel_ms=ms / n, algorithmic_bytes=nbytes, achieved_GBs=nbytes / (ms / n * 1e-3) / 1e9,
+                            frac=nbytes / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS)
+    res["config"] = "configs[3] shape: 2 context cameras x 65536 rays x 3 samples = 393216 Gaussians, packed cov6, raw row stride 156 floats"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,11 +297,12 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(G, S, 1234)
-    dec_step = None
+    dec_step = adapter_step = None
     if rank == 0 and world == 1 and not args.no_bwd:
         del inp
         torch.cuda.empty_cache()
         dec_step = decoder_step_timing(dev)
+        adapter_step = adapter_step_timing(dev)
 
     if rank == 0:
         line = {
@@ -263,7 +316,7 @@ def main():
                        "parallelism": f"replicas x{world} (one scene per rank, no data-path collective)"},
             "ms_per_view_fwd": 1e3 * el_fwd / (V * args.steps),
             "kernel_ms_per_launch": {k: (ms / n if n else None) for k, (ms, n) in prof.items()},
-            "fwdbwd": fb, "decoder_step": dec_step, "roofline": roofline, "roofline_path": path, "cpu_baseline": cpu,
+            "fwdbwd": fb, "decoder_step": dec_step, "adapter_step": adapter_step, "roofline": roofline, "roofline_path": path, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if dist is not None:

@@ -1,4 +1,4 @@
-"""ctypes binding of ``liblsr_hip.so`` (C ABI: include/lsr_rasterizer.h).
+"""ctypes binding of ``liblsr_hip.so`` (C ABI: include/lsr_rasterizer.h, include/lsr_adapter.h).
 
 The library is built in-tree by ``latentsplat_amd/csrc/Makefile`` (``__graft_entry__.build()``).
 There is no CPU fallback: if the shared object is missing or not loadable this module raises, and
@@ -61,11 +61,35 @@ class Layout(C.Structure):
                  "geom_header", "bin_keys", "bin_point_list", "img_final_T", "img_n_contrib")]
 
 
+class AdapterDims(C.Structure):      # lsr_adapter_dims (include/lsr_adapter.h)
+    _fields_ = [("num_cameras", C.c_int32), ("rays", C.c_int32), ("samples", C.c_int32),
+                ("height", C.c_int32), ("width", C.c_int32), ("cov_elems", C.c_int32),
+                ("scale_min", C.c_float), ("scale_max", C.c_float), ("eps", C.c_float),
+                ("raw_stride", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32)]
+
+
+class AdapterInputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("extrinsics", "intrinsics", "coordinates", "depths", "raw")]
+
+
+class AdapterOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("means", "covariances", "scales", "rotations")]
+
+
+class AdapterOutGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("means", "covariances", "scales", "rotations")]
+
+
+class AdapterInGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("coordinates", "depths", "raw")]
+
+
 EXPORTS = (
     "lsr_abi_version", "lsr_error_string", "lsr_last_hip_error", "lsr_geom_workspace_bytes",
     "lsr_image_workspace_bytes", "lsr_binning_workspace_bytes", "lsr_grad_workspace_bytes",
     "lsr_get_layout", "lsr_build_views", "lsr_forward_prepare", "lsr_forward_render", "lsr_backward",
     "lsr_profile_enable", "lsr_profile_num_stages", "lsr_profile_stage_name", "lsr_profile_read",
+    "lsr_adapter_forward", "lsr_adapter_backward",
 )
 
 _lib = None
@@ -122,6 +146,12 @@ def load():
     lib.lsr_profile_stage_name.restype = C.c_char_p
     lib.lsr_profile_stage_name.argtypes = [C.c_int]
     lib.lsr_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(I64)]
+    lib.lsr_adapter_forward.restype = C.c_int
+    lib.lsr_adapter_forward.argtypes = [C.POINTER(AdapterDims), C.POINTER(AdapterInputs),
+                                        C.POINTER(AdapterOutputs), P]
+    lib.lsr_adapter_backward.restype = C.c_int
+    lib.lsr_adapter_backward.argtypes = [C.POINTER(AdapterDims), C.POINTER(AdapterInputs),
+                                         C.POINTER(AdapterOutGrads), C.POINTER(AdapterInGrads), P]
     if lib.lsr_abi_version() != 2:
         raise LsrError("liblsr_hip.so ABI version mismatch; rebuild it")
     _lib = lib

@@ -45,6 +45,8 @@ void lsr::prof_end(int stage, hipStream_t s) {
 }
 
 
+void lsr::note_hip_error(int e) { g_last_hip_error = e; }
+
 static int fail_hip(hipError_t e) {
     g_last_hip_error = (int)e;
     return LSR_ELAUNCH;
@@ -122,7 +124,7 @@ int lsr_profile_num_stages(void) { return lsr::kNumStages; }
 const char *lsr_profile_stage_name(int stage) {
     static const char *names[lsr::kNumStages] = {"preprocess", "tile_scan", "scatter", "sort_tiles",
                                                   "render_forward", "render_backward", "preprocess_backward",
-                                                  "sh_forward", "sh_backward"};
+                                                  "sh_forward", "sh_backward", "adapter_forward", "adapter_backward"};
     return (stage >= 0 && stage < lsr::kNumStages) ? names[stage] : "?";
 }
 int lsr_profile_read(double *ms_out, int64_t *launches_out) {

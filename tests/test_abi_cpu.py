@@ -13,7 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    text = open(os.path.join(ROOT, "include", "lsr_rasterizer.h")).read()
+    text = ""
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        text += open(os.path.join(ROOT, "include", h)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(lsr_[a-z_0-9]+)\s*\(", text)))
 
