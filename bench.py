@@ -191,6 +191,51 @@ def adapter_step_timing(dev, steps=20):
     return res
 
 
+def latent_step_timing(dev, steps=20):
+    """posterior sample + antialiased 1/8 rescale + skip concatenation for one
+    per-GPU batch of BASELINE configs[4] (16 views x 4 latent channels x 256^2, RGB skip)."""
+    from latentsplat_amd import _lib
+    from latentsplat_amd.decoder.latent_epilogue import sample_rescale_skip
+    b, v, C, S, f = 4, 4, 4, 256, 8
+    feats = torch.randn(b, v, C, S, S, device=dev).requires_grad_()
+    mask = torch.rand(b, v, S, S, device=dev)
+    color = torch.rand(b, v, 3, S, S, device=dev)
+    noise = torch.randn(b, v, C, S, S, device=dev)
+    gz = torch.randn(b, v, C, S // f, S // f, device=dev)
+    gs = torch.randn(b, v, 3 + C, S, S, device=dev)
+
+    def fwd():
+        with torch.no_grad():
+            sample_rescale_skip(feats, mask, color, f, noise=noise)
+
+    def fwdbwd():
+        ep = sample_rescale_skip(feats, mask, color, f, noise=noise)
+        torch.autograd.backward([ep.z, ep.skip_z], [gz, gs])
+        feats.grad = None
+
+    res = {}
+    for name, fn in (("forward", fwd), ("forward_backward", fwdbwd)):
+        el = timed_region(fn, steps, 3, None, lambda: torch.cuda.synchronize(dev))
+        res[name] = dict(ms_per_step=1e3 * el / steps)
+    _lib.profile_read()
+    _lib.profile_enable(True)
+    for _ in range(5):
+        fwdbwd()
+    torch.cuda.synchronize(dev)
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+    V, px = b * v, S * S
+    bytes_fwd = 4 * V * (px * (C + 1 + C + 3) + px * (3 + C) + px + C * px // (f * f))     # in: feat, mask, noise, colour; out: skip, logvar, z
+    bytes_bwd = 4 * V * (px * C + C * px // (f * f) + px * C)                               # in: g_skip latent part, g_z; out: d_features
+    for key, nbytes in (("latent_forward", bytes_fwd), ("latent_backward", bytes_bwd)):
+        ms, n = prof.get(key, (0.0, 0))
+        if n:
+            res[key] = dict(kernel_ms=ms / n, algorithmic_bytes=nbytes, achieved_GBs=nbytes / (ms / n * 1e-3) / 1e9,
+                            frac=nbytes / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS)
+    res["config"] = "configs[4] per-GPU batch: 16 views x 4 latent channels x 256x256, factor 8, RGB skip"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,12 +342,13 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(G, S, 1234)
-    dec_step = adapter_step = None
+    dec_step = adapter_step = latent_step = None
     if rank == 0 and world == 1 and not args.no_bwd:
         del inp
         torch.cuda.empty_cache()
         dec_step = decoder_step_timing(dev)
         adapter_step = adapter_step_timing(dev)
+        latent_step = latent_step_timing(dev)
 
     if rank == 0:
         line = {
@@ -316,7 +362,7 @@ def main():
                        "parallelism": f"replicas x{world} (one scene per rank, no data-path collective)"},
             "ms_per_view_fwd": 1e3 * el_fwd / (V * args.steps),
             "kernel_ms_per_launch": {k: (ms / n if n else None) for k, (ms, n) in prof.items()},
-            "fwdbwd": fb, "decoder_step": dec_step, "adapter_step": adapter_step, "roofline": roofline, "roofline_path": path, "cpu_baseline": cpu,
+            "fwdbwd": fb, "decoder_step": dec_step, "adapter_step": adapter_step, "latent_step": latent_step, "roofline": roofline, "roofline_path": path, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if dist is not None:

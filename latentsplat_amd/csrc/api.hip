@@ -124,7 +124,7 @@ int lsr_profile_num_stages(void) { return lsr::kNumStages; }
 const char *lsr_profile_stage_name(int stage) {
     static const char *names[lsr::kNumStages] = {"preprocess", "tile_scan", "scatter", "sort_tiles",
                                                   "render_forward", "render_backward", "preprocess_backward",
-                                                  "sh_forward", "sh_backward", "adapter_forward", "adapter_backward"};
+                                                  "sh_forward", "sh_backward", "adapter_forward", "adapter_backward", "latent_forward", "latent_backward"};
     return (stage >= 0 && stage < lsr::kNumStages) ? names[stage] : "?";
 }
 int lsr_profile_read(double *ms_out, int64_t *launches_out) {

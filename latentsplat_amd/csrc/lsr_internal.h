@@ -126,7 +126,7 @@ constexpr int kWaveSlots = 256 * 4 * 4;   // CUs x SIMDs x resident compositing 
 enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrQueueFwd = 2, kHdrNumItems = 3 };
 
 // ---- optional per-stage hipEvent timing (api.hip); no-ops unless lsr_profile_enable(1) ----
-enum Stage { kStPreprocess = 0, kStTileScan, kStScatter, kStSort, kStRenderFwd, kStRenderBwd, kStPreprocessBwd, kStShFwd, kStShBwd, kStAdapterFwd, kStAdapterBwd, kNumStages };
+enum Stage { kStPreprocess = 0, kStTileScan, kStScatter, kStSort, kStRenderFwd, kStRenderBwd, kStPreprocessBwd, kStShFwd, kStShBwd, kStAdapterFwd, kStAdapterBwd, kStLatentFwd, kStLatentBwd, kNumStages };
 void prof_begin(int stage, hipStream_t s);
 void prof_end(int stage, hipStream_t s);
 void note_hip_error(int hip_error);   // what lsr_last_hip_error() returns for this thread
