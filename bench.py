@@ -70,6 +70,47 @@ def cpu_baseline(G, size, seed, budget_s=12.0):
                        f"(oracle/raster_oracle.c, gcc -O2 -fopenmp, {os.cpu_count()} threads)")
 
 
+def cpu_baseline_next_rows(budget_s=4.0):
+    """cpu_baseline leg for the §8(f) rows: the torch-CPU oracles (= the reference's own op chains,
+    oracle/adapter_oracle.py and oracle/latent_oracle.py) on the host cores, same shapes as
+    adapter_step / latent_step, forward + backward."""
+    from oracle import adapter_oracle as ao
+    from oracle import latent_oracle as lo
+    torch.set_num_threads(os.cpu_count())
+    g = torch.Generator().manual_seed(99)
+    cams, rays, S = 2, 65536, 3
+    E = torch.eye(4).repeat(cams, 1, 1)
+    K = torch.tensor([[0.8, 0, 0.5], [0, 0.8, 0.5], [0, 0, 1.0]]).repeat(cams, 1, 1)
+    coords = torch.rand(cams, rays, 2, generator=g).requires_grad_()
+    depths = (0.5 + 20 * torch.rand(cams, rays, S, generator=g)).requires_grad_()
+    rs = torch.randn(cams, rays, 3, generator=g).requires_grad_()
+    rq = torch.randn(cams, rays, 4, generator=g).requires_grad_()
+
+    def adapter():
+        m, c, _, _ = ao.adapter_geometry(E, K, coords, depths, rs, rq, (256, 256), 0.5, 15.0)
+        (m.sum() + c.sum()).backward()
+
+    b, v, C, Sz = 4, 4, 4, 256
+    feats = torch.randn(b, v, C, Sz, Sz, generator=g).requires_grad_()
+    mask, color = torch.rand(b, v, Sz, Sz, generator=g), torch.rand(b, v, 3, Sz, Sz, generator=g)
+    noise = torch.randn(b, v, C, Sz, Sz, generator=g)
+
+    def latent():
+        o = lo.latent_epilogue(feats, mask, noise, color, 8)
+        (o["z"].sum() + o["skip"].sum()).backward()
+
+    res = {}
+    for name, fn in (("adapter", adapter), ("latent", latent)):
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s and n < 50:
+            fn()
+            n += 1
+        res[name] = dict(ms_per_step=1e3 * (time.perf_counter() - t0) / n, cores=os.cpu_count(), kind="port",
+                         sample=f"{n} forward+backward passes of the torch-CPU oracle at the same shape")
+    return res
+
+
 def timed_region(step, steps, warmup, dist=None, device_sync=lambda: None, reduce_device="cpu"):
     """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + device sync on
     both sides; returns the MAX elapsed seconds over ranks (every rank gets the same number)."""
@@ -349,6 +390,9 @@ def main():
         dec_step = decoder_step_timing(dev)
         adapter_step = adapter_step_timing(dev)
         latent_step = latent_step_timing(dev)
+        if not args.no_cpu_baseline:
+            nxt = cpu_baseline_next_rows()
+            adapter_step["cpu_baseline"], latent_step["cpu_baseline"] = nxt["adapter"], nxt["latent"]
 
     if rank == 0:
         line = {
