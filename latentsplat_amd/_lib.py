@@ -1,4 +1,4 @@
-"""ctypes binding of ``liblsr_hip.so`` (C ABI: include/lsr_rasterizer.h, include/lsr_adapter.h, include/lsr_latent.h).
+"""ctypes binding of ``liblsr_hip.so`` (C ABI: include/lsr_rasterizer.h, include/lsr_adapter.h, include/lsr_latent.h, include/lsr_ply.h).
 
 The library is built in-tree by ``latentsplat_amd/csrc/Makefile`` (``__graft_entry__.build()``).
 There is no CPU fallback: if the shared object is missing or not loadable this module raises, and
@@ -61,7 +61,7 @@ class Layout(C.Structure):
                  "geom_header", "bin_keys", "bin_point_list", "img_final_T", "img_n_contrib")]
 
 
-class AdapterDims(C.Structure):      # lsr_adapter_dims (include/lsr_adapter.h, include/lsr_latent.h)
+class AdapterDims(C.Structure):      # lsr_adapter_dims (include/lsr_adapter.h, include/lsr_latent.h, include/lsr_ply.h)
     _fields_ = [("num_cameras", C.c_int32), ("rays", C.c_int32), ("samples", C.c_int32),
                 ("height", C.c_int32), ("width", C.c_int32), ("cov_elems", C.c_int32),
                 ("scale_min", C.c_float), ("scale_max", C.c_float), ("eps", C.c_float),
@@ -84,7 +84,7 @@ class AdapterInGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("coordinates", "depths", "raw")]
 
 
-class LatentDims(C.Structure):       # lsr_latent_dims (include/lsr_latent.h)
+class LatentDims(C.Structure):       # lsr_latent_dims (include/lsr_latent.h, include/lsr_ply.h)
     _fields_ = [("num_views", C.c_int32), ("channels", C.c_int32), ("height", C.c_int32),
                 ("width", C.c_int32), ("out_height", C.c_int32), ("out_width", C.c_int32),
                 ("logvar_mode", C.c_int32), ("color_channels", C.c_int32),
@@ -104,12 +104,20 @@ class LatentOutGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("skip", "z")]
 
 
+class PlyInputs(C.Structure):        # lsr_ply_inputs (include/lsr_ply.h)
+    _fields_ = [(n, C.c_void_p) for n in ("extrinsics", "means", "scales", "rotations", "harmonics",
+                                          "opacities", "center", "scale_factor")]
+
+
+PLY_VERTEX_FLOATS = 17
+
 EXPORTS = (
     "lsr_abi_version", "lsr_error_string", "lsr_last_hip_error", "lsr_geom_workspace_bytes",
     "lsr_image_workspace_bytes", "lsr_binning_workspace_bytes", "lsr_grad_workspace_bytes",
     "lsr_get_layout", "lsr_build_views", "lsr_forward_prepare", "lsr_forward_render", "lsr_backward",
     "lsr_profile_enable", "lsr_profile_num_stages", "lsr_profile_stage_name", "lsr_profile_read",
     "lsr_adapter_forward", "lsr_adapter_backward", "lsr_latent_forward", "lsr_latent_backward",
+    "lsr_ply_pack", "lsr_ply_write_host",
 )
 
 _lib = None
@@ -178,6 +186,10 @@ def load():
     lib.lsr_latent_backward.restype = C.c_int
     lib.lsr_latent_backward.argtypes = [C.POINTER(LatentDims), C.POINTER(LatentInputs),
                                         C.POINTER(LatentOutGrads), P, P]
+    lib.lsr_ply_pack.restype = C.c_int
+    lib.lsr_ply_pack.argtypes = [I64, I32, C.POINTER(PlyInputs), P, P]
+    lib.lsr_ply_write_host.restype = C.c_int
+    lib.lsr_ply_write_host.argtypes = [C.c_char_p, P, I64]
     if lib.lsr_abi_version() != 2:
         raise LsrError("liblsr_hip.so ABI version mismatch; rebuild it")
     _lib = lib
