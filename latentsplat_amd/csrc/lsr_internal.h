@@ -17,7 +17,7 @@ namespace lsr {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t header, rec, bin, tile_count, tile_cost, tile_start, tile_cursor, tile_order, tile_lpt, total;
+    size_t header, rec, bin, tile_count, tile_cost, tile_start, tile_cursor, tile_order, tile_lpt, sh_clamp, total;
     int rec_floats;
 };
 struct ImgLayout {
@@ -42,7 +42,7 @@ inline int64_t num_tiles(const lsr_dims &d) { return (int64_t)tiles_x(d) * tiles
 
 // Screen-space record of one (view, Gaussian), written by k_preprocess and gathered (one 64-byte
 // line for <= 8 payload channels) by the compositing kernels:
-//   [0] x_pix [1] y_pix [2] conicA [3] conicB [4] conicC [5] opacity [6] view z [7] colour clamp bits
+//   [0] x_pix [1] y_pix [2] conicA [3] conicB [4] conicC [5] opacity [6] view z [7] unused (0)
 //   [8 + c] payload channel c: rgb first when colour is rendered, then the feature channels; zero padded.
 // The packed gradient record of the backward pass (GradLayout) uses the same slot numbering.
 inline int rec_floats(const lsr_dims &d) {
@@ -71,6 +71,7 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     L.tile_start = o; o = align_up(o + (VT + 1) * 4);
     L.tile_order = o; o = align_up(o + 4 * VT * 4);   // work items (see kItem*), costliest first
     L.tile_lpt = o; o = align_up(o + VT * 4);         // (view,tile) ids, costliest first
+    L.sh_clamp = o; o = align_up(o + VG);             // per (view, Gaussian): colour channels clamped at 0 (sh.hip)
     L.total = o;
     return L;
 }

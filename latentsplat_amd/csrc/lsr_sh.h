@@ -7,21 +7,23 @@
 
 namespace lsr {
 
+// MAXDEG: compile-time bound on `deg` (lets the compiler drop the higher bands and their registers)
+template <int MAXDEG = 4>
 __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float *b) {
     b[0] = 0.28209479177387814f;
-    if (deg < 1) return;
+    if (MAXDEG < 1 || deg < 1) return;
     const float C1 = 0.4886025119029199f;
     b[1] = -C1 * y;
     b[2] = C1 * z;
     b[3] = -C1 * x;
-    if (deg < 2) return;
+    if (MAXDEG < 2 || deg < 2) return;
     const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
     b[4] = 1.0925484305920792f * xy;
     b[5] = -1.0925484305920792f * yz;
     b[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
     b[7] = -1.0925484305920792f * xz;
     b[8] = 0.5462742152960396f * (xx - yy);
-    if (deg < 3) return;
+    if (MAXDEG < 3 || deg < 3) return;
     b[9] = -0.5900435899266435f * y * (3.0f * xx - yy);
     b[10] = 2.890611442640554f * xy * z;
     b[11] = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
@@ -29,7 +31,7 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     b[13] = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
     b[14] = 1.445305721320277f * z * (xx - yy);
     b[15] = -0.5900435899266435f * x * (xx - 3.0f * yy);
-    if (deg < 4) return;
+    if (MAXDEG < 4 || deg < 4) return;
     b[16] = 2.5033429417967046f * xy * (xx - yy);
     b[17] = -1.7701307697799304f * yz * (3.0f * xx - yy);
     b[18] = 0.9461746957575601f * xy * (7.0f * zz - 1.0f);
@@ -42,12 +44,15 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
 }
 
 // d b[k] / d (x,y,z), treating x,y,z as independent.
+// Only rows k < (MAXDEG+1)^2 of g are touched.
+template <int MAXDEG = 4>
 __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float (*g)[3]) {
-    for (int k = 0; k < 25; ++k) g[k][0] = g[k][1] = g[k][2] = 0.0f;
-    if (deg < 1) return;
+#pragma unroll
+    for (int k = 0; k < (MAXDEG + 1) * (MAXDEG + 1); ++k) g[k][0] = g[k][1] = g[k][2] = 0.0f;
+    if (MAXDEG < 1 || deg < 1) return;
     const float C1 = 0.4886025119029199f;
     g[1][1] = -C1; g[2][2] = C1; g[3][0] = -C1;
-    if (deg < 2) return;
+    if (MAXDEG < 2 || deg < 2) return;
     const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
     const float a2 = 1.0925484305920792f, b2 = 0.31539156525252005f, c2 = 0.5462742152960396f;
     g[4][0] = a2 * y;   g[4][1] = a2 * x;
@@ -55,7 +60,7 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
     g[6][0] = -2.0f * b2 * x; g[6][1] = -2.0f * b2 * y; g[6][2] = 4.0f * b2 * z;
     g[7][0] = -a2 * z;  g[7][2] = -a2 * x;
     g[8][0] = 2.0f * c2 * x;  g[8][1] = -2.0f * c2 * y;
-    if (deg < 3) return;
+    if (MAXDEG < 3 || deg < 3) return;
     const float a3 = -0.5900435899266435f, b3 = 2.890611442640554f, c3 = -0.4570457994644658f,
                 d3 = 0.3731763325901154f, e3 = 1.445305721320277f;
     g[9][0] = a3 * 6.0f * xy;                  g[9][1] = a3 * 3.0f * (xx - yy);
@@ -65,7 +70,7 @@ __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z
     g[13][0] = c3 * (4.0f * zz - 3.0f * xx - yy);  g[13][1] = c3 * -2.0f * xy;  g[13][2] = c3 * 8.0f * xz;
     g[14][0] = e3 * 2.0f * xz;   g[14][1] = e3 * -2.0f * yz;  g[14][2] = e3 * (xx - yy);
     g[15][0] = a3 * 3.0f * (xx - yy);  g[15][1] = a3 * -6.0f * xy;
-    if (deg < 4) return;
+    if (MAXDEG < 4 || deg < 4) return;
     const float k0 = 2.5033429417967046f, k1 = -1.7701307697799304f, k2 = 0.9461746957575601f,
                 k3 = -0.6690465435572892f, k4 = 0.10578554691520431f, k6 = 0.47308734787878004f,
                 k8 = 0.6258357354491761f;

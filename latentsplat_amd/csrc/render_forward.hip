@@ -59,19 +59,21 @@ template <int NCHP, int UNR, int WPB>
 __global__ void __launch_bounds__(LSR_WAVE * WPB)
 k_render_fwd(RenderFwdParams p) {
     constexpr int PXL = 4;
-    __shared__ float4 s_q0_all[WPB][LSR_WAVE + 1];   // slot 64: null record (alpha == 0) pads partial groups
-    __shared__ float4 s_q1_all[WPB][LSR_WAVE + 1];
-    __shared__ float4 s_pay_all[WPB][LSR_WAVE + 1][NCHP / 4];
+    // Staged entries, one record per list entry: (x, y, a2, b2) (c2, log2 o, z, -) payload...
+    // One LDS address per entry (a single VALU add, the parts at immediate offsets); the odd
+    // float4 stride keeps the per-lane staging stores bank-conflict free.  Slot 64 is a null
+    // record (alpha == 0) that pads partial groups.
+    constexpr int kEnt = (2 + NCHP / 4) | 1;
+    __shared__ float4 s_ent_all[WPB][LSR_WAVE + 1][kEnt];
 
     const int lane = threadIdx.x & (LSR_WAVE - 1);
     const int wid = threadIdx.x / LSR_WAVE;
-    float4 *s_q0 = s_q0_all[wid], *s_q1 = s_q1_all[wid];
-    float4 (*s_pay)[NCHP / 4] = s_pay_all[wid];
+    float4 (*s_ent)[kEnt] = s_ent_all[wid];
     if (lane == 0) {
-        s_q0[LSR_WAVE] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        s_q1[LSR_WAVE] = make_float4(0.0f, -INFINITY, 0.0f, 0.0f);  // log2(opacity) = -inf
+        s_ent[LSR_WAVE][0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_ent[LSR_WAVE][1] = make_float4(0.0f, -INFINITY, 0.0f, 0.0f);  // log2(opacity) = -inf
 #pragma unroll
-        for (int c4 = 0; c4 < NCHP / 4; ++c4) s_pay[LSR_WAVE][c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     const uint32_t num_items = p.header[kHdrNumItems];
     const int coff = p.has_color ? 3 : 0;
@@ -139,10 +141,10 @@ k_render_fwd(RenderFwdParams p) {
                 m = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own;
                 if (m) {
                     const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
-                    s_q0[lane] = make_float4(a.x, a.y, f.a2, f.b2);
-                    s_q1[lane] = make_float4(f.c2, f.l2o, b.z, 0.0f);
+                    s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.b2);
+                    s_ent[lane][1] = make_float4(f.c2, f.l2o, b.z, 0.0f);
 #pragma unroll
-                    for (int c4 = 0; c4 < NCHP / 4; ++c4) s_pay[lane][c4] = R[2 + c4];  // payload, zero padded
+                    for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[lane][2 + c4] = R[2 + c4];  // payload, zero padded
                 }
             }
             // per quadrant: which staged entries can touch it (wave-uniform 64-bit masks)
@@ -167,10 +169,10 @@ k_render_fwd(RenderFwdParams p) {
                     float pay[UNR][NCHP];
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) {
-                        a[u] = s_q0[jj[u]]; b[u] = s_q1[jj[u]];
+                        a[u] = s_ent[jj[u]][0]; b[u] = s_ent[jj[u]][1];
 #pragma unroll
                         for (int c4 = 0; c4 < NCHP / 4; ++c4) {
-                            const float4 t = s_pay[jj[u]][c4];
+                            const float4 t = s_ent[jj[u]][2 + c4];
                             pay[u][4 * c4] = t.x; pay[u][4 * c4 + 1] = t.y; pay[u][4 * c4 + 2] = t.z; pay[u][4 * c4 + 3] = t.w;
                         }
                     }

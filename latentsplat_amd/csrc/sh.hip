@@ -1,230 +1,393 @@
 // sh.hip — view-dependent payload channels from spherical harmonics, forward and backward.
 //
 //   colour   : rgb = max(0, 0.5 + sum_k B_k(dir) * shs[k][c])            (kernel axis convention,
-//              degree <= 4, clamp flags kept for the backward)            lsr_sh.h)
+//              degree <= 4)                                               lsr_sh.h)
 //   features : f_c = 0.5 + sum_k B^ref_k(dir) * feature_sh[c][k]          (reference convention,
 //              the latent-feature evaluation the reference does in PyTorch,
 //              /root/reference/src/model/decoder/cuda_splatting.py:94-101; fused here for
 //              degree <= 2, where B^ref(x,y,z) == B(z,x,y))
 //   dir = normalize(mean * scene_scale - campos)
 //
-// One wave owns 64 consecutive Gaussians for ALL views.  Their coefficient block is contiguous in
-// memory (64 x K*3 or 64 x C*Kf floats), so it is staged through LDS with lane-contiguous loads
-// and read back per lane at an odd stride (no bank conflicts); a scene shared by all views
-// (stride 0) is staged once.  The backward accumulates coefficient gradients in a second LDS
-// array over the views and writes them back lane-contiguously — the per-thread strided
-// read-modify-write of (G,25,3) tensors this replaces was the most expensive kernel of the
-// colour + latent configuration.
+// Both kernels are HBM-bound gathers over (G, K*3) / (G, C*Kf) coefficient tensors, so the design
+// is about touching every byte once with wide accesses:
+//  * a 256-thread workgroup owns 64 consecutive Gaussians for ALL views and BOTH coefficient
+//    groups; the groups' blocks are contiguous in memory (64 x ks floats) and are staged by all four
+//    waves as flat copies with the direct global->LDS path (no staging registers); lane l reads its
+//    row at word stride ks (conflict-free for the odd colour strides); a scene shared by all
+//    views (stride 0) is staged once and the waves take different views;
+//  * forward: the payload channels of a record are written as whole 16-byte words (the upper half
+//    of the 64-byte record line), the "colour channel was clamped at 0" flags go to a dense byte
+//    array (1 B per (view, Gaussian)) so the backward never has to re-read the records;
+//  * backward: ONE kernel.  Thread (wave = view of a chunk of 4, lane = Gaussian) reads its
+//    gradient record once, computes both SH bases, the direction -> mean gradient (needs the staged
+//    coefficients) and leaves bases + channel gradients in LDS (re-using the coefficient area);
+//    then thread = element of the contiguous 64*ks coefficient-gradient runs sums over the views
+//    of the chunk and stores lane-contiguously (no read-modify-write unless a shared scene has
+//    more views than one chunk).
+// The colour degree is a template parameter (straight-line band code, no dead registers).
+#include <algorithm>
+
 #include "lsr_internal.h"
 #include "lsr_sh.h"
 
 namespace lsr {
 
+constexpr int kShThreads = 256;
+constexpr int kShWaves = kShThreads / LSR_WAVE;   // = views per chunk of the backward
+constexpr int kShBasisC = 27;   // 25 basis values + a zero slot, odd stride
+constexpr int kShBasisF = 11;   // 9 + zero slot, odd stride
+
 struct ShParams {
     lsr_dims d;
     lsr_inputs in;
     const BinRec *binrec;     // radius > 0 <=> visible
-    float *rec;               // forward: screen-space records (payload slots written here)
+    float *rec;               // screen-space records (forward writes the payload slots)
+    uint8_t *clamp;           // [V*G] bit c set: colour channel c clamped at 0
     const float *grec;        // backward: packed gradient records
     int RF;
     lsr_in_grads g;
-    int group;                // 0 = colour (G,K,3), 1 = features (G,C,Kf)
+    int has[2];               // group enabled: 0 = colour (G,K,3)|(G,3,K), 1 = features (G,C,Kf)
+    int ks[2];                // floats per Gaussian of each group (0 when disabled)
+    int offF;                 // LDS word offset of the feature rows (16-byte aligned)
+    uint32_t mdiv[2];         // ceil(2^22 / ks): x / ks == (x * mdiv) >> 22 for x < 8192
+    uint32_t mdivK, mdivKf;   // same for K (coefficients per colour channel) and Kf
 };
+__device__ __forceinline__ int udiv_small(int x, uint32_t m) { return (int)(((uint32_t)x * m) >> 22); }
 
-__device__ __forceinline__ int padded_stride(int ks) { return ks; }   // rows are staged unpadded (see stage_in)
-
-// Stage `rows`*ks floats (a contiguous, 16-byte aligned run: 64 Gaussians x ks coefficients) into
-// LDS unchanged, with lane-contiguous 16-byte loads.  Lane l later reads its row at word stride
-// ks: conflict-free when ks is odd (colour: 3*K with K = 1,9,25 ...), a few-way conflict otherwise.
-__device__ __forceinline__ void stage_in(float *lds, const float *src, int ks, int rows, int lane) {
+// Stage group `grp` of view v (rows x ks floats, one contiguous 16-byte aligned run) as a flat copy
+// into its LDS region with the direct global->LDS path (global_load_lds_dwordx4: no staging VGPRs,
+// destination = wave-uniform base + lane*16, i.e. the source order).  Lane l later reads its row at
+// word stride ks: conflict-free for odd ks (colour: 3*K with K = 1, 9, 25), a few-way otherwise.
+__device__ __forceinline__ void stage_group(float *lds, const ShParams &p, int grp, int v, int g0, int rows, int tid) {
+    const int ks = p.ks[grp];
+    if (!ks) return;
+    const int64_t vs = grp == 0 ? p.d.vs_color : p.d.vs_feat;
+    const float *src = (grp == 0 ? p.in.color : p.in.features) + (size_t)v * vs + (size_t)g0 * ks;
+    float *dst = lds + (grp == 0 ? 0 : p.offF);
     const int n = rows * ks, n4 = n >> 2;
-    const float4 *src4 = (const float4 *)src;
-    float4 *lds4 = (float4 *)lds;
-    for (int t = lane; t < n4; t += LSR_WAVE) lds4[t] = src4[t];
-    for (int t = (n4 << 2) + lane; t < n; t += LSR_WAVE) lds[t] = src[t];
+    const int lane = tid & (LSR_WAVE - 1);
+    for (int t4 = tid; t4 - lane < n4; t4 += kShThreads) {
+        if (t4 < n4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * (size_t)t4),
+                                             (__attribute__((address_space(3))) void *)(dst + 4 * (size_t)(t4 - lane)), 16, 0, 0);
+    }
+    for (int t = (n4 << 2) + tid; t < n; t += kShThreads) dst[t] = src[t];
 }
-// coefficient (k, c) of this lane's Gaussian inside its LDS row
-__device__ __forceinline__ int coef_index(bool channel_major, int k, int c, int K) { return channel_major ? c * K + k : 3 * k + c; }
+// all outstanding direct loads have landed in LDS, then the workgroup barrier
+__device__ __forceinline__ void staged_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 
-template <bool BACKWARD>
-__global__ void __launch_bounds__(LSR_WAVE)
-k_sh(ShParams p) {
+// sum_k bas[k] * co[k * stride] over the bands up to `deg` (<= MAXDEG), ascending k (oracle order)
+// (compile-time stride: the LDS reads become one address register + immediate offsets)
+template <int MAXDEG, int stride>
+__device__ __forceinline__ float sh_dot(const float *bas, const float *co, int deg) {
+    float a = bas[0] * co[0];
+    if (MAXDEG > 0 && deg > 0) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) a += bas[k] * co[k * stride];
+        if (MAXDEG > 1 && deg > 1) {
+#pragma unroll
+            for (int k = 4; k < 9; ++k) a += bas[k] * co[k * stride];
+            if (MAXDEG > 2 && deg > 2) {
+#pragma unroll
+                for (int k = 9; k < 16; ++k) a += bas[k] * co[k * stride];
+                if (MAXDEG > 3 && deg > 3) {
+#pragma unroll
+                    for (int k = 16; k < 25; ++k) a += bas[k] * co[k * stride];
+                }
+            }
+        }
+    }
+    return a;
+}
+
+struct ShDir {
+    float dx, dy, dz, len, sc;
+};
+__device__ __forceinline__ ShDir sh_direction(const ShParams &p, int v, int i) {
+    const float *vw = p.in.views + (size_t)v * LSR_VIEW_FLOATS;
+    ShDir r;
+    r.sc = vw[40];
+    const float *mp = p.in.means3D + (size_t)v * p.d.vs_means + 3 * (size_t)i;
+    float dx = mp[0] * r.sc - vw[32], dy = mp[1] * r.sc - vw[33], dz = mp[2] * r.sc - vw[34];
+    r.len = sqrtf(dx * dx + dy * dy + dz * dz);
+    r.dx = dx / r.len; r.dy = dy / r.len; r.dz = dz / r.len;
+    return r;
+}
+
+__device__ __forceinline__ bool sh_shared_scene(const ShParams &p) {
+    return (!p.has[0] || p.d.vs_color == 0) && (!p.has[1] || p.d.vs_feat == 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// DEGC: colour SH degree, -1 = colour is not evaluated here.  COFF: payload slot of feature 0.
+template <int DEGC, int COFF>
+__global__ void __launch_bounds__(kShThreads)
+k_sh_fwd(ShParams p) {
     extern __shared__ float s_lds[];
     const lsr_dims &d = p.d;
-    const int lane = threadIdx.x, G = d.num_gaussians, V = d.num_views;
+    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wave = tid / LSR_WAVE;
+    const int G = d.num_gaussians, V = d.num_views;
     const int g0 = blockIdx.x * LSR_WAVE, i = g0 + lane;
     const int rows = G - g0 < LSR_WAVE ? G - g0 : LSR_WAVE;
     const bool active = i < G;
-    const int group = p.group;
-    const int coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
-    const int deg = group == 0 ? d.sh_degree : d.feat_sh_degree;
-    const int K = group == 0 ? d.sh_coeffs : d.feat_sh_coeffs;          // coefficients stored per channel
-    const int nch = group == 0 ? 3 : d.feat_channels;
-    const int nb = (deg + 1) * (deg + 1);
-    const int ks = K * nch, ps = padded_stride(ks);
-    const int64_t vs = group == 0 ? d.vs_color : d.vs_feat;
-    const float *coef_base = group == 0 ? p.in.color : p.in.features;
-    float *s_coef = s_lds;
-    const float *my = s_coef + lane * ps;
-    const int slot0 = 8 + (group == 0 ? 0 : coff);                        // first payload slot of the group
-    const bool cmaj = group == 1 || d.color_sh_channel_major != 0;       // coefficient layout [c][k] vs [k][c]
+    const int C = d.feat_channels, K = d.sh_coeffs, Kf = d.feat_sh_coeffs, degF = d.feat_sh_degree;
+    const bool hasF = p.has[1] != 0;
+    const bool cmaj = d.color_sh_channel_major != 0;
+    const float *my = s_lds + lane * p.ks[0];
+    const float *myF = s_lds + p.offF + lane * p.ks[1];
 
-    if (vs == 0) {
-        stage_in(s_coef, coef_base + (size_t)g0 * ks, ks, rows, lane);
-        __syncthreads();
-    }
-    float gmean_acc[3] = {0.0f, 0.0f, 0.0f};
-    for (int v = 0; v < V; ++v) {
-        if (vs != 0) {
-            __syncthreads();
-            stage_in(s_coef, coef_base + (size_t)v * vs + (size_t)g0 * ks, ks, rows, lane);
-            __syncthreads();
-        }
+    auto compute = [&](int v) {
         const size_t o = (size_t)v * G + (active ? i : 0);
-        const bool vis = active && p.binrec[o].radius > 0;
-        float gm[3] = {0.0f, 0.0f, 0.0f};
-        if (vis) {
-            const float *vw = p.in.views + (size_t)v * LSR_VIEW_FLOATS;
-            const float sc = vw[40];
-            const float *mp = p.in.means3D + (size_t)v * d.vs_means + 3 * (size_t)i;
-            float dx = mp[0] * sc - vw[32], dy = mp[1] * sc - vw[33], dz = mp[2] * sc - vw[34];
-            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-            dx = dx / len; dy = dy / len; dz = dz / len;
-            // features use the reference's axis naming: B^ref(x,y,z) = B(z,x,y) up to degree 2
-            const float bx = group == 0 ? dx : dz, by = group == 0 ? dy : dx, bz = group == 0 ? dz : dy;
-            float bas[25];
-            sh_basis(deg, bx, by, bz, bas);
-            if (!BACKWARD) {
-                float *R = p.rec + o * (size_t)p.RF;
-                uint32_t clampbits = 0;
-                for (int c = 0; c < nch; ++c) {
-                    float acc = 0.0f;
-                    for (int k = 0; k < nb; ++k) acc += bas[k] * my[coef_index(cmaj, k, c, K)];
-                    acc += 0.5f;
-                    if (group == 0) {
-                        if (acc < 0.0f) clampbits |= 1u << c;
-                        acc = acc > 0.0f ? acc : 0.0f;
-                    }
-                    R[slot0 + c] = acc;
+        if (!(active && p.binrec[o].radius > 0)) return;
+        const ShDir dir = sh_direction(p, v, i);
+        float *R = p.rec + o * (size_t)p.RF + 8;
+        float basF[9];
+        // features use the reference's axis naming: B^ref(x,y,z) = B(z,x,y) up to degree 2
+        if (hasF) sh_basis<2>(degF, dir.dz, dir.dx, dir.dy, basF);
+        auto feat = [&](int c) -> float {               // feature channel c, 0 beyond the last one (padding)
+            if (c >= C) return 0.0f;
+            return sh_dot<2, 1>(basF, myF + c * Kf, degF) + 0.5f;
+        };
+        int c_next = 0;                                 // first feature channel not yet written
+        if (COFF == 3) {
+            float col[3] = {0.0f, 0.0f, 0.0f};
+            if (DEGC >= 0) {
+                float basC[25];
+                sh_basis<DEGC>(DEGC, dir.dx, dir.dy, dir.dz, basC);
+                uint32_t bits = 0;
+                // one channel at a time, each consuming its LDS reads before the next starts (fully
+                // interleaved, the 75 reads cost ~60 more live registers and a wave of occupancy)
+                float a0, a1, a2;
+                if (cmaj) {
+                    a0 = sh_dot<DEGC, 1>(basC, my, DEGC) + 0.5f;
+                    __builtin_amdgcn_sched_barrier(0);
+                    a1 = sh_dot<DEGC, 1>(basC, my + K, DEGC) + 0.5f;
+                    __builtin_amdgcn_sched_barrier(0);
+                    a2 = sh_dot<DEGC, 1>(basC, my + 2 * K, DEGC) + 0.5f;
+                } else {
+                    a0 = sh_dot<DEGC, 3>(basC, my, DEGC) + 0.5f;
+                    __builtin_amdgcn_sched_barrier(0);
+                    a1 = sh_dot<DEGC, 3>(basC, my + 1, DEGC) + 0.5f;
+                    __builtin_amdgcn_sched_barrier(0);
+                    a2 = sh_dot<DEGC, 3>(basC, my + 2, DEGC) + 0.5f;
                 }
-                if (group == 0) R[7] = __uint_as_float(clampbits);
-            } else {
-                // direction gradient only (coefficient gradients: k_sh_coef_backward below):
-                //   sg[k] = sum_c coef[k][c] * dL/dchannel_c ;  dL/d(b) = sum_k dB_k/d(b) * sg[k]
-                const float *gr = p.grec + o * (size_t)p.RF;
-                const uint32_t clampbits = group == 0 ? __float_as_uint(p.rec[o * (size_t)p.RF + 7]) : 0u;
-                float sg[25];
-#pragma unroll
-                for (int k = 0; k < 25; ++k) sg[k] = 0.0f;
-                for (int c = 0; c < nch; ++c) {
-                    const float gc = (clampbits >> c & 1u) ? 0.0f : gr[slot0 + c];
-#pragma unroll
-                    for (int k = 0; k < 25; ++k)
-                        if (k < nb) sg[k] = __builtin_fmaf(my[coef_index(cmaj, k, c, K)], gc, sg[k]);
-                }
-                float dbas[25][3];
-                sh_basis_grad(deg, bx, by, bz, dbas);
-                float dd[3] = {0.0f, 0.0f, 0.0f};   // dL / d(bx,by,bz)
-#pragma unroll
-                for (int k = 0; k < 25; ++k)
-                    if (k < nb) { dd[0] += dbas[k][0] * sg[k]; dd[1] += dbas[k][1] * sg[k]; dd[2] += dbas[k][2] * sg[k]; }
-                // back to (dx,dy,dz) naming, then through the normalisation and the scene scale
-                const float ddx = group == 0 ? dd[0] : dd[1], ddy = group == 0 ? dd[1] : dd[2], ddz = group == 0 ? dd[2] : dd[0];
-                const float dot = ddx * dx + ddy * dy + ddz * dz;
-                const float f = sc / len;
-                gm[0] = (ddx - dx * dot) * f; gm[1] = (ddy - dy * dot) * f; gm[2] = (ddz - dz * dot) * f;
+                if (a0 < 0.0f) bits |= 1u;
+                if (a1 < 0.0f) bits |= 2u;
+                if (a2 < 0.0f) bits |= 4u;
+                col[0] = a0 > 0.0f ? a0 : 0.0f; col[1] = a1 > 0.0f ? a1 : 0.0f; col[2] = a2 > 0.0f ? a2 : 0.0f;
+                p.clamp[o] = (uint8_t)bits;
             }
+            if (DEGC >= 0 && hasF) {
+                *(float4 *)R = make_float4(col[0], col[1], col[2], feat(0));
+            } else if (DEGC >= 0) {
+                R[0] = col[0]; R[1] = col[1]; R[2] = col[2];
+            } else if (hasF) {
+                R[3] = feat(0);
+            }
+            c_next = 1;
         }
-        if (BACKWARD) {
-            if (d.vs_means != 0) {
-                if (vis) {
-                    float *o3 = p.g.means3D + (size_t)v * d.vs_means + 3 * (size_t)i;
-                    o3[0] += gm[0]; o3[1] += gm[1]; o3[2] += gm[2];
-                }
-            } else { gmean_acc[0] += gm[0]; gmean_acc[1] += gm[1]; gmean_acc[2] += gm[2]; }
+        if (hasF) {
+            const int pad = ((COFF + C + 3) & ~3) - COFF;   // feature channels incl. the zero padding
+#pragma unroll 1
+            for (int c = c_next; c < pad; c += 4)
+                *(float4 *)(R + COFF + c) = make_float4(feat(c), feat(c + 1), feat(c + 2), feat(c + 3));
         }
-    }
-    if (BACKWARD) {
-        if (d.vs_means == 0 && active) {
-            float *o3 = p.g.means3D + 3 * (size_t)i;
-            o3[0] += gmean_acc[0]; o3[1] += gmean_acc[1]; o3[2] += gmean_acc[2];
+    };
+
+    if (sh_shared_scene(p)) {
+        stage_group(s_lds, p, 0, 0, g0, rows, tid);
+        stage_group(s_lds, p, 1, 0, g0, rows, tid);
+        staged_barrier();
+        for (int v = wave; v < V; v += kShWaves) compute(v);
+    } else {
+        for (int v = 0; v < V; ++v) {
+            __syncthreads();
+            stage_group(s_lds, p, 0, v, g0, rows, tid);
+            stage_group(s_lds, p, 1, v, g0, rows, tid);
+            staged_barrier();
+            if (wave == (v & (kShWaves - 1))) compute(v);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// Coefficient gradients.  Those of a 64-Gaussian block are ONE contiguous run of 64*ks floats
-// (ks = K*channels).  Phase A (lane = Gaussian) leaves the SH basis and the (clamp-masked) channel
-// gradients of up to kShViewChunk views in LDS; phase B (lane = element of the run) sums
-// basis[v][g][k] * gch[v][g][c] over those views and stores the run lane-contiguously.
-// Few registers (no per-element state), coalesced stores, no read-modify-write except when a
-// shared scene has more views than one chunk.
-constexpr int kShViewChunk = 4;
-constexpr int kShBasisStride = 27;   // 25 basis values + a zero slot, odd stride
-
-__global__ void __launch_bounds__(256)
-k_sh_coef_backward(ShParams p) {
+template <int DEGC, int COFF>
+__global__ void __launch_bounds__(kShThreads)
+k_sh_bwd(ShParams p) {
     extern __shared__ float s_lds[];
+    __shared__ float s_part[kShWaves][LSR_WAVE][3];
     const lsr_dims &d = p.d;
-    const int tid = threadIdx.x, G = d.num_gaussians, V = d.num_views;
-    const int g0 = blockIdx.x * LSR_WAVE;
+    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wave = tid / LSR_WAVE;
+    const int G = d.num_gaussians, V = d.num_views;
+    const int g0 = blockIdx.x * LSR_WAVE, i = g0 + lane;
     const int rows = G - g0 < LSR_WAVE ? G - g0 : LSR_WAVE;
-    const int group = p.group;
-    const int coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
-    const int deg = group == 0 ? d.sh_degree : d.feat_sh_degree;
-    const int K = group == 0 ? d.sh_coeffs : d.feat_sh_coeffs;
-    const int nch = group == 0 ? 3 : d.feat_channels;
-    const int nb = (deg + 1) * (deg + 1);
-    const int ks = K * nch;
-    const int64_t vs = group == 0 ? d.vs_color : d.vs_feat;
-    float *gcoef_base = group == 0 ? p.g.color : p.g.features;
-    const int slot0 = 8 + (group == 0 ? 0 : coff);
-    const bool cmaj = group == 1 || d.color_sh_channel_major != 0;
-    constexpr int BS = kShBasisStride;
-    const int cs = nch | 1;
-    const int chunk = vs != 0 ? 1 : kShViewChunk;            // per-view outputs: one view at a time
-    float *s_bas = s_lds, *s_gch = s_lds + kShViewChunk * LSR_WAVE * BS;
+    const bool active = i < G;
+    const int C = d.feat_channels, K = d.sh_coeffs, Kf = d.feat_sh_coeffs, degF = d.feat_sh_degree;
+    constexpr int nbC = DEGC >= 0 ? (DEGC + 1) * (DEGC + 1) : 0;
+    const int nbF = (degF + 1) * (degF + 1);
+    const bool hasF = p.has[1] != 0;
+    const bool cmaj = d.color_sh_channel_major != 0;
+    const bool shared = sh_shared_scene(p);
+    const int chunk = shared ? kShWaves : 1;            // per-view coefficient outputs: one view at a time
+    const int ntot = COFF + C, cs = ntot | 1;
+    // LDS: [ coefficient rows | (re-used after the direction pass) basC, basF ] [ gch ]
+    const int area = max(p.offF + LSR_WAVE * p.ks[1], kShWaves * LSR_WAVE * (kShBasisC + kShBasisF));
+    float *s_basC = s_lds, *s_basF = s_lds + kShWaves * LSR_WAVE * kShBasisC;
+    float *s_gch = s_lds + area;
+    const float *my = s_lds + lane * p.ks[0];
+    const float *myF = s_lds + p.offF + lane * p.ks[1];
+    float acc[3] = {0.0f, 0.0f, 0.0f};   // mean gradient summed over this thread's views (shared means)
 
     for (int v0 = 0; v0 < V; v0 += chunk) {
         const int nv = V - v0 < chunk ? V - v0 : chunk;
-        __syncthreads();   // previous chunk's phase B is done with the LDS arrays
-        // ---- phase A: thread = (view of the chunk, Gaussian) ----
-        if (tid < nv * LSR_WAVE) {
-            const int vi = tid / LSR_WAVE, lane = tid % LSR_WAVE, v = v0 + vi, i = g0 + lane;
-            const bool active = i < G;
-            const size_t o = (size_t)v * G + (active ? i : 0);
-            const bool vis = active && p.binrec[o].radius > 0;
-            float *mb = s_bas + (vi * LSR_WAVE + lane) * BS, *mg = s_gch + (vi * LSR_WAVE + lane) * cs;
-            float bas[25];
+        __syncthreads();   // previous chunk's element pass is done with the LDS arrays
+        stage_group(s_lds, p, 0, shared ? 0 : v0, g0, rows, tid);
+        stage_group(s_lds, p, 1, shared ? 0 : v0, g0, rows, tid);
+        staged_barrier();
+        // ---- pass 1: thread = (view v0 + wave, Gaussian lane) ----
+        const int v = v0 + wave;
+        const size_t o = (size_t)v * G + (active ? i : 0);
+        const bool vis = wave < nv && active && p.binrec[o].radius > 0;
+        float *mg = s_gch + (wave * LSR_WAVE + lane) * cs;
+        if (vis) {
+            const ShDir dir = sh_direction(p, v, i);
+            const float *gr = p.grec + o * (size_t)p.RF + 8;
+            float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;   // dL / d(unit direction)
+            if (DEGC >= 0) {
+                const uint32_t bits = p.clamp[o];
+                float sg[nbC > 0 ? nbC : 1];
 #pragma unroll
-            for (int k = 0; k < 25; ++k) bas[k] = 0.0f;
-            if (vis) {
-                const float *vw = p.in.views + (size_t)v * LSR_VIEW_FLOATS;
-                const float sc = vw[40];
-                const float *mp = p.in.means3D + (size_t)v * d.vs_means + 3 * (size_t)i;
-                float dx = mp[0] * sc - vw[32], dy = mp[1] * sc - vw[33], dz = mp[2] * sc - vw[34];
-                const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-                dx = dx / len; dy = dy / len; dz = dz / len;
-                sh_basis(deg, group == 0 ? dx : dz, group == 0 ? dy : dx, group == 0 ? dz : dy, bas);
+                for (int k = 0; k < nbC; ++k) sg[k] = 0.0f;
+#pragma unroll 1
+                for (int c = 0; c < 3; ++c) {   // not unrolled: 25 coefficient reads in flight, not 75
+                    const float gc = (bits >> c & 1u) ? 0.0f : gr[c];
+                    mg[c] = gc;
+                    if (cmaj) {
+                        const float *co = my + c * K;
+#pragma unroll
+                        for (int k = 0; k < nbC; ++k) sg[k] = __builtin_fmaf(co[k], gc, sg[k]);
+                    } else {
+                        const float *co = my + c;
+#pragma unroll
+                        for (int k = 0; k < nbC; ++k) sg[k] = __builtin_fmaf(co[3 * k], gc, sg[k]);
+                    }
+                }
+                float dbas[nbC > 0 ? nbC : 1][3];
+                sh_basis_grad<DEGC>(DEGC, dir.dx, dir.dy, dir.dz, dbas);
+#pragma unroll
+                for (int k = 0; k < nbC; ++k) { ddx += dbas[k][0] * sg[k]; ddy += dbas[k][1] * sg[k]; ddz += dbas[k][2] * sg[k]; }
+            } else if (COFF == 3) {
+                mg[0] = mg[1] = mg[2] = 0.0f;
             }
+            if (hasF) {
+                float sg[9];
 #pragma unroll
-            for (int k = 0; k < 25; ++k) mb[k] = (vis && k < nb) ? bas[k] : 0.0f;
-            mb[25] = 0.0f;
-            const float *gr = p.grec + o * (size_t)p.RF;
-            const uint32_t clampbits = (vis && group == 0) ? __float_as_uint(p.rec[o * (size_t)p.RF + 7]) : 0u;
-            for (int c = 0; c < nch; ++c) mg[c] = (vis && !(clampbits >> c & 1u)) ? gr[slot0 + c] : 0.0f;
+                for (int k = 0; k < 9; ++k) sg[k] = 0.0f;
+#pragma unroll 1
+                for (int c = 0; c < C; ++c) {
+                    const float gc = gr[COFF + c];
+                    mg[COFF + c] = gc;
+                    const float *co = myF + c * Kf;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+                        if (k < nbF) sg[k] = __builtin_fmaf(co[k], gc, sg[k]);
+                }
+                float dbas[9][3];
+                sh_basis_grad<2>(degF, dir.dz, dir.dx, dir.dy, dbas);
+                float e0 = 0.0f, e1 = 0.0f, e2 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    if (k < nbF) { e0 += dbas[k][0] * sg[k]; e1 += dbas[k][1] * sg[k]; e2 += dbas[k][2] * sg[k]; }
+                ddx += e1; ddy += e2; ddz += e0;   // basis arguments were (dz, dx, dy)
+            } else {
+                for (int c = 0; c < C; ++c) mg[COFF + c] = 0.0f;
+            }
+            // through the normalisation and the scene scale to the mean
+            const float dot = ddx * dir.dx + ddy * dir.dy + ddz * dir.dz;
+            const float f = dir.sc / dir.len;
+            const float gm[3] = {(ddx - dir.dx * dot) * f, (ddy - dir.dy * dot) * f, (ddz - dir.dz * dot) * f};
+            if (d.vs_means != 0) {
+                float *o3 = p.g.means3D + (size_t)v * d.vs_means + 3 * (size_t)i;
+                o3[0] += gm[0]; o3[1] += gm[1]; o3[2] += gm[2];
+            } else {
+                acc[0] += gm[0]; acc[1] += gm[1]; acc[2] += gm[2];
+            }
+        } else {
+            for (int j = 0; j < ntot; ++j) mg[j] = 0.0f;
+        }
+        __syncthreads();   // every thread is done reading the coefficient rows
+        {   // the SH bases go where the coefficients were (recomputed here rather than kept live
+            // through the direction pass: registers, not VALU, limit this kernel's occupancy)
+            ShDir dir = {0.0f, 0.0f, 1.0f, 1.0f, 1.0f};
+            if (vis) dir = sh_direction(p, v, i);
+            if (DEGC >= 0) {
+                float basC[nbC > 0 ? nbC : 1];
+                sh_basis<DEGC>(DEGC, dir.dx, dir.dy, dir.dz, basC);
+                float *mb = s_basC + (wave * LSR_WAVE + lane) * kShBasisC;
+#pragma unroll
+                for (int k = 0; k < 26; ++k) mb[k] = (vis && k < nbC) ? basC[k < nbC ? k : 0] : 0.0f;
+            }
+            if (hasF) {
+                float basF[9];
+                sh_basis<2>(degF, dir.dz, dir.dx, dir.dy, basF);
+                float *mb = s_basF + (wave * LSR_WAVE + lane) * kShBasisF;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) mb[k] = (vis && k < nbF) ? basF[k] : 0.0f;
+                mb[9] = 0.0f;
+            }
         }
         __syncthreads();
-        // ---- phase B: thread = element of the contiguous coefficient-gradient run ----
-        float *dst = gcoef_base + (vs != 0 ? (size_t)v0 * vs : 0) + (size_t)g0 * ks;
-        for (int t = tid; t < rows * ks; t += 256) {
-            const int g = t / ks, rem = t - g * ks;
-            const int k = cmaj ? rem % K : rem / 3, c = cmaj ? rem / K : rem % 3;
-            const int kb = k < nb ? k : 25;   // coefficients beyond the evaluated bands: zero slot
-            float a = (vs == 0 && v0 > 0) ? dst[t] : 0.0f;
-            for (int vi = 0; vi < nv; ++vi)
-                a = __builtin_fmaf(s_bas[(vi * LSR_WAVE + g) * BS + kb], s_gch[(vi * LSR_WAVE + g) * cs + c], a);
-            dst[t] = a;
+        // ---- pass 2: thread = element of the contiguous coefficient-gradient runs ----
+        const bool rmw = shared && v0 > 0;
+        if (DEGC >= 0) {
+            const int ks = p.ks[0];
+            float *dst = p.g.color + (d.vs_color != 0 ? (size_t)v0 * d.vs_color : 0) + (size_t)g0 * ks;
+            for (int t = tid; t < rows * ks; t += kShThreads) {
+                const int g = udiv_small(t, p.mdiv[0]), rem = t - g * ks;
+                int k, c;
+                if (cmaj) { c = udiv_small(rem, p.mdivK); k = rem - c * K; }
+                else { k = (rem * 0xAAABu) >> 17; c = rem - 3 * k; }
+                const int kb = k < nbC ? k : 25;   // coefficients beyond the evaluated bands: zero slot
+                float a = rmw ? dst[t] : 0.0f;
+                const float *pb = s_basC + g * kShBasisC + kb, *pg = s_gch + g * cs + c;
+#pragma unroll
+                for (int vi = 0; vi < kShWaves; ++vi)
+                    if (vi < nv) a = __builtin_fmaf(pb[vi * LSR_WAVE * kShBasisC], pg[vi * LSR_WAVE * cs], a);
+                dst[t] = a;
+            }
+        }
+        if (hasF) {
+            const int ks = p.ks[1];
+            float *dst = p.g.features + (d.vs_feat != 0 ? (size_t)v0 * d.vs_feat : 0) + (size_t)g0 * ks;
+            for (int t = tid; t < rows * ks; t += kShThreads) {
+                const int g = udiv_small(t, p.mdiv[1]), rem = t - g * ks;
+                const int c = udiv_small(rem, p.mdivKf), k = rem - c * Kf;
+                const int kb = k < nbF ? k : 9;
+                float a = rmw ? dst[t] : 0.0f;
+                const float *pb = s_basF + g * kShBasisF + kb, *pg = s_gch + g * cs + COFF + c;
+#pragma unroll
+                for (int vi = 0; vi < kShWaves; ++vi)
+                    if (vi < nv) a = __builtin_fmaf(pb[vi * LSR_WAVE * kShBasisF], pg[vi * LSR_WAVE * cs], a);
+                dst[t] = a;
+            }
+        }
+    }
+    if (d.vs_means == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) s_part[wave][lane][a] = acc[a];
+        __syncthreads();
+        if (wave == 0 && active) {
+            float *o3 = p.g.means3D + 3 * (size_t)i;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float t = 0.0f;
+#pragma unroll
+                for (int w = 0; w < kShWaves; ++w) t += s_part[w][lane][a];
+                o3[a] += t;
+            }
         }
     }
 }
@@ -233,22 +396,55 @@ static bool group_enabled(const lsr_dims &d, int group) {
     return group == 0 ? d.color_mode == LSR_COLOR_SH : (d.feat_channels > 0 && d.feat_mode == LSR_FEAT_SH);
 }
 
+static uint32_t mdiv_of(int x) { return x > 0 ? (uint32_t)(((1u << 22) + x - 1) / x) : 0u; }
+
+static ShParams make_params(const lsr_dims &d, const lsr_inputs &in, const GeomLayout &L, const char *geom) {
+    ShParams p;
+    p.d = d; p.in = in; p.binrec = (const BinRec *)(geom + L.bin);
+    p.rec = (float *)const_cast<char *>(geom + L.rec); p.clamp = (uint8_t *)const_cast<char *>(geom + L.sh_clamp);
+    p.grec = nullptr; p.RF = L.rec_floats; p.g = lsr_in_grads{};
+    p.has[0] = group_enabled(d, 0); p.has[1] = group_enabled(d, 1);
+    p.ks[0] = p.has[0] ? d.sh_coeffs * 3 : 0;
+    p.ks[1] = p.has[1] ? d.feat_sh_coeffs * d.feat_channels : 0;
+    p.offF = (LSR_WAVE * p.ks[0] + 3) & ~3;
+    for (int g = 0; g < 2; ++g) p.mdiv[g] = mdiv_of(p.ks[g]);
+    p.mdivK = mdiv_of(d.sh_coeffs); p.mdivKf = mdiv_of(d.feat_sh_coeffs);
+    return p;
+}
+
+// colour degree / feature offset -> template instance
+#define LSR_SH_DISPATCH(KERNEL, degc, coff, ...)                                          \
+    do {                                                                                   \
+        if (degc == 4) hipLaunchKernelGGL((KERNEL<4, 3>), __VA_ARGS__);                    \
+        else if (degc == 3) hipLaunchKernelGGL((KERNEL<3, 3>), __VA_ARGS__);               \
+        else if (degc == 2) hipLaunchKernelGGL((KERNEL<2, 3>), __VA_ARGS__);               \
+        else if (degc == 1) hipLaunchKernelGGL((KERNEL<1, 3>), __VA_ARGS__);               \
+        else if (degc == 0) hipLaunchKernelGGL((KERNEL<0, 3>), __VA_ARGS__);               \
+        else if (coff == 3) hipLaunchKernelGGL((KERNEL<-1, 3>), __VA_ARGS__);              \
+        else hipLaunchKernelGGL((KERNEL<-1, 0>), __VA_ARGS__);                             \
+    } while (0)
+
 hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s) {
     if (d.num_gaussians == 0) return hipSuccess;
     if (!group_enabled(d, 0) && !group_enabled(d, 1)) return hipSuccess;
     const GeomLayout L = geom_layout(d);
+    const ShParams p = make_params(d, in, L, geom);
+    const int degc = p.has[0] ? d.sh_degree : -1, coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
+    const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), block(kShThreads);
+    const size_t shm = ((size_t)p.offF + (size_t)LSR_WAVE * p.ks[1]) * 4;
     prof_begin(kStShFwd, s);
-    for (int group = 0; group < 2; ++group) {
-        if (!group_enabled(d, group)) continue;
-        ShParams p;
-        p.d = d; p.in = in; p.binrec = (const BinRec *)(geom + L.bin);
-        p.rec = (float *)(geom + L.rec); p.grec = nullptr; p.RF = L.rec_floats; p.g = lsr_in_grads{}; p.group = group;
-        const int ks = group == 0 ? d.sh_coeffs * 3 : d.feat_sh_coeffs * d.feat_channels;
-        const size_t shm = (size_t)LSR_WAVE * ks * 4 + 16;
-        hipLaunchKernelGGL((k_sh<false>), dim3((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), dim3(LSR_WAVE), shm, s, p);
-    }
+    LSR_SH_DISPATCH(k_sh_fwd, degc, coff, grid, block, shm, s, p);
     prof_end(kStShFwd, s);
     return hipGetLastError();
+}
+
+template <int DEGC, int COFF>
+static void allow_big_lds(size_t shm) {
+    static bool done = false;
+    if (!done && shm > 65536) {
+        (void)hipFuncSetAttribute((const void *)k_sh_bwd<DEGC, COFF>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        done = true;
+    }
 }
 
 hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom, const char *grad,
@@ -257,21 +453,21 @@ hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const cha
     if (!group_enabled(d, 0) && !group_enabled(d, 1)) return hipSuccess;
     const GeomLayout L = geom_layout(d);
     const GradLayout R = grad_layout(d);
-    prof_begin(kStShBwd, s);
-    for (int group = 0; group < 2; ++group) {
-        if (!group_enabled(d, group)) continue;
-        ShParams p;
-        p.d = d; p.in = in; p.binrec = (const BinRec *)(geom + L.bin);
-        p.rec = (float *)const_cast<char *>(geom + L.rec); p.grec = (const float *)(grad + R.rec); p.RF = L.rec_floats; p.g = gin; p.group = group;
-        const int nch = group == 0 ? 3 : d.feat_channels;
-        const int ks = group == 0 ? d.sh_coeffs * 3 : d.feat_sh_coeffs * d.feat_channels;
-        const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), block(LSR_WAVE);
-        // (1) direction -> mean gradient (needs the coefficients, staged through LDS)
-        hipLaunchKernelGGL((k_sh<true>), grid, block, (size_t)LSR_WAVE * ks * 4 + 16, s, p);
-        // (2) coefficient gradients
-        const size_t shm = (size_t)kShViewChunk * LSR_WAVE * (kShBasisStride + (nch | 1)) * 4;
-        hipLaunchKernelGGL(k_sh_coef_backward, grid, dim3(256), shm, s, p);
+    ShParams p = make_params(d, in, L, geom);
+    p.grec = (const float *)(grad + R.rec); p.g = gin;
+    const int degc = p.has[0] ? d.sh_degree : -1, coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
+    const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), block(kShThreads);
+    const int cs = (coff + d.feat_channels) | 1;
+    const int area = std::max(p.offF + LSR_WAVE * p.ks[1], kShWaves * LSR_WAVE * (kShBasisC + kShBasisF));
+    const size_t shm = ((size_t)area + (size_t)kShWaves * LSR_WAVE * cs) * 4;
+    if (shm > 65536) {   // many direct channels next to an SH group
+        if (degc == 4) allow_big_lds<4, 3>(shm); else if (degc == 3) allow_big_lds<3, 3>(shm);
+        else if (degc == 2) allow_big_lds<2, 3>(shm); else if (degc == 1) allow_big_lds<1, 3>(shm);
+        else if (degc == 0) allow_big_lds<0, 3>(shm); else if (coff == 3) allow_big_lds<-1, 3>(shm);
+        else allow_big_lds<-1, 0>(shm);
     }
+    prof_begin(kStShBwd, s);
+    LSR_SH_DISPATCH(k_sh_bwd, degc, coff, grid, block, shm, s, p);
     prof_end(kStShBwd, s);
     return hipGetLastError();
 }

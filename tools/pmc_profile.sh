@@ -2,7 +2,7 @@
 # Collect hardware counters for the bench workload on the GPU box (run through gpurun).
 # Each --pmc set is its own rocprofv3 run (SQ: 8 slots, TCC: FETCH_SIZE uses 3, WRITE_SIZE 2);
 # never combined with sys/hip/hsa tracing.  Output: gpurun_out/pmc_<tag>/pass*/...csv
-# usage: tools/pmc_profile.sh <tag> [bench args...]
+# usage: tools/pmc_profile.sh <tag> [bench args...]      (PMC_CMD="python tools/bench_decoder.py" profiles another workload)
 set -u
 TAG=${1:-r01}; shift || true
 ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline}
@@ -17,6 +17,6 @@ for SET in \
   "WRITE_SIZE GRBM_GUI_ACTIVE" \
   "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" ; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/pass$i -o p -- python bench.py $ARGS > $OUT/pass$i.log 2>&1 || echo "pass $i failed: $(tail -2 $OUT/pass$i.log)"
+  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/pass$i -o p -- ${PMC_CMD:-python bench.py $ARGS} > $OUT/pass$i.log 2>&1 || echo "pass $i failed: $(tail -2 $OUT/pass$i.log)"
 done
 find $OUT -name "*.csv" | head -20
