@@ -9,7 +9,7 @@
 //   k_scatter   : every visible Gaussian writes (depth_bits<<32 | index) into each tile segment
 //                 it overlaps.  Slots come from a two-level reservation: LDS counters per block,
 //                 then ONE global atomic per (block, tile).
-//   k_sort_tiles: per-tile bitonic sort of the 64-bit keys in LDS.  Ascending (depth bits, index)
+//   k_sort_tiles: per-tile sort of the 64-bit keys in LDS (bucket sort, bitonic fallback).  Ascending (depth bits, index)
 //                 == the published stable sort by depth with ties in emission (= index) order,
 //                 so lists are bit-exact whatever order the scatter produced.
 #include "lsr_internal.h"
@@ -172,7 +172,7 @@ k_scatter(int G, int gx, int T, const BinRec *__restrict__ binrec,
 }
 
 // ------------------------------------------------------------------------------------------
-constexpr int kSortThreads = 256;
+constexpr int kSortThreads = 512;
 
 // One workgroup per (tile, view); list length n <= CAP, keys sorted inside LDS.
 //
@@ -190,7 +190,7 @@ template <int CAP>
 __global__ void __launch_bounds__(kSortThreads)
 k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
              uint32_t *__restrict__ point_list) {
-    constexpr int NB = CAP < 4096 ? CAP : 4096;          // buckets
+    constexpr int NB = CAP < 2048 ? CAP : 2048;          // buckets
     extern __shared__ uint64_t s_keys[];                  // [CAP] sorted keys
     uint32_t *s_cnt = (uint32_t *)(s_keys + CAP);         // [NB] histogram -> bucket end offsets
     __shared__ uint64_t s_red[2 * (kSortThreads / LSR_WAVE)];
@@ -204,9 +204,30 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
     const uint64_t *src = keys + start;
     if (n == 1) { if (tid == 0) point_list[start] = (uint32_t)src[0]; return; }
 
+    // ---- the list is read from memory ONCE, all loads of a thread in flight together; lists up
+    // to 4096 entries then live in registers for the range / histogram / scatter passes ----
+    constexpr bool REG = CAP <= 4096;
+    constexpr int PERK = REG ? CAP / kSortThreads : 1;
+    uint64_t kreg[PERK];
+    if (REG) {
+#pragma unroll
+        for (int q = 0; q < PERK; ++q) {
+            const uint32_t i = tid + q * kSortThreads;
+            kreg[q] = i < n ? src[i] : ~0ull;
+        }
+    }
     // ---- key range ----
     uint64_t kmin = ~0ull, kmax = 0ull;
-    for (uint32_t i = tid; i < n; i += kSortThreads) { const uint64_t k = src[i]; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+    if (REG) {
+#pragma unroll
+        for (int q = 0; q < PERK; ++q) {
+            const uint64_t k = kreg[q];
+            kmin = k < kmin ? k : kmin;
+            if (tid + q * kSortThreads < n) kmax = k > kmax ? k : kmax;
+        }
+    } else {
+        for (uint32_t i = tid; i < n; i += kSortThreads) { const uint64_t k = src[i]; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const uint64_t a = __shfl_xor(kmin, off), b = __shfl_xor(kmax, off);
@@ -227,7 +248,13 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
     const int shift = bits > LOGNB ? bits - LOGNB : 0;
 
     // ---- histogram, scan ----
-    for (uint32_t i = tid; i < n; i += kSortThreads) atomicAdd(&s_cnt[(uint32_t)((src[i] - kmin) >> shift)], 1u);
+    if (REG) {
+#pragma unroll
+        for (int q = 0; q < PERK; ++q)
+            if (tid + q * kSortThreads < n) atomicAdd(&s_cnt[(uint32_t)((kreg[q] - kmin) >> shift)], 1u);
+    } else {
+        for (uint32_t i = tid; i < n; i += kSortThreads) atomicAdd(&s_cnt[(uint32_t)((src[i] - kmin) >> shift)], 1u);
+    }
     __syncthreads();
     constexpr int PER = NB / kSortThreads;
     uint32_t loc[PER], sum = 0, mx = 0;
@@ -248,9 +275,15 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
         for (int q = 0; q < PER; ++q) { s_cnt[tid * PER + q] = run; run += loc[q]; }   // exclusive starts
         __syncthreads();
         // ---- scatter into buckets (s_cnt[b] ends up as the END of bucket b) ----
-        for (uint32_t i = tid; i < n; i += kSortThreads) {
-            const uint64_t k = src[i];
-            s_keys[atomicAdd(&s_cnt[(uint32_t)((k - kmin) >> shift)], 1u)] = k;
+        if (REG) {
+#pragma unroll
+            for (int q = 0; q < PERK; ++q)
+                if (tid + q * kSortThreads < n) s_keys[atomicAdd(&s_cnt[(uint32_t)((kreg[q] - kmin) >> shift)], 1u)] = kreg[q];
+        } else {
+            for (uint32_t i = tid; i < n; i += kSortThreads) {
+                const uint64_t k = src[i];
+                s_keys[atomicAdd(&s_cnt[(uint32_t)((k - kmin) >> shift)], 1u)] = k;
+            }
         }
         __syncthreads();
         // ---- finish inside each bucket ----
@@ -269,7 +302,13 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
         uint32_t npad = 2;
         while (npad < n) npad <<= 1;
         __syncthreads();
-        for (uint32_t i = tid; i < npad; i += kSortThreads) s_keys[i] = i < n ? src[i] : ~0ull;
+        if (REG) {
+#pragma unroll
+            for (int q = 0; q < PERK; ++q)
+                if (tid + q * kSortThreads < npad) s_keys[tid + q * kSortThreads] = kreg[q];   // padding = ~0
+        } else {
+            for (uint32_t i = tid; i < npad; i += kSortThreads) s_keys[i] = i < n ? src[i] : ~0ull;
+        }
         __syncthreads();
         for (uint32_t k = 2; k <= npad; k <<= 1) {
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -358,9 +397,9 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         if ((size_t)CAPV * 8 + 16384 > 65536)                                                    \
             (void)hipFuncSetAttribute((const void *)k_sort_tiles<CAPV>,                          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize,                \
-                                      CAPV * 8 + (CAPV < 4096 ? CAPV : 4096) * 4);               \
+                                      CAPV * 8 + (CAPV < 2048 ? CAPV : 2048) * 4);               \
         hipLaunchKernelGGL((k_sort_tiles<CAPV>), grid, dim3(kSortThreads),                       \
-                           (size_t)CAPV * 8 + (size_t)(CAPV < 4096 ? CAPV : 4096) * 4, s,        \
+                           (size_t)CAPV * 8 + (size_t)(CAPV < 2048 ? CAPV : 2048) * 4, s,        \
                            T, ts, (const uint64_t *)keys, plist);                                \
     } while (0)
         if (max_tile_pairs <= 1024) LSR_SORT(1024);
