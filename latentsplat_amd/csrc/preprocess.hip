@@ -28,7 +28,11 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
     extern __shared__ uint32_t s_hist[];
     // 64-byte records are staged here and stored by the whole block as one contiguous run
     // (lane-contiguous 16-byte stores) instead of 4 strided partial-line stores per thread.
-    __shared__ float4 s_rec[kPreThreads * 4];
+    // Layout [k][thread] with a row stride of kPreThreads + 4 float4: the per-thread stores (fixed k,
+    // consecutive threads) and the run-order loads (4 consecutive lanes = the 4 words of one
+    // record) are both bank-conflict free.
+    constexpr int kRecRow = kPreThreads + 4;
+    __shared__ float4 s_rec[kRecRow * 4];
     const bool staged = RF == 16;
     const int v = blockIdx.y;
     const int G = d.num_gaussians;
@@ -176,7 +180,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
         }
         if (staged) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s_rec[threadIdx.x * 4 + k] = rr[k];
+            for (int k = 0; k < 4; ++k) s_rec[k * kRecRow + threadIdx.x] = rr[k];
             __syncthreads();
             float4 *dst = (float4 *)(rec + ((size_t)v * G + chunk0) * 16);
             const int nrec = G - chunk0 < kPreThreads ? G - chunk0 : kPreThreads;
@@ -184,7 +188,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
             for (int k = 0; k < 4; ++k) {
                 const int idx = k * kPreThreads + threadIdx.x;      // float4 index inside the run
                 // culled Gaussians (view z == 0 in their staged record) are never read: skip them
-                if (idx < nrec * 4 && s_rec[(idx & ~3) + 1].z > 0.0f) dst[idx] = s_rec[idx];
+                if (idx < nrec * 4 && s_rec[kRecRow + (idx >> 2)].z > 0.0f) dst[idx] = s_rec[(idx & 3) * kRecRow + (idx >> 2)];
             }
             __syncthreads();
         }

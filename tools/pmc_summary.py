@@ -14,6 +14,30 @@ def short(name):
     return name[:60]
 
 
+def write_traffic_json(root, acc, path, kernel="lsr::k_render_fwd"):
+    """profiles/traffic_render_forward.json: HBM bytes per launch of the dominant kernel, read by
+    bench.py for roofline.traffic."""
+    import json
+    for k, counters in acc.items():
+        if not k.startswith(kernel):
+            continue
+        c = {n: v[0] / max(v[1], 1) for n, v in counters.items()}
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        fetch, write = c["FETCH_SIZE"], c["WRITE_SIZE"]
+        json.dump({
+            "kernel": "k_render_fwd", "instance": k,
+            "source": f"{root} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, mean per launch)",
+            "fetch_size_kib": fetch, "write_size_kib": write,
+            "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
+            "hbm_bytes_per_launch_uncorrected": (fetch + write) * 1024,
+            "note": "corrected = 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950 "
+                    "(FETCH_SIZE tallies 128-B requests at 64 B); the kernel's reads are 64-byte record gathers, "
+                    "for which the factor is uncalibrated, so the uncorrected figure is given too",
+        }, open(path, "w"), indent=1)
+        return
+
+
 def main():
     root = sys.argv[1]
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -26,6 +50,8 @@ def main():
                 a = acc[k][row["Counter_Name"]]
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1
+    if len(sys.argv) > 3 and sys.argv[2] == "--traffic-json":
+        write_traffic_json(root, acc, sys.argv[3])
     print(f"# PMC counters per launch (mean over launches), {root}\n")
     print("FETCH_SIZE / WRITE_SIZE are in KiB as reported; on gfx950 FETCH_SIZE under-counts wide")
     print("coalesced reads by 2x (MI355X_MICROARCH.md §HBM) — `hbm_read_corrected` doubles it.\n")
