@@ -76,7 +76,8 @@ def cpu_baseline_next_rows(budget_s=4.0):
     adapter_step / latent_step, forward + backward."""
     from oracle import adapter_oracle as ao
     from oracle import latent_oracle as lo
-    torch.set_num_threads(os.cpu_count())
+    threads = min(32, os.cpu_count())      # many small elementwise ops: more threads only thrash
+    torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(99)
     cams, rays, S = 2, 65536, 3
     E = torch.eye(4).repeat(cams, 1, 1)
@@ -106,7 +107,7 @@ def cpu_baseline_next_rows(budget_s=4.0):
         while time.perf_counter() - t0 < budget_s and n < 50:
             fn()
             n += 1
-        res[name] = dict(ms_per_step=1e3 * (time.perf_counter() - t0) / n, cores=os.cpu_count(), kind="port",
+        res[name] = dict(ms_per_step=1e3 * (time.perf_counter() - t0) / n, cores=threads, kind="port",
                          sample=f"{n} forward+backward passes of the torch-CPU oracle at the same shape")
     return res
 
