@@ -138,6 +138,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; it has to be the HIP runtime of the process, so make sure it
+    # is loaded before our library pulls in the system copy (two runtimes = "no device" at launch)
+    import torch  # noqa: F401
     if not os.path.exists(_SO):
         raise LsrError(
             f"{_SO} not found: the MI355X rasterizer extension has not been built. Run "
