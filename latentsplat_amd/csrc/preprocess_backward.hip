@@ -5,8 +5,10 @@
 // and back through the in-kernel scene scale.  (SH colour / latent-SH gradients: sh.hip.)
 // Also scatters the per-(view, Gaussian) opacity / feature / precomputed-colour gradients from the
 // packed records to the caller's tensors.
-// One thread owns one Gaussian for ALL views, so inputs shared between views (stride 0) get their
-// gradients summed in registers / thread-private read-modify-write, without atomics.
+// PARTS adjacent lanes own one Gaussian and split its views between them (lane part p takes views
+// p, p+PARTS, ...: PARTS x more waves in flight and shorter per-thread load chains than one thread
+// per Gaussian); gradients of inputs shared between views (stride 0) are summed in registers and
+// combined across the PARTS lanes with DPP quad permutes — no atomics, no read-modify-write.
 // Spec: SURVEY.md Appendix A.6.
 #include "lsr_internal.h"
 
@@ -23,32 +25,71 @@ struct PreBwdParams {
     lsr_in_grads g;
 };
 
+constexpr int kPreBwdFeat = 8;   // shared direct-feature gradients kept in registers up to this many channels
+
+// sum over the PARTS (1, 2 or 4) adjacent lanes of a quad
+template <int PARTS>
+__device__ __forceinline__ float quad_sum(float v) {
+    if (PARTS >= 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+    if (PARTS >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+    return v;
+}
+
+template <int PARTS>
 __global__ void __launch_bounds__(256)
 k_preprocess_bwd(PreBwdParams p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int part = gt % PARTS;
     const lsr_dims &d = p.d;
     const int G = d.num_gaussians;
-    if (i >= G) return;
+    const bool live = gt / PARTS < G;
+    const int i = live ? gt / PARTS : G - 1;     // idle lanes shadow the last Gaussian (they take part in the DPP sums)
     const int V = d.num_views;
     const int ce = d.cov_elems;
     float am[3] = {0, 0, 0}, ac[6] = {0, 0, 0, 0, 0, 0}, aop = 0.0f;  // accumulators for shared inputs
+    float af[kPreBwdFeat], acol[3] = {0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < kPreBwdFeat; ++c) af[c] = 0.0f;
     const int coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
+    const bool feat_direct = d.feat_channels > 0 && d.feat_mode == LSR_FEAT_DIRECT;
+    const bool feat_reg = feat_direct && d.vs_feat == 0 && d.feat_channels <= kPreBwdFeat;
+    const bool feat_rmw = feat_direct && d.vs_feat == 0 && !feat_reg;   // many shared channels: one lane, memory accumulate
 #pragma unroll 4
-    for (int v = 0; v < V; ++v) {
+    for (int v = (feat_rmw ? 0 : part); v < (live ? V : 0); v += (feat_rmw ? 1 : PARTS)) {
+        if (feat_rmw && part != 0) break;
         const size_t o = (size_t)v * G + i;
         const float *rc = p.rec + o * p.rec_floats;
         const float4 r0 = *(const float4 *)rc, r1 = *(const float4 *)(rc + 4);  // gx gy gA gB | gC go gz -
         // opacity / features / precomputed colours: plain pass-through of the record
         if (d.vs_opac != 0) p.g.opacities[(size_t)v * d.vs_opac + i] = r1.y; else aop += r1.y;
-        if (d.feat_channels > 0 && d.feat_mode == LSR_FEAT_DIRECT) {
+        if (feat_reg) {
+            if (p.rec_floats == 16) {   // the whole payload half of the record as two 16-byte loads
+                const float4 q0 = *(const float4 *)(rc + 8), q1 = *(const float4 *)(rc + 12);
+                const float pay[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                if (coff == 0) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) af[c] += pay[c];        // slots past the last channel are zero
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) af[c] += pay[3 + c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < kPreBwdFeat; ++c)
+                    if (c < d.feat_channels) af[c] += rc[8 + coff + c];
+            }
+        } else if (feat_direct) {
             float *gf = p.g.features + (size_t)v * d.vs_feat + (size_t)i * d.feat_channels;
             const bool first = d.vs_feat != 0 || v == 0;
             for (int c = 0; c < d.feat_channels; ++c) gf[c] = first ? rc[8 + coff + c] : gf[c] + rc[8 + coff + c];
         }
         if (d.color_mode == LSR_COLOR_PRECOMP) {
-            float *gcp = p.g.color + (size_t)v * d.vs_color + 3 * (size_t)i;
-            const bool first = d.vs_color != 0 || v == 0;
-            for (int c = 0; c < 3; ++c) gcp[c] = first ? rc[8 + c] : gcp[c] + rc[8 + c];
+            if (d.vs_color != 0) {
+                float *gcp = p.g.color + (size_t)v * d.vs_color + 3 * (size_t)i;
+                for (int c = 0; c < 3; ++c) gcp[c] = rc[8 + c];
+            } else {
+                for (int c = 0; c < 3; ++c) acol[c] += rc[8 + c];
+            }
         }
         float gm[3] = {0, 0, 0}, gc[6] = {0, 0, 0, 0, 0, 0};
         float m2x = 0.0f, m2y = 0.0f;
@@ -171,21 +212,52 @@ k_preprocess_bwd(PreBwdParams p) {
             o2[0] = m2x; o2[1] = m2y; o2[2] = 0.0f;
         }
     }
+    // ---- shared inputs: combine the PARTS lanes of the Gaussian, part 0 stores ----
+    const bool writer = live && part == 0;
     if (d.vs_means == 0) {
-        float *o3 = p.g.means3D + 3 * (size_t)i;
-        o3[0] = am[0]; o3[1] = am[1]; o3[2] = am[2];
-    }
-    if (d.vs_cov == 0) {
-        float *o6 = p.g.cov3D + (size_t)ce * (size_t)i;
-        if (ce == 9) {
-            o6[0] = ac[0]; o6[1] = ac[1]; o6[2] = ac[2]; o6[3] = 0.0f; o6[4] = ac[3]; o6[5] = ac[4];
-            o6[6] = 0.0f; o6[7] = 0.0f; o6[8] = ac[5];
-        } else {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) o6[k] = ac[k];
+        for (int k = 0; k < 3; ++k) am[k] = quad_sum<PARTS>(am[k]);
+        if (writer) {
+            float *o3 = p.g.means3D + 3 * (size_t)i;
+            o3[0] = am[0]; o3[1] = am[1]; o3[2] = am[2];
         }
     }
-    if (d.vs_opac == 0) p.g.opacities[i] = aop;
+    if (d.vs_cov == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ac[k] = quad_sum<PARTS>(ac[k]);
+        if (writer) {
+            float *o6 = p.g.cov3D + (size_t)ce * (size_t)i;
+            if (ce == 9) {
+                o6[0] = ac[0]; o6[1] = ac[1]; o6[2] = ac[2]; o6[3] = 0.0f; o6[4] = ac[3]; o6[5] = ac[4];
+                o6[6] = 0.0f; o6[7] = 0.0f; o6[8] = ac[5];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o6[k] = ac[k];
+            }
+        }
+    }
+    if (d.vs_opac == 0) {
+        aop = quad_sum<PARTS>(aop);
+        if (writer) p.g.opacities[i] = aop;
+    }
+    if (feat_reg) {
+#pragma unroll
+        for (int c = 0; c < kPreBwdFeat; ++c) af[c] = quad_sum<PARTS>(af[c]);
+        if (writer) {
+            float *gf = p.g.features + (size_t)i * d.feat_channels;
+#pragma unroll
+            for (int c = 0; c < kPreBwdFeat; ++c)
+                if (c < d.feat_channels) gf[c] = af[c];
+        }
+    }
+    if (d.color_mode == LSR_COLOR_PRECOMP && d.vs_color == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acol[c] = quad_sum<PARTS>(acol[c]);
+        if (writer) {
+            float *gcp = p.g.color + 3 * (size_t)i;
+            gcp[0] = acol[0]; gcp[1] = acol[1]; gcp[2] = acol[2];
+        }
+    }
 }
 
 hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
@@ -200,7 +272,11 @@ hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, c
     p.rec = (const float *)(grad + R.rec); p.rec_floats = R.rec_floats;
     p.g = gin;
     prof_begin(kStPreprocessBwd, s);
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((d.num_gaussians + 255) / 256), dim3(256), 0, s, p);
+    const int parts = d.num_views >= 4 ? 4 : (d.num_views >= 2 ? 2 : 1);
+    const dim3 grid((unsigned)(((int64_t)d.num_gaussians * parts + 255) / 256));
+    if (parts == 4) hipLaunchKernelGGL(k_preprocess_bwd<4>, grid, dim3(256), 0, s, p);
+    else if (parts == 2) hipLaunchKernelGGL(k_preprocess_bwd<2>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_preprocess_bwd<1>, grid, dim3(256), 0, s, p);
     prof_end(kStPreprocessBwd, s);
     return hipGetLastError();
 }
