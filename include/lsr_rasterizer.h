@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSR_ABI_VERSION 2
+#define LSR_ABI_VERSION 3
 #define LSR_TILE 16            /* tile edge in pixels (16x16 = the published algorithm's tile) */
 #define LSR_MAX_FEAT_CHANNELS 32
 #define LSR_MAX_SH_DEGREE 4
@@ -173,11 +173,15 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
                        void *img_ws, int64_t num_pairs, int32_t max_tile_pairs,
                        const lsr_outputs *out, lsr_stream_t stream);
 
-/* ---- backward. Needs the three workspaces of the matching forward, unmodified. Async. */
+/* ---- backward. Needs the three workspaces of the matching forward, unmodified, and the images
+ * that forward produced (`fwd`: colour / feature / depth are read wherever the corresponding
+ * gradient in `gout` is given; mask and radii are not used).  The compositing gradient walks the
+ * tile lists front to back like the forward and gets "everything behind this entry" as
+ * (rendered value - prefix), which is why the rendered values are an input.  Async. */
 int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws,
                  const void *bin_ws, const void *img_ws, int64_t num_pairs,
-                 const int32_t *radii, const lsr_out_grads *gout, void *grad_ws,
-                 const lsr_in_grads *gin, lsr_stream_t stream);
+                 const int32_t *radii, const lsr_outputs *fwd, const lsr_out_grads *gout,
+                 void *grad_ws, const lsr_in_grads *gin, lsr_stream_t stream);
 
 /* ---- optional measurement hook (bench.py): when enabled, every stage kernel is bracketed by
  * hipEvents on the caller's stream; lsr_profile_read() waits for them, returns the accumulated

@@ -171,7 +171,7 @@ def load():
     lib.lsr_forward_render.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, I32,
                                        C.POINTER(Outputs), P]
     lib.lsr_backward.restype = C.c_int
-    lib.lsr_backward.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, P,
+    lib.lsr_backward.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, P, C.POINTER(Outputs),
                                  C.POINTER(OutGrads), P, C.POINTER(InGrads), P]
     lib.lsr_profile_enable.argtypes = [C.c_int]
     lib.lsr_profile_stage_name.restype = C.c_char_p
@@ -193,7 +193,7 @@ def load():
     lib.lsr_ply_pack.argtypes = [I64, I32, C.POINTER(PlyInputs), P, P]
     lib.lsr_ply_write_host.restype = C.c_int
     lib.lsr_ply_write_host.argtypes = [C.c_char_p, P, I64]
-    if lib.lsr_abi_version() != 2:
+    if lib.lsr_abi_version() != 3:
         raise LsrError("liblsr_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -235,7 +235,7 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
 }
 
 int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, const void *bin_ws,
-                 const void *img_ws, int64_t num_pairs, const int32_t *radii,
+                 const void *img_ws, int64_t num_pairs, const int32_t *radii, const lsr_outputs *fwd,
                  const lsr_out_grads *gout, void *grad_ws, const lsr_in_grads *gin,
                  lsr_stream_t stream) {
     g_last_hip_error = 0;
@@ -243,8 +243,11 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
     if (rc) return rc;
     rc = check_inputs(d, in);
     if (rc) return rc;
-    if (!gout || !gin || !geom_ws || !img_ws || !grad_ws) return LSR_ENULL;
+    if (!gout || !gin || !geom_ws || !img_ws || !grad_ws || !fwd) return LSR_ENULL;
     if (d->num_gaussians == 0) return LSR_OK;
+    if ((gout->color && d->color_mode != LSR_COLOR_NONE && !fwd->color) || (gout->feature && d->feat_channels > 0 && !fwd->feature) ||
+        (gout->depth && !fwd->depth))
+        return LSR_ENULL;
     if (!radii || !gin->means3D || !gin->cov3D || !gin->opacities) return LSR_ENULL;
     if (d->color_mode != LSR_COLOR_NONE && !gin->color) return LSR_ENULL;
     if (d->feat_channels > 0 && !gin->features) return LSR_ENULL;
@@ -254,7 +257,7 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
     LSR_HIP(hipMemsetAsync(grad_ws, 0, grad_layout(*d).total, s));
     if (num_pairs > 0)
         LSR_STAGE("render_backward", s, launch_render_backward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs,
-                                       (const char *)img_ws, *gout, (char *)grad_ws, *gin, s));
+                                       (const char *)img_ws, *fwd, *gout, (char *)grad_ws, *gin, s));
     LSR_STAGE("preprocess_backward", s, launch_preprocess_backward(*d, *in, (const char *)geom_ws, radii, (const char *)grad_ws, *gin, s));
     LSR_STAGE("sh_backward", s, launch_sh_backward(*d, *in, (const char *)geom_ws, (const char *)grad_ws, *gin, s));
     return LSR_OK;

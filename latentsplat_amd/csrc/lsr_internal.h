@@ -149,8 +149,8 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
                                  hipStream_t s);
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                   const char *bin, int64_t num_pairs, const char *img,
-                                  const lsr_out_grads &gout, char *grad, const lsr_in_grads &gin,
-                                  hipStream_t s);
+                                  const lsr_outputs &fwd, const lsr_out_grads &gout, char *grad,
+                                  const lsr_in_grads &gin, hipStream_t s);
 hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                       const int32_t *radii, const char *grad,
                                       const lsr_in_grads &gin, hipStream_t s);

@@ -1,11 +1,19 @@
-// render_backward.hip — stage K7: per-pixel back-to-front gradient of the compositing, with the
-// same quadrant decomposition and culling as the forward (lsr_blend.h).
+// render_backward.hip — stage K7: per-pixel gradient of the compositing, with the same quadrant
+// decomposition and culling as the forward (lsr_blend.h).
 //
-// Per (entry, pixel): recompute alpha with the forward's exact arithmetic, divide it out of the
-// running transmittance, form dL/dalpha from the colour accumulated behind the entry, and emit
+// The lists are walked FRONT TO BACK like the forward (the published kernel goes back to front and
+// keeps, per pixel and channel, the colour accumulated behind the current entry: four operations
+// per channel per evaluation).  Here the only per-pixel state is the transmittance T and ONE scalar
+//   R_i = sum_{j>i} w_j (g . c_j)  [+ T_final (g . bg - g_mask)]  =  (g . C_rendered) - prefix_i,
+// seeded from the rendered images of the matching forward; with d_i = g . c_i
+//   dL/dalpha_i = T_i d_i - R_i / (1 - alpha_i),      R_i = R_{i-1} - w_i d_i,   T_{i+1} = T_i (1 - alpha_i)
+// i.e. one dot product and one FMA (payload gradient) per channel.  Half the per-pixel registers,
+// so 8-channel payloads also run 4 pixels per lane.  Cancellation in R only matters when the
+// remaining contribution is already ~1e-7 of the pixel's total — far below the 1e-4 tolerance.
+// Per (entry, pixel): recompute alpha with the forward's exact arithmetic and emit
 //   dL/d(x,y)_pixel, dL/d(A,B,C) conic, dL/d opacity, dL/d payload (rgb / features), dL/d z.
 // The per-lane arithmetic is branch-free: an invalid (pixel, entry) simply has alpha = G = 0, which
-// leaves the transmittance, the accumulated colour and every gradient sum unchanged.
+// leaves T, R and every gradient sum unchanged.
 // Per (entry, wave): contributions of the wave's 64*PXL pixels are summed with the transposed
 // butterfly of lsr_blend.h (permlane swaps + DPP, no LDS traffic), which leaves the total of
 // gradient slot s in lane 4s; ONE atomic instruction then adds the whole 64-byte gradient record
@@ -41,6 +49,7 @@ struct RenderBwdParams {
     const float *final_T;
     const uint32_t *n_contrib;
     const float *g_color, *g_feat, *g_mask, *g_depth;  // dL/d outputs (any may be NULL)
+    const float *f_color, *f_feat, *f_depth;           // images rendered by the matching forward
     float *rec;         // [V*G][rec_floats] packed gradient records (zeroed by the caller)
     int rec_floats;
 };
@@ -85,10 +94,9 @@ k_render_bwd(RenderBwdParams p) {
         const size_t vG = (size_t)v * p.G;
         const uint32_t start = p.tile_start[vt];
         const uint32_t own = owned_mask<PXL>(part);
-        const float *vw = p.views + (size_t)v * LSR_VIEW_FLOATS;
 
-        float pxf[PXL], pyf[PXL], Tr[PXL], tb[PXL], ddep[PXL], accd[PXL];
-        float dpix[PXL][NCHP], accum[PXL][NCHP];
+        float pxf[PXL], pyf[PXL], Tr[PXL], Rr[PXL], ddep[PXL];
+        float dpix[PXL][NCHP];
         uint32_t last[PXL];
         uint32_t maxlast = 0;
 #pragma unroll
@@ -99,37 +107,41 @@ k_render_bwd(RenderBwdParams p) {
             const bool inside = px < p.W && py < p.H;
             const size_t pix = (size_t)py * p.W + px, vp = (size_t)v * HW + pix;
             const float Tfin = inside ? p.final_T[vp] : 1.0f;
-            Tr[k] = Tfin;
+            Tr[k] = 1.0f;
             last[k] = inside ? p.n_contrib[vp] : 0u;
             maxlast = max(maxlast, last[k]);
-            float bd = 0.0f;
+            // R_0 = g . (rendered - T_final * bg)  +  T_final * (g . bg - g_mask)  =  g . rendered - T_final * g_mask
+            float r0 = 0.0f;
 #pragma unroll
-            for (int c = 0; c < NCHP; ++c) { dpix[k][c] = 0.0f; accum[k][c] = 0.0f; }
+            for (int c = 0; c < NCHP; ++c) dpix[k][c] = 0.0f;
             if (inside) {
                 if (p.has_color && p.g_color) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         dpix[k][c] = p.g_color[((size_t)v * 3 + c) * HW + pix];
-                        bd = __builtin_fmaf(vw[37 + c], dpix[k][c], bd);
+                        r0 = __builtin_fmaf(p.f_color[((size_t)v * 3 + c) * HW + pix], dpix[k][c], r0);
                     }
                 }
                 if (p.g_feat) {
 #pragma unroll
                     for (int c = 0; c < NCHP; ++c)
-                        if (c >= coff && c - coff < p.C) dpix[k][c] = p.g_feat[((size_t)v * p.C + (c - coff)) * HW + pix];
+                        if (c >= coff && c - coff < p.C) {
+                            dpix[k][c] = p.g_feat[((size_t)v * p.C + (c - coff)) * HW + pix];
+                            r0 = __builtin_fmaf(p.f_feat[((size_t)v * p.C + (c - coff)) * HW + pix], dpix[k][c], r0);
+                        }
                 }
-                if (p.g_mask) bd -= p.g_mask[vp];  // mask = 1 - T_final
+                if (p.g_mask) r0 = __builtin_fmaf(-Tfin, p.g_mask[vp], r0);  // mask = 1 - T_final
             }
-            tb[k] = Tfin * bd;   // T_final * (bg . dL/dcolour - dL/dmask)
             ddep[k] = (DEPTH_GRAD && inside) ? p.g_depth[vp] : 0.0f;
-            accd[k] = 0.0f;
+            if (DEPTH_GRAD && inside) r0 = __builtin_fmaf(p.f_depth[vp], ddep[k], r0);
+            Rr[k] = r0;
         }
         // wave-uniform upper bound of the entries any owned pixel has to consider
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) maxlast = max(maxlast, (uint32_t)__shfl_xor((int)maxlast, off));
         maxlast = __builtin_amdgcn_readfirstlane(maxlast);
 
-        for (int chunk = maxlast ? (int)((maxlast - 1) / LSR_WAVE) : -1; chunk >= 0; --chunk) {
+        for (int chunk = 0; (uint32_t)chunk * LSR_WAVE < maxlast; ++chunk) {
             const uint32_t rel = (uint32_t)chunk * LSR_WAVE + lane;  // 0-based position in the list
             uint32_t m = 0;
             if (rel < maxlast) {
@@ -151,8 +163,8 @@ k_render_bwd(RenderBwdParams p) {
             wave_lds_fence_bwd();
 
             while (todo) {
-                const int j = 63 - __builtin_clzll(todo);  // back to front
-                todo &= ~(1ull << j);
+                const int j = __builtin_ctzll(todo);  // front to back
+                todo &= todo - 1;
                 const float4 a = s_q0[j], b = s_q1[j];
                 const uint32_t pos = (uint32_t)chunk * LSR_WAVE + (uint32_t)j + 1u;
                 float pay[NCHP];
@@ -181,25 +193,23 @@ k_render_bwd(RenderBwdParams p) {
                     const bool vb = __builtin_amdgcn_inverse_ballot_w64(valid);
                     const float alpha = vb ? aclamp : 0.0f;
                     const float Gv = vb ? araw * inv_o : 0.0f;      // exp(power)
-                    const float rcp1m = __builtin_amdgcn_rcpf(1.0f - alpha);
-                    const float Tk = Tr[k] * rcp1m;  // transmittance in front of this entry
-                    Tr[k] = Tk;
+                    const float om = 1.0f - alpha;
+                    const float rcp1m = __builtin_amdgcn_rcpf(om);
+                    const float Tk = Tr[k];          // transmittance in front of this entry
                     const float w = alpha * Tk;
-                    float dL_dalpha = 0.0f;
+                    float dsum = 0.0f;               // g . c_i
 #pragma unroll
                     for (int c = 0; c < NCHP; ++c) {
-                        const float diff = pay[c] - accum[k][c];
-                        dL_dalpha = __builtin_fmaf(diff, dpix[k][c], dL_dalpha);
-                        accum[k][c] = __builtin_fmaf(alpha, diff, accum[k][c]);
+                        dsum = __builtin_fmaf(pay[c], dpix[k][c], dsum);
                         gpay[c] = __builtin_fmaf(w, dpix[k][c], gpay[c]);
                     }
                     if (DEPTH_GRAD) {
-                        const float diff = b.z - accd[k];
-                        dL_dalpha = __builtin_fmaf(diff, ddep[k], dL_dalpha);
-                        accd[k] = __builtin_fmaf(alpha, diff, accd[k]);
+                        dsum = __builtin_fmaf(b.z, ddep[k], dsum);
                         gz = __builtin_fmaf(w, ddep[k], gz);
                     }
-                    dL_dalpha = __builtin_fmaf(dL_dalpha, Tk, -tb[k] * rcp1m);
+                    Rr[k] = __builtin_fmaf(-w, dsum, Rr[k]);      // what is left behind this entry
+                    Tr[k] = Tk * om;
+                    const float dL_dalpha = __builtin_fmaf(Tk, dsum, -Rr[k] * rcp1m);
                     const float dL_dG = b.y * dL_dalpha;    // straight through the 0.99 clamp (A.6)
                     const float tA = Gv * dx * dL_dG, tC = Gv * dy * dL_dG;
                     sx = __builtin_fmaf(tA, a.z, __builtin_fmaf(tC, a.w, sx));     // -(dL/dx)
@@ -243,11 +253,11 @@ k_render_bwd(RenderBwdParams p) {
 static int pick_pxl_bwd(int nchp, int64_t tiles_total) {
     if (const char *e = getenv("LSR_PXL_BWD")) {
         const int x = atoi(e);
-        if (x == 1 || x == 2 || x == 4) return nchp > 12 ? 1 : ((nchp > 4 && x == 4) ? 2 : x);
+        if (x == 1 || x == 2 || x == 4) return nchp > 12 ? 1 : ((nchp > 8 && x == 4) ? 2 : x);
     }
     // aim for >= 4 waves on each of the 1024 SIMDs (the kernel is VALU bound and needs them)
     int pxl = tiles_total >= 4096 ? 4 : (tiles_total >= 2048 ? 2 : 1);
-    if (nchp > 4 && pxl == 4) pxl = 2;  // dpix + accum double the per-pixel register cost
+    if (nchp > 8 && pxl == 4) pxl = 2;  // per-pixel upstream gradients: PXL * NCHP registers
     if (nchp > 12) pxl = 1;
     return pxl;
 }
@@ -265,8 +275,8 @@ static void launch_variant(const RenderBwdParams &p, hipStream_t s) {
 
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                   const char *bin, int64_t num_pairs, const char *img,
-                                  const lsr_out_grads &gout, char *grad, const lsr_in_grads &gin,
-                                  hipStream_t s) {
+                                  const lsr_outputs &fwd, const lsr_out_grads &gout, char *grad,
+                                  const lsr_in_grads &gin, hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const ImgLayout I = img_layout(d);
     const BinLayout B = bin_layout(d, num_pairs, 0);
@@ -281,6 +291,7 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     p.point_list = (const uint32_t *)(bin + B.point_list);
     p.final_T = (const float *)(img + I.final_T); p.n_contrib = (const uint32_t *)(img + I.n_contrib);
     p.g_color = gout.color; p.g_feat = gout.feature; p.g_mask = gout.mask; p.g_depth = gout.depth;
+    p.f_color = fwd.color; p.f_feat = fwd.feature; p.f_depth = fwd.depth;
     p.rec = (float *)(grad + R.rec); p.rec_floats = R.rec_floats;
     p.queue = (uint32_t *)(grad + R.total - 256);   // inside the zeroed tail of the gradient workspace
     (void)gin;
@@ -296,7 +307,7 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
         else launch_variant<N, X, false, W>(p, s);                  \
     } while (0)
     if (nchp == 4) { if (pxl == 4) LSR_RB(4, 4, 16); else if (pxl == 2) LSR_RB(4, 2, 16); else LSR_RB(4, 1, 16); }
-    else if (nchp == 8) { if (pxl == 2) LSR_RB(8, 2, 16); else LSR_RB(8, 1, 16); }
+    else if (nchp == 8) { if (pxl == 4) LSR_RB(8, 4, 16); else if (pxl == 2) LSR_RB(8, 2, 16); else LSR_RB(8, 1, 16); }
     else if (nchp == 12) { if (pxl == 2) LSR_RB(12, 2, 16); else LSR_RB(12, 1, 16); }
     else LSR_RB(36, 1, 4);
 #undef LSR_RB

@@ -190,19 +190,22 @@ class _RasterizeViews(torch.autograd.Function):
         ctx.debug = debug
         ctx.m2d_shape = None if means2D is None else tuple(means2D.shape)
         ctx.has = (shs is not None, colors_precomp is not None, features is not None)
-        ctx.save_for_backward(views, means3D, cov3D, opacities,
-                              color if color is not None else views.new_empty(0),
-                              features if features is not None else views.new_empty(0))
         ctx.mark_non_differentiable(radii)
         empty = views.new_empty(0)
-        return (out_color if out_color is not None else empty,
+        outs = (out_color if out_color is not None else empty,
                 out_feat if out_feat is not None else empty, out_mask, out_depth, radii)
+        # the rendered images are inputs of the backward (lsr_backward's `fwd`)
+        ctx.save_for_backward(views, means3D, cov3D, opacities,
+                              color if color is not None else views.new_empty(0),
+                              features if features is not None else views.new_empty(0),
+                              outs[0], outs[1], out_depth)
+        return outs
 
     @staticmethod
     def backward(ctx, g_color, g_feat, g_mask, g_depth, _g_radii):
         lib = _lib.load()
         plan: _Plan = ctx.plan
-        views, means3D, cov3D, opacities, color, features = ctx.saved_tensors
+        views, means3D, cov3D, opacities, color, features, f_color, f_feat, f_depth = ctx.saved_tensors
         has_shs, has_cp, has_f = ctx.has
         dev = means3D.device
         d = plan.dims
@@ -225,12 +228,14 @@ class _RasterizeViews(torch.autograd.Function):
         d_m2d = torch.empty((V, G, 3), **f32)
         gradws = torch.empty(lib.lsr_grad_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
         gout = OutGrads(_ptr(g_color), _ptr(g_feat), _ptr(g_mask), _ptr(g_depth))
+        fwd = Outputs(_ptr(f_color) if f_color.numel() else None, _ptr(f_feat) if f_feat.numel() else None,
+                      None, _ptr(f_depth), None)
         gin = InGrads(_ptr(d_means), _ptr(d_cov), _ptr(d_opac), _ptr(d_color), _ptr(d_feat), _ptr(d_m2d))
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
             _lib.check(lib.lsr_backward(C.byref(d), C.byref(inp), _ptr(plan.geom), _ptr(plan.bin),
-                                        _ptr(plan.img), plan.num_pairs, _ptr(plan.radii), C.byref(gout),
-                                        _ptr(gradws), C.byref(gin), stream), "lsr_backward")
+                                        _ptr(plan.img), plan.num_pairs, _ptr(plan.radii), C.byref(fwd),
+                                        C.byref(gout), _ptr(gradws), C.byref(gin), stream), "lsr_backward")
             if ctx.debug:
                 torch.cuda.synchronize(dev)
         if ctx.m2d_shape is None or not ctx.needs_input_grad[2]:
