@@ -358,22 +358,36 @@ def main():
     render_ms, render_n = prof["render_forward"]
     render_ms_per_launch = render_ms / max(render_n, 1)
     roofline = None
+    roofline_valu = None
     path = None
     if P is not None:
         # algorithmic bytes of ONE render launch (V views): sorted index + gathered record per pair,
         # every output word once (SURVEY.md §8(d) terms P*b_rec + H*W*b_out, plus the 4-byte index)
         render_bytes = P * (4 + b_rec) + V * S * S * b_out
         achieved = render_bytes / (render_ms_per_launch * 1e-3) / 1e9
-        traffic = None
+        traffic, tinfo = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_render_forward.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tinfo = json.load(open(tpath))
+                traffic = tinfo.get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic, tinfo = None, None
         roofline = dict(bound="hbm", kernel="k_render_fwd", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                         algorithmic_bytes_per_launch=render_bytes, launch_ms=render_ms_per_launch)
+        # The kernel is bound by f32 VALU issue, not by HBM: report that ceiling next to the required
+        # HBM figure.  Instruction counts come from the committed PMC pass (same workload), the
+        # launch time is this run's; one wave64 VALU instruction occupies a SIMD for 4 cycles
+        # (transcendentals 16), 1024 SIMDs at 2.4 GHz.
+        if tinfo and tinfo.get("valu_insts_per_launch"):
+            n_valu, n_trans = tinfo["valu_insts_per_launch"], tinfo.get("valu_trans_insts_per_launch") or 0.0
+            issue_cycles = 4.0 * (n_valu - n_trans) + 16.0 * n_trans
+            peak_cycles = 1024 * 2.4e9 * render_ms_per_launch * 1e-3
+            roofline_valu = dict(bound="valu_issue", kernel="k_render_fwd", valu_insts_per_launch=n_valu,
+                                 achieved=n_valu / (render_ms_per_launch * 1e-3) / 1e9, unit="G wave-instr/s",
+                                 peak=1024 * 2.4e9 / 4 / 1e9, frac=issue_cycles / peak_cycles,
+                                 source="profiles/traffic_render_forward.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_INSTS_VALU_TRANS_F32)")
         # whole forward path per view against the same roofline (SURVEY §8(d) B_fwd)
         B_fwd_step = V * G * b_in + g_vis * b_rec + P * 16 + P * b_rec + V * S * S * b_out
         step_s = el_fwd / args.steps
@@ -407,7 +421,7 @@ def main():
                        "parallelism": f"replicas x{world} (one scene per rank, no data-path collective)"},
             "ms_per_view_fwd": 1e3 * el_fwd / (V * args.steps),
             "kernel_ms_per_launch": {k: (ms / n if n else None) for k, (ms, n) in prof.items()},
-            "fwdbwd": fb, "decoder_step": dec_step, "adapter_step": adapter_step, "latent_step": latent_step, "roofline": roofline, "roofline_path": path, "cpu_baseline": cpu,
+            "fwdbwd": fb, "decoder_step": dec_step, "adapter_step": adapter_step, "latent_step": latent_step, "roofline": roofline, "roofline_valu": roofline_valu, "roofline_path": path, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if dist is not None:
