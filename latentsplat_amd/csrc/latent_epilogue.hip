@@ -68,7 +68,13 @@ __global__ __launch_bounds__(kLatentThreads) void k_latent_fwd(lsr_latent_dims d
         if (!out.skip) return;
         const float *src = in.color + ((size_t)v * 3 + plane) * HW;
         float *dst = out.skip + ((size_t)v * (cc + C) + plane) * HW;
-        for (int i = own_lo * W + threadIdx.x; i < own_hi * W; i += kLatentThreads) dst[i] = src[i];
+        if ((W & 3) == 0) {
+            const float4 *s4 = (const float4 *)src;
+            float4 *d4 = (float4 *)dst;
+            for (int i = (own_lo * W >> 2) + threadIdx.x; i < (own_hi * W >> 2); i += kLatentThreads) d4[i] = s4[i];
+        } else {
+            for (int i = own_lo * W + threadIdx.x; i < own_hi * W; i += kLatentThreads) dst[i] = src[i];
+        }
         return;
     }
     const int c = plane - cc;
@@ -87,6 +93,55 @@ __global__ __launch_bounds__(kLatentThreads) void k_latent_fwd(lsr_latent_dims d
     ty.lo = ty.hi = own_lo;
     if (want_z) ty = aa_taps(band, (float)H / (float)d.out_height, H);
     const int y0 = want_z ? min(own_lo, ty.lo) : own_lo, y1 = want_z ? max(own_hi, ty.hi) : own_hi;
+    const float var_lo = expf(d.logvar_min), var_hi = expf(d.logvar_max);
+    // one element: sample value s (and the clamped logvar on request)
+    auto sample_of = [&](float m, float raw, float nz, bool want_lv, float &lv_out) -> float {
+        float s = m;
+        if (d.logvar_mode == LSR_LOGVAR_FROM_MASK) {
+            // std = exp(clamp(log(1 - m)) / 2) = sqrt(clamp(1 - m, e^min, e^max)): no log / exp per
+            // element; the logvar itself is only needed on the own rows of one channel
+            const float om = 1.0f - raw;
+            if (want_lv) lv_out = clamp_keep_nan(__logf(om), d.logvar_min, d.logvar_max);
+            if (noise) s += (om < 0.0f ? __builtin_nanf("") : __fsqrt_rn(clamp_keep_nan(om, var_lo, var_hi))) * nz;
+        } else {
+            const float lv = clamp_keep_nan(raw, d.logvar_min, d.logvar_max);
+            if (want_lv) lv_out = lv;
+            if (noise) s += __expf(0.5f * lv) * nz;
+        }
+        return s;
+    };
+    const int tpr = W >> 2;                              // threads per row with 16-byte accesses
+    if ((W & 3) == 0 && tpr <= kLatentThreads && kLatentThreads % tpr == 0) {
+        // ---- vector path: a thread owns 4 adjacent columns; kLatentThreads / tpr rows in flight ----
+        const int rl = threadIdx.x / tpr, cg = threadIdx.x - rl * tpr, nrl = kLatentThreads / tpr;
+        float4 a4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int y = y0 + rl; y < y1; y += nrl) {
+            const bool own = y >= own_lo && y < own_hi;
+            const float wy = want_z ? aa_weight(ty, y) : 0.0f;
+            const size_t i4 = ((size_t)y * W >> 2) + cg;
+            const float4 m = ((const float4 *)mean)[i4];
+            const bool need_lv = noise || (lvout && own);
+            const float4 raw = need_lv ? ((const float4 *)lvsrc)[i4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float4 nz = noise ? ((const float4 *)noise)[i4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float4 lv = make_float4(0.0f, 0.0f, 0.0f, 0.0f), s4;
+            const bool wl = lvout && own;
+            s4.x = sample_of(m.x, raw.x, nz.x, wl, lv.x); s4.y = sample_of(m.y, raw.y, nz.y, wl, lv.y);
+            s4.z = sample_of(m.z, raw.z, nz.z, wl, lv.z); s4.w = sample_of(m.w, raw.w, nz.w, wl, lv.w);
+            if (wl) ((float4 *)lvout)[i4] = lv;
+            if (own && sample) ((float4 *)sample)[i4] = s4;
+            a4.x += wy * s4.x; a4.y += wy * s4.y; a4.z += wy * s4.z; a4.w += wy * s4.w;
+        }
+        if (!want_z) return;
+        // column sums: add the row lanes through LDS (rl = 0 stores, the others add in turn)
+        for (int r = 0; r < nrl; ++r) {
+            if (rl == r) {
+                float4 *c4 = (float4 *)col + cg;
+                if (r == 0) *c4 = a4;
+                else { float4 t = *c4; t.x += a4.x; t.y += a4.y; t.z += a4.z; t.w += a4.w; *c4 = t; }
+            }
+            __syncthreads();
+        }
+    } else {
     float acc[kLatentMaxCols] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 4
     for (int y = y0; y < y1; ++y) {                      // own rows and filter window overlap: one contiguous range
@@ -97,14 +152,10 @@ __global__ __launch_bounds__(kLatentThreads) void k_latent_fwd(lsr_latent_dims d
             const int x = threadIdx.x + k * kLatentThreads;
             if (x >= W) break;
             const size_t i = (size_t)y * W + x;
-            float s = mean[i];
-            if (noise || (lvout && own)) {
-                float lv = lvsrc[i];
-                if (d.logvar_mode == LSR_LOGVAR_FROM_MASK) lv = logf(1.0f - lv);
-                lv = clamp_keep_nan(lv, d.logvar_min, d.logvar_max);
-                if (lvout && own) lvout[i] = lv;
-                if (noise) s += expf(0.5f * lv) * noise[i];
-            }
+            const bool need_lv = noise || (lvout && own);
+            float lv = 0.0f;
+            const float s = sample_of(mean[i], need_lv ? lvsrc[i] : 0.0f, noise ? noise[i] : 0.0f, lvout && own, lv);
+            if (lvout && own) lvout[i] = lv;
             if (own && sample) sample[i] = s;
             acc[k] += wy * s;
         }
@@ -116,6 +167,7 @@ __global__ __launch_bounds__(kLatentThreads) void k_latent_fwd(lsr_latent_dims d
         if (x < W) col[x] = acc[k];
     }
     __syncthreads();
+    }
     const float sx = (float)W / (float)d.out_width;
     float *zrow = out.z + (((size_t)v * C + c) * d.out_height + band) * d.out_width;
     for (int ox = threadIdx.x; ox < d.out_width; ox += kLatentThreads) {
