@@ -104,16 +104,6 @@ inline GradLayout grad_layout(const lsr_dims &d) {
     return L;
 }
 
-// Multiplier for the tile-order permutation t -> (t * stride) % T: about 0.618 T, coprime with T.
-inline int coprime_stride(int T) {
-    if (T <= 2) return 1;
-    auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
-    int s = (int)(0.6180339887 * T);
-    if (s < 1) s = 1;
-    while (gcd(s, T) != 1) ++s;
-    return s % T ? s % T : 1;
-}
-
 // Compositing work items: one wave renders the quadrants in `own` of one (view, tile).
 //   item = (view*T + tile) | own << 28.  k_tile_scan emits them costliest-first.  When there are
 //   fewer tiles than wave slots every tile is split into 2 or 4 items (disjoint quadrant sets) to
