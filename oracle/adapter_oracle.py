@@ -14,7 +14,7 @@ Gaussians, written against torch tensors on the CPU so that autograd provides th
   * gaussian_adapter.py:101-102                                          means
 
 Parity status: PINNED — tests/test_adapter_cpu.py checks this file against
-tests/golden/adapter_*.npz, which tools/make_golden_adapter.py produced by importing and running
+tests/golden/adapter_*.npz, which tests/golden/make_golden_adapter.py produced by importing and running
 the reference's own GaussianAdapter (forward and autograd backward) in the build container.
 """
 from __future__ import annotations

@@ -11,7 +11,7 @@ rasterizer and the VAE decoder (paths relative to /root/reference):
 
 Parity status: PINNED for sample / logvar / skip (tests/golden/latent_*.npz are produced by the
 reference's own DecoderSplattingCUDA.render_to_decoder_output + DiagonalGaussianDistribution,
-tools/make_golden_latent.py).  `rescale` is torchvision's tensor `resize(antialias=True)`;
+tests/golden/make_golden_latent.py).  `rescale` is torchvision's tensor `resize(antialias=True)`;
 torchvision is not installed in the build image, so the anchor is the ATen operator it dispatches
 to — `torch.nn.functional.interpolate(mode="bilinear", align_corners=False, antialias=True)` —
 called here and when generating the fixtures.

@@ -7,7 +7,7 @@ torch wrapper (``OracleRasterizer``) so the oracle can stand in for
 (/root/reference/src/model/decoder/cuda_splatting.py:132-158) is imported to generate golden
 fixtures, and so ``bench.py`` can time it as the ``cpu_baseline`` leg.
 
-Only ``tests/``, ``__graft_entry__.smoke()``, ``tools/make_golden.py`` and ``bench.py``'s
+Only ``tests/``, ``__graft_entry__.smoke()``, ``tests/golden/make_golden.py`` and ``bench.py``'s
 cpu_baseline leg may import this module.
 """
 from __future__ import annotations

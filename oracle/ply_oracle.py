@@ -7,7 +7,7 @@ little-endian PLY layout plyfile writes.
 
 Parity status: PINNED — tests/golden/ply_export.npz holds the `elements` array the reference's own
 `export_ply` handed to plyfile (captured with a stand-in `plyfile` module by
-tools/make_golden_ply.py, plyfile itself is not installed in the build image).
+tests/golden/make_golden_ply.py, plyfile itself is not installed in the build image).
 """
 from __future__ import annotations
 

@@ -5,7 +5,7 @@ forward and autograd backward — on seeded inputs shaped the way the encoder ca
 (src/model/encoder/encoder_epipolar.py:184-193: cameras (b v 1 1 1 ..), rows (b v r srf 1 ..),
 depths (b v r srf spp)).  Only the vectors travel; nothing of the reference is copied.
 
-Stubs: jaxtyping / e3nn placeholders as in tools/make_golden.py; ``rotate_sh`` (e3nn Wigner-D,
+Stubs: jaxtyping / e3nn placeholders as in tests/golden/make_golden.py; ``rotate_sh`` (e3nn Wigner-D,
 not installable here) is replaced by the identity — the geometry outputs pinned here (means,
 covariances, scales, rotations, opacities and their gradients) do not depend on it.
 """
@@ -18,10 +18,10 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 CASES = {
     # name: (b, v, h, w, srf, spp, color_deg, feat_deg, feat_ch, scale_min, scale_max)

@@ -1,5 +1,5 @@
 """Gaussian adapter tail, CPU side: the oracle restatement is pinned against
-vectors produced by the reference's own GaussianAdapter (tools/make_golden_adapter.py), and the
+vectors produced by the reference's own GaussianAdapter (tests/golden/make_golden_adapter.py), and the
 host mirror's non-kernel logic matches them."""
 import glob
 import os
