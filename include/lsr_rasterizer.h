@@ -187,7 +187,9 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws,
  * hipEvents on the caller's stream; lsr_profile_read() waits for them, returns the accumulated
  * milliseconds and launch counts per stage since the previous read, and resets the totals.
  * Arrays must hold lsr_profile_num_stages() entries. Not thread-safe; one instance per process,
- * matching the reference's one-rasterizer-per-DDP-process use. */
+ * matching the reference's one-rasterizer-per-DDP-process use.
+ * on = 0: off; 1: every stage; otherwise a bit mask, bit (s + 1) enables stage s only (two event
+ * packets per enabled stage and launch are the whole cost). */
 int lsr_profile_enable(int on);
 int lsr_profile_num_stages(void);
 const char *lsr_profile_stage_name(int stage);

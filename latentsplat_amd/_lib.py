@@ -199,8 +199,17 @@ def load():
     return lib
 
 
-def profile_enable(on: bool) -> None:
-    load().lsr_profile_enable(1 if on else 0)
+def profile_enable(on, only: tuple = ()) -> None:
+    """on: all stages; only=("render_forward", ...): just those stages (two event packets each)."""
+    lib = load()
+    if only:
+        names = [lib.lsr_profile_stage_name(i).decode() for i in range(lib.lsr_profile_num_stages())]
+        mask = 0
+        for n in only:
+            mask |= 1 << (names.index(n) + 1)
+        lib.lsr_profile_enable(mask)
+    else:
+        lib.lsr_profile_enable(1 if on else 0)
 
 
 def profile_read() -> dict:

@@ -15,7 +15,8 @@ static thread_local int g_last_hip_error = 0;
 // ---- per-stage timing with hipEvents recorded on the caller's stream -----------------------
 namespace {
 struct Prof {
-    bool on = false;
+    unsigned on = 0;                                    // 0 off, 1 all stages, else bit (s + 1) = stage s
+    bool wants(int stage) const { return on == 1u || ((on >> (stage + 1)) & 1u); }
     std::vector<hipEvent_t> pool;                       // free events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[lsr::kNumStages];
     hipEvent_t open_ev[lsr::kNumStages] = {};
@@ -31,13 +32,13 @@ struct Prof {
 Prof g_prof;
 }  // namespace
 void lsr::prof_begin(int stage, hipStream_t s) {
-    if (!g_prof.on) return;
+    if (!g_prof.wants(stage)) return;
     hipEvent_t e = g_prof.get();
     (void)hipEventRecord(e, s);
     g_prof.open_ev[stage] = e;
 }
 void lsr::prof_end(int stage, hipStream_t s) {
-    if (!g_prof.on || !g_prof.open_ev[stage]) return;
+    if (!g_prof.open_ev[stage]) return;
     hipEvent_t e = g_prof.get();
     (void)hipEventRecord(e, s);
     g_prof.pending[stage].push_back({g_prof.open_ev[stage], e});
@@ -117,7 +118,7 @@ extern "C" {
 int lsr_abi_version(void) { return LSR_ABI_VERSION; }
 
 int lsr_profile_enable(int on) {
-    g_prof.on = on != 0;
+    g_prof.on = (unsigned)on;
     return LSR_OK;
 }
 int lsr_profile_num_stages(void) { return lsr::kNumStages; }
