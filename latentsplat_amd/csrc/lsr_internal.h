@@ -61,10 +61,10 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     const size_t VG = (size_t)d.num_views * (size_t)d.num_gaussians;
     const size_t VT = (size_t)d.num_views * (size_t)num_tiles(d);
     size_t o = 0;
-    L.header = o; o += 256;
     L.rec_floats = rec_floats(d);
     L.rec = o; o = align_up(o + VG * (size_t)L.rec_floats * 4);
     L.bin = o; o = align_up(o + VG * sizeof(BinRec));
+    L.header = o; o += 256;                        // header .. tile_cursor are cleared by ONE memset per forward
     L.tile_count = o; o = align_up(o + VT * 4);
     L.tile_cost = o; o = align_up(o + VT * 4);     // compositing work estimate per tile (see k_preprocess)
     L.tile_cursor = o; o = align_up(o + VT * 4);   // adjacent to tile_count: one memset clears both

@@ -207,9 +207,7 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     const GeomLayout L = geom_layout(d);
     const int T = (int)num_tiles(d);
     // zero header + tile_count + tile_cursor (adjacent)
-    hipError_t e = hipMemsetAsync(geom + L.header, 0, 256, s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(geom + L.tile_count, 0, L.tile_start - L.tile_count, s);
+    hipError_t e = hipMemsetAsync(geom + L.header, 0, L.tile_start - L.header, s);
     if (e != hipSuccess) return e;
     if (d.num_gaussians == 0) return hipSuccess;
     dim3 grid((d.num_gaussians + kPreThreads * kPreItems - 1) / (kPreThreads * kPreItems), d.num_views);

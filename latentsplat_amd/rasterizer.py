@@ -225,7 +225,8 @@ class _RasterizeViews(torch.autograd.Function):
         d_opac = torch.empty_like(opacities)
         d_color = torch.empty_like(color) if (has_shs or has_cp) else None
         d_feat = torch.empty_like(features) if has_f else None
-        d_m2d = torch.empty((V, G, 3), **f32)
+        want_m2d = ctx.m2d_shape is not None and ctx.needs_input_grad[2]
+        d_m2d = torch.empty((V, G, 3), **f32) if want_m2d else None   # 12 B per (view, Gaussian) nobody reads otherwise
         gradws = torch.empty(lib.lsr_grad_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
         gout = OutGrads(_ptr(g_color), _ptr(g_feat), _ptr(g_mask), _ptr(g_depth))
         fwd = Outputs(_ptr(f_color) if f_color.numel() else None, _ptr(f_feat) if f_feat.numel() else None,
@@ -238,7 +239,7 @@ class _RasterizeViews(torch.autograd.Function):
                                         C.byref(gout), _ptr(gradws), C.byref(gin), stream), "lsr_backward")
             if ctx.debug:
                 torch.cuda.synchronize(dev)
-        if ctx.m2d_shape is None or not ctx.needs_input_grad[2]:
+        if not want_m2d:
             d_m2d = None
         elif len(ctx.m2d_shape) == 2:  # one (G,3) tensor shared by the views
             d_m2d = d_m2d.sum(0) if V > 1 else d_m2d[0]
@@ -271,8 +272,6 @@ def rasterize_views(views: Tensor, image_height: int, image_width: int, sh_degre
         from math import isqrt
         feat_sh_degree = isqrt(feature_sh.shape[-1]) - 1
         features = feature_sh
-    if means2D is None:
-        means2D = torch.zeros((V, means3D.shape[-2], 3), dtype=torch.float32, device=means3D.device)
     color, feat, mask, depth, radii = _RasterizeViews.apply(
         views, means3D, means2D, cov3D_precomp, opacities, shs, colors_precomp, features,
         int(image_height), int(image_width), int(sh_degree), bool(debug), int(feat_sh_degree),
