@@ -27,7 +27,9 @@
  *
  * Plain C: pointers and sizes only, no torch / HIP types in the signatures.  All data pointers
  * are DEVICE pointers unless the name ends in `_host`.  All functions return 0 on success or a
- * negative LSR_E* code; nothing here throws.  The library never allocates device memory.
+ * negative LSR_E* code; nothing here throws.  The library never allocates device memory (its one
+ * allocation is a 64-byte pinned host buffer per calling thread, through which lsr_forward_prepare
+ * receives the pair count without a copy command).
  */
 #ifndef LSR_RASTERIZER_H
 #define LSR_RASTERIZER_H

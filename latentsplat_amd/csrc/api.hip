@@ -206,10 +206,30 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
     hipStream_t s = (hipStream_t)stream;
     char *geom = (char *)geom_ws;
     LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, s));
-    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, s));
+    // Pair count and longest list come back through a 64-byte pinned, device-mapped host buffer that
+    // k_tile_scan writes directly (one per host thread, allocated on first use; the library's only
+    // allocation and it is host memory).  Without it: a device-to-host copy command.
+    static thread_local uint32_t *h_hdr = nullptr, *h_hdr_dev = nullptr;
+    static thread_local bool h_tried = false;
+    if (!h_tried) {
+        h_tried = true;
+        void *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
+            hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            h_hdr = (uint32_t *)hp; h_hdr_dev = (uint32_t *)dp;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, h_hdr_dev, s));
     uint32_t hdr[2] = {0, 0};
-    LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));
-    LSR_HIP(hipStreamSynchronize(s));
+    if (h_hdr) {
+        LSR_HIP(hipStreamSynchronize(s));
+        hdr[0] = h_hdr[0]; hdr[1] = h_hdr[1];
+    } else {
+        LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));
+        LSR_HIP(hipStreamSynchronize(s));
+    }
     *num_pairs_host = (int64_t)hdr[0];
     *max_tile_pairs_host = (int32_t)hdr[1];
     return LSR_OK;

@@ -21,7 +21,7 @@ constexpr int kScanThreads = 1024;
 
 __global__ void __launch_bounds__(kScanThreads)
 k_tile_scan(const uint32_t *__restrict__ count, const uint32_t *__restrict__ cost, uint32_t *__restrict__ start, uint32_t *header,
-            uint32_t *__restrict__ order, uint32_t *__restrict__ lpt, int N, int force_base, int limit_pct) {
+            uint32_t *host_mirror, uint32_t *__restrict__ order, uint32_t *__restrict__ lpt, int N, int force_base, int limit_pct) {
     __shared__ uint32_t s_sum[kScanThreads];
     __shared__ uint32_t s_max[kScanThreads];
     const int tid = threadIdx.x;
@@ -40,7 +40,12 @@ k_tile_scan(const uint32_t *__restrict__ count, const uint32_t *__restrict__ cos
     }
     uint32_t run = s_sum[tid] - sum;  // exclusive prefix of this thread's chunk
     for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
-    if (tid == kScanThreads - 1) { start[N] = s_sum[tid]; header[kHdrPairs] = s_sum[tid]; header[kHdrMaxTile] = s_max[tid]; }
+    if (tid == kScanThreads - 1) {
+        start[N] = s_sum[tid]; header[kHdrPairs] = s_sum[tid]; header[kHdrMaxTile] = s_max[tid];
+        // the two numbers the host is waiting for go straight into its (mapped, pinned) memory:
+        // no copy command between this kernel and the stream synchronisation
+        if (host_mirror) { host_mirror[0] = s_sum[tid]; host_mirror[1] = s_max[tid]; }
+    }
     // ---- work items, costliest first: counting sort on kScanThreads classes of the per-tile work
     // estimate accumulated by k_preprocess (list length is a poor proxy: the work per entry depends
     // on how many quadrants its footprint reaches) ----
@@ -102,13 +107,13 @@ k_tile_scan(const uint32_t *__restrict__ count, const uint32_t *__restrict__ cos
     }
 }
 
-hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s) {
+hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror, hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const int N = d.num_views * (int)num_tiles(d);
     prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
                        (const uint32_t *)(geom + L.tile_count), (const uint32_t *)(geom + L.tile_cost), (uint32_t *)(geom + L.tile_start),
-                       (uint32_t *)(geom + L.header), (uint32_t *)(geom + L.tile_order), (uint32_t *)(geom + L.tile_lpt), N,
+                       (uint32_t *)(geom + L.header), host_mirror, (uint32_t *)(geom + L.tile_order), (uint32_t *)(geom + L.tile_lpt), N,
                        getenv("LSR_SPLIT") ? atoi(getenv("LSR_SPLIT")) : 0,
                        getenv("LSR_LIMIT") ? atoi(getenv("LSR_LIMIT")) : 100000);
     prof_end(kStTileScan, s);

@@ -125,7 +125,7 @@ void note_hip_error(int hip_error);   // what lsr_last_hip_error() returns for t
 // ---- stage launchers (defined one per .hip file) ----
 hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii,
                              hipStream_t s);
-hipError_t launch_tile_scan(const lsr_dims &d, char *geom, hipStream_t s);
+hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror, hipStream_t s);
 hipError_t launch_build_views(int V, const float *extrinsics, const float *intrinsics, const float *near,
                               const float *far, const float *bg, int bg_stride, int scale_invariant,
                               float *out, hipStream_t s);
