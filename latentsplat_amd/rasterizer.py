@@ -166,16 +166,19 @@ class _RasterizeViews(torch.autograd.Function):
         radii = torch.empty((V, G), dtype=torch.int32, device=dev)
         npairs, maxtile = C.c_int64(0), C.c_int32(0)
         with torch.cuda.device(dev):
-            _lib.check(lib.lsr_forward_prepare(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii),
-                                               C.byref(npairs), C.byref(maxtile), stream),
-                       "lsr_forward_prepare")
-            binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), npairs.value, maxtile.value), **u8)
+            # everything that does not depend on the pair count is allocated BEFORE prepare(): the GPU
+            # idles between prepare's synchronisation and the launches of render(), so that window
+            # should hold as little host work as possible
             f32 = dict(dtype=torch.float32, device=dev)
             out_color = torch.empty((V, 3, H, W), **f32) if color is not None else None
             out_feat = torch.empty((V, Cf, H, W), **f32) if Cf else None
             out_mask = torch.empty((V, H, W), **f32)
             out_depth = torch.empty((V, H, W), **f32)
             outs = Outputs(_ptr(out_color), _ptr(out_feat), _ptr(out_mask), _ptr(out_depth), _ptr(radii))
+            _lib.check(lib.lsr_forward_prepare(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii),
+                                               C.byref(npairs), C.byref(maxtile), stream),
+                       "lsr_forward_prepare")
+            binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), npairs.value, maxtile.value), **u8)
             _lib.check(lib.lsr_forward_render(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img),
                                               npairs.value, maxtile.value, C.byref(outs), stream),
                        "lsr_forward_render")
