@@ -46,9 +46,9 @@ k_tile_scan(const uint32_t *__restrict__ count, const uint32_t *__restrict__ cos
         // no copy command between this kernel and the stream synchronisation
         if (host_mirror) { host_mirror[0] = s_sum[tid]; host_mirror[1] = s_max[tid]; }
     }
-    // ---- work items, costliest first: counting sort on kScanThreads classes of the per-tile work
-    // estimate accumulated by k_preprocess (list length is a poor proxy: the work per entry depends
-    // on how many quadrants its footprint reaches) ----
+    // ---- work items, costliest first: counting sort on kScanThreads classes of the per-tile cost
+    // (= list length; `cost` aliases `count`.  A finer estimate — quadrants reached per entry,
+    // accumulated by k_preprocess — was measured to schedule no better and was removed) ----
     const uint32_t maxc = s_max[kScanThreads - 1], total = s_sum[kScanThreads - 1];
     __syncthreads();
     uint32_t wmax = 0;
@@ -112,7 +112,7 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror
     const int N = d.num_views * (int)num_tiles(d);
     prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
-                       (const uint32_t *)(geom + L.tile_count), (const uint32_t *)(geom + L.tile_cost), (uint32_t *)(geom + L.tile_start),
+                       (const uint32_t *)(geom + L.tile_count), (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
                        (uint32_t *)(geom + L.header), host_mirror, (uint32_t *)(geom + L.tile_order), (uint32_t *)(geom + L.tile_lpt), N,
                        getenv("LSR_SPLIT") ? atoi(getenv("LSR_SPLIT")) : 0,
                        getenv("LSR_LIMIT") ? atoi(getenv("LSR_LIMIT")) : 100000);

@@ -17,7 +17,7 @@ namespace lsr {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t header, rec, bin, tile_count, tile_cost, tile_start, tile_cursor, tile_order, tile_lpt, sh_clamp, total;
+    size_t header, rec, bin, tile_count, tile_start, tile_cursor, tile_order, tile_lpt, sh_clamp, total;
     int rec_floats;
 };
 struct ImgLayout {
@@ -66,7 +66,6 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     L.bin = o; o = align_up(o + VG * sizeof(BinRec));
     L.header = o; o += 256;                        // header .. tile_cursor are cleared by ONE memset per forward
     L.tile_count = o; o = align_up(o + VT * 4);
-    L.tile_cost = o; o = align_up(o + VT * 4);     // compositing work estimate per tile (see k_preprocess)
     L.tile_cursor = o; o = align_up(o + VT * 4);   // adjacent to tile_count: one memset clears both
     L.tile_start = o; o = align_up(o + (VT + 1) * 4);
     L.tile_order = o; o = align_up(o + 4 * VT * 4);   // work items (see kItem*), costliest first

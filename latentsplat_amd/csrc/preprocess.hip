@@ -24,7 +24,7 @@ constexpr int kPreItems = 8;  // Gaussians per thread => 2048 per block, one his
 template <int COLOR_MODE, bool LDS_HIST>
 __global__ void __launch_bounds__(kPreThreads)
 k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec *__restrict__ binrec,
-             int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_cost) {
+             int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
     extern __shared__ uint32_t s_hist[];
     // 64-byte records are staged here and stored by the whole block as one contiguous run
     // (lane-contiguous 16-byte stores) instead of 4 strided partial-line stores per thread.
@@ -39,7 +39,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
     const int gx = (d.width + LSR_TILE - 1) / LSR_TILE, gy = (d.height + LSR_TILE - 1) / LSR_TILE;
     const int T = gx * gy;
     if (LDS_HIST) {
-        for (int t = threadIdx.x; t < 2 * T; t += kPreThreads) s_hist[t] = 0;   // [T] pair counts, [T] work estimates
+        for (int t = threadIdx.x; t < T; t += kPreThreads) s_hist[t] = 0;   // [T] pair counts
         __syncthreads();
     }
     const float *vw = in.views + (size_t)v * LSR_VIEW_FLOATS;
@@ -56,7 +56,6 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
     const float *covs = in.cov3D + (size_t)v * d.vs_cov;
     const float *opac = in.opacities + (size_t)v * d.vs_opac;
     uint32_t *tc = tile_count + (size_t)v * T;
-    uint32_t *tw = tile_cost + (size_t)v * T;
 
     const int base = blockIdx.x * (kPreThreads * kPreItems);
 #pragma unroll 1
@@ -155,22 +154,12 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
                     else R[2 + c4] = make_float4(w[0], w[1], w[2], w[3]);
                 }
             }
-            // Work estimate for the compositing kernels' scheduler: 1 (staging) + 3 per 8x8 quadrant
-            // of the tile that the alpha >= 1/255 footprint can reach (same box the compositing
-            // kernels cull with).  A scheduling hint only — no result depends on it.
-            const float op_i = opac[i];
-            const float tau = op_i >= LSR_ALPHA_MIN ? __logf(255.0f * op_i) : -1.0f;
-            const float ex = tau > 0.0f ? sqrtf(2.0f * tau * ca) + 0.5f : -1.0f;
-            const float ey = tau > 0.0f ? sqrtf(2.0f * tau * cc) + 0.5f : -1.0f;
+            // per-tile pair counts (also the compositing kernels' scheduling key: a finer work
+            // estimate — quadrants reached per entry — was measured to schedule no better)
             for (int y = rminy; y < rmaxy; ++y)
                 for (int x = rminx; x < rmaxx; ++x) {
-                    const float x0 = px - ex - 16.0f * x, x1 = px + ex - 16.0f * x;
-                    const float y0 = py - ey - 16.0f * y, y1 = py + ey - 16.0f * y;
-                    const int nqx = (int)(x0 <= 7.0f && x1 >= 0.0f) + (int)(x0 <= 15.0f && x1 >= 8.0f);
-                    const int nqy = (int)(y0 <= 7.0f && y1 >= 0.0f) + (int)(y0 <= 15.0f && y1 >= 8.0f);
-                    const uint32_t cost = ex > 0.0f ? 1u + 3u * (uint32_t)(nqx * nqy) : 1u;
-                    if (LDS_HIST) { atomicAdd(&s_hist[y * gx + x], 1u); atomicAdd(&s_hist[T + y * gx + x], cost); }
-                    else { atomicAdd(&tc[y * gx + x], 1u); atomicAdd(&tw[y * gx + x], cost); }
+                    if (LDS_HIST) atomicAdd(&s_hist[y * gx + x], 1u);
+                    else atomicAdd(&tc[y * gx + x], 1u);
                 }
         } while (0);
         if (in_range) {
@@ -197,7 +186,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
         __syncthreads();
         for (int t = threadIdx.x; t < T; t += kPreThreads) {
             const uint32_t c = s_hist[t];
-            if (c) { atomicAdd(&tc[t], c); atomicAdd(&tw[t], s_hist[T + t]); }
+            if (c) atomicAdd(&tc[t], c);
         }
     }
 }
@@ -215,15 +204,14 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     BinRec *binrec = (BinRec *)(geom + L.bin);
     const int RF = L.rec_floats;
     uint32_t *tc = (uint32_t *)(geom + L.tile_count);
-    uint32_t *tw = (uint32_t *)(geom + L.tile_cost);
     const bool lds = T <= 4096;
-    const size_t shm = lds ? (size_t)T * 8 : 0;
+    const size_t shm = lds ? (size_t)T * 4 : 0;
 #define LSR_PRE(CM)                                                                              \
     do {                                                                                         \
         if (lds) hipLaunchKernelGGL((k_preprocess<CM, true>), grid, dim3(kPreThreads), shm, s,   \
-                                    d, in, rec, RF, binrec, radii, tc, tw);                     \
+                                    d, in, rec, RF, binrec, radii, tc);                         \
         else hipLaunchKernelGGL((k_preprocess<CM, false>), grid, dim3(kPreThreads), 0, s, d, in, \
-                                rec, RF, binrec, radii, tc, tw);                                \
+                                rec, RF, binrec, radii, tc);                                    \
     } while (0)
     prof_begin(kStPreprocess, s);
     if (d.color_mode == LSR_COLOR_SH) LSR_PRE(LSR_COLOR_SH);

@@ -3,7 +3,7 @@
 // final_T / n_contrib for the backward pass.  Spec: SURVEY.md Appendix A.3 step 7 + A.4.
 //
 // Execution shape (CDNA4): persistent waves process work items — (view, tile, set of 8x8
-// quadrants), sorted by estimated work (lsr_internal.h kItem*): the first one per wave by a static
+// quadrants), sorted by list length (lsr_internal.h kItem*): the first one per wave by a static
 // balanced assignment, further ones from a global queue.  A lane owns the same position
 // in each of the 4 quadrants (4 pixels per lane); quadrants outside the item's set are simply
 // never touched.  Per 64 staged list entries the wave walks, quadrant by quadrant, only the
