@@ -81,7 +81,8 @@ typedef struct lsr_dims {
     int32_t color_mode;     /* LSR_COLOR_* : none / `shs=` / `colors_precomp=` */
     int32_t sh_degree;      /* `settings.sh_degree`, 0..4 */
     int32_t sh_coeffs;      /* K = shs.shape[1] >= (sh_degree+1)^2 */
-    /* element strides between consecutive views; 0 = shared by all views */
+    /* element strides between consecutive views (or view groups, see views_per_group);
+     * 0 = shared by all views */
     int64_t vs_means;       /* means3D   (G,3)   */
     int64_t vs_cov;         /* cov3D_precomp (G,6): xx,xy,xz,yy,yz,zz (cuda_splatting.py:148,157) */
     int64_t vs_opac;        /* opacities (G,1)   */
@@ -98,7 +99,12 @@ typedef struct lsr_dims {
     int32_t color_sh_channel_major; /* 0: shs (G,K,3) as the reference hands them to the rasterizer;
                                1: (G,3,K) = `gaussian_color_sh_coefficients` as stored (skips the
                                `rearrange(...).contiguous()` copy of cuda_splatting.py:91) */
-    int32_t reserved0;
+    int32_t views_per_group; /* 0 or 1: a non-zero stride advances per view.  n > 1: consecutive blocks
+                               of n views form a group that shares its inputs, the strides advance
+                               per GROUP (b scenes x n views in one call: what
+                               DecoderSplattingCUDA.forward receives); num_views % n == 0 and every
+                               per-Gaussian input must then be strided (!= 0).  Gradients of strided
+                               inputs have one slice per group, summed over the group's views. */
 } lsr_dims;
 
 typedef struct lsr_inputs {

@@ -101,6 +101,45 @@ static int check_dims(const lsr_dims *d) {
     }
     if (d->color_mode == LSR_COLOR_SH && d->sh_coeffs * 3 > 120) return LSR_EUNSUPPORTED;
     if (d->feat_channels > 0 && d->vs_feat != 0 && d->vs_feat != feat_elems * G) return LSR_EINVAL;
+    if (d->views_per_group < 0) return LSR_EINVAL;
+    if (d->views_per_group > 1) {   // view groups: all inputs strided per group
+        if (d->num_views % d->views_per_group != 0) return LSR_EINVAL;
+        if (d->vs_means == 0 || d->vs_cov == 0 || d->vs_opac == 0) return LSR_EUNSUPPORTED;
+        if (d->color_mode != LSR_COLOR_NONE && d->vs_color == 0) return LSR_EUNSUPPORTED;
+        if (d->feat_channels > 0 && d->vs_feat == 0) return LSR_EUNSUPPORTED;
+    }
+    return LSR_OK;
+}
+
+// The stages that sum over views (SH kernels, preprocess backward) run once per view group.
+// fn(dims of the launch, its inputs, its input-gradient pointers, layout dims or nullptr, first view)
+template <class F>
+static int for_each_view_group(const lsr_dims &d, const lsr_inputs &in, const lsr_in_grads *gin, F fn) {
+    if (d.views_per_group <= 1) return fn(d, in, gin ? *gin : lsr_in_grads{}, (const lsr_dims *)nullptr, 0);
+    const int n = d.views_per_group;
+    for (int g = 0; g * n < d.num_views; ++g) {
+        lsr_dims ds = d;
+        ds.num_views = n; ds.views_per_group = 0;
+        ds.vs_means = ds.vs_cov = ds.vs_opac = ds.vs_color = ds.vs_feat = 0;
+        lsr_inputs is = in;
+        is.views = in.views + (size_t)g * n * LSR_VIEW_FLOATS;
+        is.means3D = in.means3D + (size_t)g * d.vs_means;
+        is.cov3D = in.cov3D + (size_t)g * d.vs_cov;
+        is.opacities = in.opacities + (size_t)g * d.vs_opac;
+        if (in.color) is.color = in.color + (size_t)g * d.vs_color;
+        if (in.features) is.features = in.features + (size_t)g * d.vs_feat;
+        lsr_in_grads gs{};
+        if (gin) {
+            gs = *gin;
+            gs.means3D = gin->means3D + (size_t)g * d.vs_means;
+            gs.cov3D = gin->cov3D + (size_t)g * d.vs_cov;
+            gs.opacities = gin->opacities + (size_t)g * d.vs_opac;
+            if (gin->color) gs.color = gin->color + (size_t)g * d.vs_color;
+            if (gin->features) gs.features = gin->features + (size_t)g * d.vs_feat;
+        }
+        const int rc = fn(ds, is, gs, &d, g * n);
+        if (rc) return rc;
+    }
     return LSR_OK;
 }
 static int check_inputs(const lsr_dims *d, const lsr_inputs *in) {
@@ -249,7 +288,11 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
     if (num_pairs < 0 || max_tile_pairs < 0) return LSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    LSR_STAGE("sh_forward", s, launch_sh_forward(*d, *in, (char *)geom_ws, s));
+    rc = for_each_view_group(*d, *in, nullptr, [&](const lsr_dims &dg, const lsr_inputs &ig, const lsr_in_grads &, const lsr_dims *layout, int view0) -> int {
+        LSR_STAGE("sh_forward", s, launch_sh_forward(dg, ig, (char *)geom_ws, s, layout, view0));
+        return LSR_OK;
+    });
+    if (rc) return rc;
     LSR_STAGE("binning", s, launch_binning(*d, (char *)geom_ws, (char *)bin_ws, num_pairs, max_tile_pairs, out->radii, s));
     LSR_STAGE("render_forward", s, launch_render_forward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs, (char *)img_ws, *out, s));
     return LSR_OK;
@@ -279,9 +322,11 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
     if (num_pairs > 0)
         LSR_STAGE("render_backward", s, launch_render_backward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs,
                                        (const char *)img_ws, *fwd, *gout, (char *)grad_ws, *gin, s));
-    LSR_STAGE("preprocess_backward", s, launch_preprocess_backward(*d, *in, (const char *)geom_ws, radii, (const char *)grad_ws, *gin, s));
-    LSR_STAGE("sh_backward", s, launch_sh_backward(*d, *in, (const char *)geom_ws, (const char *)grad_ws, *gin, s));
-    return LSR_OK;
+    return for_each_view_group(*d, *in, gin, [&](const lsr_dims &dg, const lsr_inputs &ig, const lsr_in_grads &gg, const lsr_dims *layout, int view0) -> int {
+        LSR_STAGE("preprocess_backward", s, launch_preprocess_backward(dg, ig, (const char *)geom_ws, radii, (const char *)grad_ws, gg, s, layout, view0));
+        LSR_STAGE("sh_backward", s, launch_sh_backward(dg, ig, (const char *)geom_ws, (const char *)grad_ws, gg, s, layout, view0));
+        return LSR_OK;
+    });
 }
 
 }  // extern "C"

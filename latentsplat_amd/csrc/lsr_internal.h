@@ -109,6 +109,9 @@ inline GradLayout grad_layout(const lsr_dims &d) {
 //   fill the machine.  Splitting only the LONG lists for balance is implemented but off by
 //   default (LSR_LIMIT=<percent of mean length>): measured on MI355X each extra item re-pays the
 //   per-entry staging cost and the makespan did not improve (experiments).
+// Input slice a view reads: its own (per-view strides), its group's, or the shared one (stride 0).
+__host__ __device__ inline int input_slice(const lsr_dims &d, int v) { return d.views_per_group > 1 ? v / d.views_per_group : v; }
+
 constexpr uint32_t kItemTileMask = 0x0FFFFFFFu;
 constexpr int kItemOwnShift = 28;
 constexpr int kWaveSlots = 256 * 4 * 4;   // CUs x SIMDs x resident compositing waves per SIMD
@@ -128,9 +131,14 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror
 hipError_t launch_build_views(int V, const float *extrinsics, const float *intrinsics, const float *near,
                               const float *far, const float *bg, int bg_stride, int scale_invariant,
                               float *out, hipStream_t s);
-hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s);
+// Stages that sum over views run once per view group (lsr_dims::views_per_group): `d` / `in` / `gin`
+// then describe ONE group (its views, its input slices, strides 0 = shared inside the group) while
+// `layout` (the full call's dims) and `view0` (first view of the group) locate its part of the
+// per-(view, Gaussian) workspace arrays.  layout == nullptr: `d` is the whole call.
+hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s,
+                             const lsr_dims *layout = nullptr, int view0 = 0);
 hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom, const char *grad,
-                              const lsr_in_grads &gin, hipStream_t s);
+                              const lsr_in_grads &gin, hipStream_t s, const lsr_dims *layout = nullptr, int view0 = 0);
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
                           int32_t max_tile_pairs, const int32_t *radii, hipStream_t s);
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
@@ -142,6 +150,6 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
                                   const lsr_in_grads &gin, hipStream_t s);
 hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                       const int32_t *radii, const char *grad,
-                                      const lsr_in_grads &gin, hipStream_t s);
+                                      const lsr_in_grads &gin, hipStream_t s, const lsr_dims *layout = nullptr, int view0 = 0);
 
 }  // namespace lsr

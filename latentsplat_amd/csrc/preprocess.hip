@@ -52,9 +52,10 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
     const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
     const float scale = vw[40], scale2 = scale * scale;   // scene scale (1/near), applied like the reference does
     const int ce = d.cov_elems;
-    const float *means = in.means3D + (size_t)v * d.vs_means;
-    const float *covs = in.cov3D + (size_t)v * d.vs_cov;
-    const float *opac = in.opacities + (size_t)v * d.vs_opac;
+    const size_t sl = (size_t)input_slice(d, v);   // which per-view / per-group input slice this view reads
+    const float *means = in.means3D + sl * d.vs_means;
+    const float *covs = in.cov3D + sl * d.vs_cov;
+    const float *opac = in.opacities + sl * d.vs_opac;
     uint32_t *tc = tile_count + (size_t)v * T;
 
     const int base = blockIdx.x * (kPreThreads * kPreItems);
@@ -128,7 +129,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
             if (COLOR_MODE == LSR_COLOR_SH) {
                 // filled by k_sh (sh.hip) for visible Gaussians
             } else if (COLOR_MODE == LSR_COLOR_PRECOMP) {
-                const float *cp = in.color + (size_t)v * d.vs_color + 3 * (size_t)i;
+                const float *cp = in.color + sl * d.vs_color + 3 * (size_t)i;
                 pay[0] = cp[0]; pay[1] = cp[1]; pay[2] = cp[2];
             }
             out_radius = (int32_t)my_radius;
@@ -141,7 +142,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
             {   // payload slots 8.. : rgb (if any) then the feature channels, zero padded
                 constexpr int coff = COLOR_MODE == LSR_COLOR_NONE ? 0 : 3;
                 const bool direct_feat = d.feat_mode == LSR_FEAT_DIRECT;
-                const float *fp = in.features + (size_t)v * d.vs_feat + (size_t)i * d.feat_channels;
+                const float *fp = in.features + sl * d.vs_feat + (size_t)i * d.feat_channels;
                 for (int c4 = 0; c4 < (RF - 8) / 4; ++c4) {
                     float w[4];
 #pragma unroll

@@ -262,15 +262,17 @@ k_preprocess_bwd(PreBwdParams p) {
 
 hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                       const int32_t *radii, const char *grad,
-                                      const lsr_in_grads &gin, hipStream_t s) {
+                                      const lsr_in_grads &gin, hipStream_t s, const lsr_dims *layout, int view0) {
     if (d.num_gaussians == 0) return hipSuccess;
-    const GeomLayout L = geom_layout(d);
-    const GradLayout R = grad_layout(d);
+    const GeomLayout L = geom_layout(layout ? *layout : d);
+    const GradLayout R = grad_layout(layout ? *layout : d);
+    const size_t off = (size_t)view0 * (size_t)d.num_gaussians;   // first (view, Gaussian) slot of this launch
     PreBwdParams p;
-    p.d = d; p.in = in; p.radii = radii;
-    p.geo = (const float *)(geom + L.rec); p.geo_floats = L.rec_floats;
-    p.rec = (const float *)(grad + R.rec); p.rec_floats = R.rec_floats;
+    p.d = d; p.in = in; p.radii = radii + off;
+    p.geo = (const float *)(geom + L.rec) + off * L.rec_floats; p.geo_floats = L.rec_floats;
+    p.rec = (const float *)(grad + R.rec) + off * R.rec_floats; p.rec_floats = R.rec_floats;
     p.g = gin;
+    if (p.g.means2D) p.g.means2D += off * 3;
     prof_begin(kStPreprocessBwd, s);
     const int parts = d.num_views >= 4 ? 4 : (d.num_views >= 2 ? 2 : 1);
     const dim3 grid((unsigned)(((int64_t)d.num_gaussians * parts + 255) / 256));

@@ -398,10 +398,12 @@ static bool group_enabled(const lsr_dims &d, int group) {
 
 static uint32_t mdiv_of(int x) { return x > 0 ? (uint32_t)(((1u << 22) + x - 1) / x) : 0u; }
 
-static ShParams make_params(const lsr_dims &d, const lsr_inputs &in, const GeomLayout &L, const char *geom) {
+static ShParams make_params(const lsr_dims &d, const lsr_inputs &in, const GeomLayout &L, const char *geom, int view0) {
     ShParams p;
-    p.d = d; p.in = in; p.binrec = (const BinRec *)(geom + L.bin);
-    p.rec = (float *)const_cast<char *>(geom + L.rec); p.clamp = (uint8_t *)const_cast<char *>(geom + L.sh_clamp);
+    const size_t off = (size_t)view0 * (size_t)d.num_gaussians;   // first (view, Gaussian) slot of this launch
+    p.d = d; p.in = in; p.binrec = (const BinRec *)(geom + L.bin) + off;
+    p.rec = (float *)const_cast<char *>(geom + L.rec) + off * L.rec_floats;
+    p.clamp = (uint8_t *)const_cast<char *>(geom + L.sh_clamp) + off;
     p.grec = nullptr; p.RF = L.rec_floats; p.g = lsr_in_grads{};
     p.has[0] = group_enabled(d, 0); p.has[1] = group_enabled(d, 1);
     p.ks[0] = p.has[0] ? d.sh_coeffs * 3 : 0;
@@ -424,11 +426,12 @@ static ShParams make_params(const lsr_dims &d, const lsr_inputs &in, const GeomL
         else hipLaunchKernelGGL((KERNEL<-1, 0>), __VA_ARGS__);                             \
     } while (0)
 
-hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s) {
+hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s,
+                             const lsr_dims *layout, int view0) {
     if (d.num_gaussians == 0) return hipSuccess;
     if (!group_enabled(d, 0) && !group_enabled(d, 1)) return hipSuccess;
-    const GeomLayout L = geom_layout(d);
-    const ShParams p = make_params(d, in, L, geom);
+    const GeomLayout L = geom_layout(layout ? *layout : d);
+    const ShParams p = make_params(d, in, L, geom, view0);
     const int degc = p.has[0] ? d.sh_degree : -1, coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
     const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), block(kShThreads);
     const size_t shm = ((size_t)p.offF + (size_t)LSR_WAVE * p.ks[1]) * 4;
@@ -448,13 +451,13 @@ static void allow_big_lds(size_t shm) {
 }
 
 hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom, const char *grad,
-                              const lsr_in_grads &gin, hipStream_t s) {
+                              const lsr_in_grads &gin, hipStream_t s, const lsr_dims *layout, int view0) {
     if (d.num_gaussians == 0) return hipSuccess;
     if (!group_enabled(d, 0) && !group_enabled(d, 1)) return hipSuccess;
-    const GeomLayout L = geom_layout(d);
-    const GradLayout R = grad_layout(d);
-    ShParams p = make_params(d, in, L, geom);
-    p.grec = (const float *)(grad + R.rec); p.g = gin;
+    const GeomLayout L = geom_layout(layout ? *layout : d);
+    const GradLayout R = grad_layout(layout ? *layout : d);
+    ShParams p = make_params(d, in, L, geom, view0);
+    p.grec = (const float *)(grad + R.rec) + (size_t)view0 * d.num_gaussians * R.rec_floats; p.g = gin;
     const int degc = p.has[0] ? d.sh_degree : -1, coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
     const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), block(kShThreads);
     const int cs = (coff + d.feat_channels) | 1;

@@ -116,8 +116,9 @@ def _view_table(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tenso
 
 def _render_views(views: Tensor, image_shape, means: Tensor, covariances: Tensor, opacities: Tensor,
                   color_sh, feature_sh, use_sh: bool) -> RenderOutput:
-    """``views`` (B,44); UNSCALED means (B|1,G,3) / covariances (B|1,G,3,3); opacities (B|1,G);
-    *_sh (B|1,G,.,.)."""
+    """``views`` (B,44); UNSCALED means (S,G,3) / covariances (S,G,3,3); opacities (S,G);
+    *_sh (S,G,.,.) with S = 1 (shared), B (one slice per view) or a divisor of B (scenes of B/S
+    consecutive views each)."""
     h, w = image_shape
     degree, kw = 0, {}
     if use_sh:
@@ -208,9 +209,15 @@ def render_scenes(
     # one camera-table launch for all b*v views
     views = _view_table(extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(0, 1), far.flatten(0, 1),
                         background_color, scale_invariant)
-    for s in range(b):
+    fsh_all = gaussian_feature_sh_coefficients
+    if b == 1 or not use_sh or fsh_all is None or fused_feature_sh_supported(fsh_all):
+        # ONE call for all b*v views: the b scenes are view groups of v views each (inputs keep their
+        # leading scene dimension, nothing is replicated or concatenated)
+        return _render_views(views, image_shape, gaussian_means, gaussian_covariances, gaussian_opacities,
+                             gaussian_color_sh_coefficients, fsh_all, use_sh)
+    for s in range(b):   # latent SH evaluated on the host (degree > 2 / too many coefficients): per scene
         csh = None if gaussian_color_sh_coefficients is None else gaussian_color_sh_coefficients[s][None]
-        fsh = None if gaussian_feature_sh_coefficients is None else gaussian_feature_sh_coefficients[s][None]
+        fsh = fsh_all[s][None]
         outs.append(_render_views(views[s * v:(s + 1) * v], image_shape, gaussian_means[s][None],
                                   gaussian_covariances[s][None], gaussian_opacities[s][None], csh, fsh, use_sh))
     cat = lambda xs: None if xs[0] is None else torch.cat(xs, dim=0)

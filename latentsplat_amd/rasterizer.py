@@ -94,12 +94,17 @@ def _prep(t: Optional[Tensor], name: str, dev) -> Optional[Tensor]:
     return t.contiguous()
 
 
-def _stride(t: Optional[Tensor], base_dims: int, V: int, name: str) -> int:
-    """0 for a tensor shared by all views (G,...), elements-per-view for a (V,G,...) tensor."""
+def _stride(t: Optional[Tensor], base_dims: int, V: int, name: str, groups: Optional[list] = None) -> int:
+    """0 for a tensor shared by all views (G,...); elements per slice for a (V,G,...) tensor (one
+    slice per view) or a (B,G,...) tensor with V % B == 0 (one slice per group of V/B consecutive
+    views: B scenes rendered from V/B cameras each).  ``groups`` collects the slice counts seen."""
     if t is None or t.dim() == base_dims:
         return 0
-    if t.dim() != base_dims + 1 or t.shape[0] != V:
-        raise LsrError(f"{name}: expected {base_dims} dims (shared) or a leading view dim of {V}, got {tuple(t.shape)}")
+    if t.dim() != base_dims + 1 or t.shape[0] < 1 or V % t.shape[0] != 0:
+        raise LsrError(f"{name}: expected {base_dims} dims (shared) or a leading dim dividing the {V} views, "
+                       f"got {tuple(t.shape)}")
+    if groups is not None:
+        groups.append(t.shape[0])
     return t[0].numel()
 
 
@@ -148,13 +153,20 @@ class _RasterizeViews(torch.autograd.Function):
         if Cf > _lib.MAX_FEAT_CHANNELS:
             raise LsrError(f"features has {Cf} channels; at most {_lib.MAX_FEAT_CHANNELS} are supported")
         K = 0 if shs is None else (shs.shape[-1] if shs_channel_major else shs.shape[-2])
-        d = Dims(V, G, H, W, Cf, color_mode, int(sh_degree), K,
-                 _stride(means3D, 2, V, "means3D"), _stride(cov3D, cov_base, V, "cov3D_precomp"),
-                 _stride(opacities, 2, V, "opacities"),
-                 _stride(color, 3 if shs is not None else 2, V, "shs/colors_precomp"),
-                 _stride(features, 3 if feat_sh else 2, V, "features"),
+        slices: list = []
+        strides = (_stride(means3D, 2, V, "means3D", slices), _stride(cov3D, cov_base, V, "cov3D_precomp", slices),
+                   _stride(opacities, 2, V, "opacities", slices),
+                   _stride(color, 3 if shs is not None else 2, V, "shs/colors_precomp", slices),
+                   _stride(features, 3 if feat_sh else 2, V, "features", slices))
+        if len(set(slices)) > 1:
+            raise LsrError(f"per-view / per-scene inputs disagree on their leading dimension: {sorted(set(slices))}")
+        vpg = V // slices[0] if slices else 0           # views per group; 1 = one slice per view
+        if vpg > 1 and len(slices) != sum(t is not None for t in (means3D, cov3D, opacities, color, features)):
+            raise LsrError("with per-scene inputs (leading dim < number of views) every per-Gaussian input must "
+                           "carry the scene dimension")
+        d = Dims(V, G, H, W, Cf, color_mode, int(sh_degree), K, *strides,
                  cov_elems, _lib.FEAT_SH if feat_sh else _lib.FEAT_DIRECT, max(int(feat_sh_degree), 0), Kf,
-                 1 if (shs is not None and shs_channel_major) else 0, 0)
+                 1 if (shs is not None and shs_channel_major) else 0, vpg if vpg > 1 else 0)
         inp = Inputs(_ptr(views), _ptr(means3D), _ptr(cov3D), _ptr(opacities), _ptr(color), _ptr(features))
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         u8 = dict(dtype=torch.uint8, device=dev)

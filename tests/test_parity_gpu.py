@@ -263,3 +263,71 @@ def test_fused_scene_inputs_match_oracle(hip_device, cfg, shared):
         else:
             for v in range(V):
                 util.assert_grad_close_except_fragile(got[v], want[v], frag[v][0], frag[v][1], ABS_TOL, f"dL/d{k}[view {v}]")
+
+
+@pytest.mark.parametrize("cfg,direct", [
+    (dict(color_sh_degree=4, feature_channels=4, feature_sh_degree=2), False),      # the reference's experiment payload
+    (dict(color_sh_degree=None, feature_channels=4, feature_sh_degree=0), True),    # direct features only
+    (dict(color_sh_degree=1, feature_channels=8, feature_sh_degree=0), False),
+])
+def test_view_groups_equal_per_scene_calls(hip_device, cfg, direct):
+    """b scenes x v views in ONE call (inputs keep their leading scene dimension, lsr_dims
+    views_per_group) == b separate shared-scene calls: images, radii and every gradient."""
+    from latentsplat_amd.decoder import cuda_splatting as cs
+    from latentsplat_amd.rasterizer import make_view_table, rasterize_views
+    dev, b, v, size, G = hip_device, 3, 2, 64, 1500
+    scenes = [util.make_scene(G, image_size=size, views=v, seed=50 + s, **cfg) for s in range(b)]
+    tables = []
+    for sc in scenes:
+        cams, scale = cs._scaled_cameras(sc.extrinsics, sc.intrinsics, sc.near * torch.linspace(1.0, 1.2, v), sc.far, True)
+        tables.append(make_view_table(cams.view_matrix, cams.full_projection, cams.campos, cams.tan_fov_x,
+                                      cams.tan_fov_y, torch.tensor([[0.3, 0.2, 0.1]]).expand(v, 3), scale))
+    views = torch.cat(tables).to(dev)
+    stack = lambda name: None if getattr(scenes[0], name) is None else torch.stack([getattr(s, name) for s in scenes])
+    fields = dict(means=stack("means"), cov=stack("covariances"), opac=stack("opacities")[..., None],
+                  shs=stack("color_sh"), feats=stack("feature_sh")[..., 0].contiguous() if direct else stack("feature_sh"))
+    deg = 0 if fields["shs"] is None else int(round(fields["shs"].shape[-1] ** 0.5)) - 1
+    gen = torch.Generator().manual_seed(9)
+
+    def run(t, vw):
+        leaf = {k: (None if x is None else x.to(dev).clone().requires_grad_(True)) for k, x in t.items()}
+        kw = dict(features=leaf["feats"]) if direct else dict(feature_sh=leaf["feats"])
+        out = rasterize_views(vw, size, size, deg, leaf["means"], leaf["cov"], leaf["opac"], shs=leaf["shs"],
+                              shs_channel_major=True, **kw)
+        return out, leaf
+
+    (color, feat, mask, depth, radii), leaf = run(fields, views)
+    g_feat = torch.randn(feat.shape, generator=gen).to(dev)
+    g_color = None if color is None else torch.randn(color.shape, generator=gen).to(dev)
+    g_depth = torch.randn(depth.shape, generator=gen).to(dev)
+    ((feat * g_feat).sum() + (depth * g_depth).sum() + (0 if color is None else (color * g_color).sum())).backward()
+    for s in range(b):
+        one = {k: (None if x is None else x[s]) for k, x in fields.items()}          # (G, ...): shared by the scene's views
+        sl = slice(s * v, (s + 1) * v)
+        (c1, f1, m1, d1, r1), leaf1 = run(one, views[sl])
+        assert torch.equal(radii[sl], r1)
+        assert torch.equal(feat[sl], f1) and torch.equal(mask[sl], m1) and torch.equal(depth[sl], d1)
+        assert color is None or torch.equal(color[sl], c1)
+        ((f1 * g_feat[sl]).sum() + (d1 * g_depth[sl]).sum() + (0 if c1 is None else (c1 * g_color[sl]).sum())).backward()
+        for k in leaf:
+            if leaf[k] is None:
+                continue
+            a, r = leaf[k].grad[s], leaf1[k].grad
+            assert a.shape == r.shape
+            assert float((a - r).abs().max()) <= 1e-5 * max(1e-6, float(r.abs().max())), k
+
+
+def test_view_group_argument_errors(hip_device):
+    from latentsplat_amd.rasterizer import LsrError, rasterize_views
+    sc = util.make_scene(300, image_size=32, views=4, color_sh_degree=None, feature_channels=4, seed=1)
+    bi = util.boundary_inputs(sc, 32, 32)
+    vt = util.view_table(bi, hip_device)
+    m, c, f = (bi[k][0].to(hip_device) for k in ("means", "cov6", "features"))
+    o = bi["opac"].to(hip_device)                      # (G, 1): shared
+    two = lambda t: torch.stack([t, t])
+    with pytest.raises(LsrError):      # 3 slices do not divide 4 views
+        rasterize_views(vt, 32, 32, 0, torch.stack([m, m, m]), c, o, features=f)
+    with pytest.raises(LsrError):      # per-scene means but shared covariances
+        rasterize_views(vt, 32, 32, 0, two(m), c, o, features=f)
+    out = rasterize_views(vt, 32, 32, 0, two(m), two(c), two(o), features=two(f))
+    assert out[1].shape == (4, 4, 32, 32)

@@ -202,7 +202,9 @@ def to_boundary(views, v, means3D, cov3D_precomp, opacities, shs, colors_precomp
     reference hands to its rasterizer (scaled means, packed scaled covariance, (G,K,3) colour SH,
     evaluated latent features).  Pure torch, differentiable; used by the CPU stand-in below and by
     the gradient tests to chain oracle gradients back to scene-level inputs."""
-    pv = lambda t, base: None if t is None else (t[v] if t.dim() == base + 1 else t)
+    V = views.shape[0]
+    # leading dim: one slice per view, or per scene (group of V / S consecutive views), or shared
+    pv = lambda t, base: None if t is None else (t[v * t.shape[0] // V] if t.dim() == base + 1 else t)
     vw = views[v]
     scale = vw[40]
     means = pv(means3D, 2) * scale
