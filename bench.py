@@ -146,21 +146,22 @@ def rank_seed(base, rank):
     return base + rank
 
 
-def decoder_step_timing(dev, steps=10):
+def decoder_step_timing(dev, steps=10, scenes=1):
     """BASELINE configs[3] shape through the decoder surface: DecoderSplattingCUDA.forward
     (+ backward of an MSE-like loss on colour and latent mean) for batch_size 1 x 4 target views,
     G = 393 216 Gaussians (2 context views x 256^2 x 3), colour SH degree 4 + 4-channel latent SH
     degree 2 — the call the reference's training_step makes (model_wrapper.py:361-371)."""
     from latentsplat_amd import decoder as dec
     from latentsplat_amd.synthetic import make_scene
-    sc = make_scene(393_216, image_size=256, views=4, color_sh_degree=4, feature_channels=4,
-                    feature_sh_degree=2, seed=4321).to(dev)
-    leaf = lambda t: t[None].contiguous().requires_grad_(True)
-    gauss = dec.Gaussians(leaf(sc.means), leaf(sc.covariances), leaf(sc.opacities), leaf(sc.color_sh), leaf(sc.feature_sh))
+    scs = [make_scene(393_216, image_size=256, views=4, color_sh_degree=4, feature_channels=4,
+                      feature_sh_degree=2, seed=4321 + i).to(dev) for i in range(scenes)]
+    st = lambda name: torch.stack([getattr(sc, name) for sc in scs])
+    leaf = lambda name: st(name).contiguous().requires_grad_(True)
+    gauss = dec.Gaussians(leaf("means"), leaf("covariances"), leaf("opacities"), leaf("color_sh"), leaf("feature_sh"))
     d = dec.get_decoder(dec.DecoderSplattingCUDACfg(name="splatting_cuda"), [0.0, 0.0, 0.0]).to(dev)
-    args = (gauss, sc.extrinsics[None], sc.intrinsics[None], sc.near[None], sc.far[None], (256, 256))
-    gc = torch.randn((1, 4, 3, 256, 256), device=dev)
-    gf = torch.randn((1, 4, 4, 256, 256), device=dev)
+    args = (gauss, st("extrinsics"), st("intrinsics"), st("near"), st("far"), (256, 256))
+    gc = torch.randn((scenes, 4, 3, 256, 256), device=dev)
+    gf = torch.randn((scenes, 4, 4, 256, 256), device=dev)
     leaves = (gauss.means, gauss.covariances, gauss.opacities, gauss.color_harmonics, gauss.feature_harmonics)
 
     def fwd():
@@ -176,8 +177,9 @@ def decoder_step_timing(dev, steps=10):
     res = {}
     for name, fn in (("forward", fwd), ("forward_backward", fwdbwd)):
         el = timed_region(fn, steps, 3, None, lambda: torch.cuda.synchronize(dev))
-        res[name] = dict(ms_per_step=1e3 * el / steps, views_per_s=4 * steps / el)
-    res["config"] = "configs[3] shape: 1 scene x 4 views, 393216 Gaussians, colour SH deg 4 + 4-ch latent SH deg 2, 256x256"
+        res[name] = dict(ms_per_step=1e3 * el / steps, views_per_s=4 * scenes * steps / el)
+    res["config"] = (f"configs[{3 if scenes == 1 else 4}] per-GPU shape: {scenes} scene(s) x 4 views, 393216 Gaussians each, "
+                     "colour SH deg 4 + 4-ch latent SH deg 2, 256x256")
     return res
 
 
@@ -410,6 +412,7 @@ def main():
         del inp
         torch.cuda.empty_cache()
         dec_step = decoder_step_timing(dev)
+        dec_step["batch4"] = decoder_step_timing(dev, scenes=4)      # configs[4]: batch_size 4 per GPU
         adapter_step = adapter_step_timing(dev)
         latent_step = latent_step_timing(dev)
         if not args.no_cpu_baseline:
