@@ -54,17 +54,35 @@ k_preprocess_bwd(PreBwdParams p) {
     const bool feat_direct = d.feat_channels > 0 && d.feat_mode == LSR_FEAT_DIRECT;
     const bool feat_reg = feat_direct && d.vs_feat == 0 && d.feat_channels <= kPreBwdFeat;
     const bool feat_rmw = feat_direct && d.vs_feat == 0 && !feat_reg;   // many shared channels: one lane, memory accumulate
-#pragma unroll 4
-    for (int v = (feat_rmw ? 0 : part); v < (live ? V : 0); v += (feat_rmw ? 1 : PARTS)) {
-        if (feat_rmw && part != 0) break;
+    // The record (one 64-byte line) and the radius of the NEXT view of this lane are loaded before
+    // the current view is processed: the per-view stores below keep the compiler from hoisting
+    // loads across iterations on its own, and the loop is bound by memory latency.
+    struct ViewRec { float4 r0, r1, q0, q1; int radius; };
+    const bool pay16 = feat_reg && p.rec_floats == 16;
+    auto load_view = [&](int v) {
+        ViewRec r;
         const size_t o = (size_t)v * G + i;
         const float *rc = p.rec + o * p.rec_floats;
-        const float4 r0 = *(const float4 *)rc, r1 = *(const float4 *)(rc + 4);  // gx gy gA gB | gC go gz -
+        r.r0 = *(const float4 *)rc; r.r1 = *(const float4 *)(rc + 4);           // gx gy gA gB | gC go gz -
+        r.q0 = r.q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (pay16) { r.q0 = *(const float4 *)(rc + 8); r.q1 = *(const float4 *)(rc + 12); }
+        r.radius = p.radii[o];
+        return r;
+    };
+    const int v_first = feat_rmw ? 0 : part, v_step = feat_rmw ? 1 : PARTS, v_end = (live && !(feat_rmw && part != 0)) ? V : 0;
+    ViewRec nxt;
+    if (v_first < v_end) nxt = load_view(v_first);
+    for (int v = v_first; v < v_end; v += v_step) {
+        const ViewRec cur = nxt;
+        if (v + v_step < v_end) nxt = load_view(v + v_step);
+        const size_t o = (size_t)v * G + i;
+        const float *rc = p.rec + o * p.rec_floats;
+        const float4 r0 = cur.r0, r1 = cur.r1;
         // opacity / features / precomputed colours: plain pass-through of the record
         if (d.vs_opac != 0) p.g.opacities[(size_t)v * d.vs_opac + i] = r1.y; else aop += r1.y;
         if (feat_reg) {
             if (p.rec_floats == 16) {   // the whole payload half of the record as two 16-byte loads
-                const float4 q0 = *(const float4 *)(rc + 8), q1 = *(const float4 *)(rc + 12);
+                const float4 q0 = cur.q0, q1 = cur.q1;
                 const float pay[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
                 if (coff == 0) {
 #pragma unroll
@@ -93,7 +111,7 @@ k_preprocess_bwd(PreBwdParams p) {
         }
         float gm[3] = {0, 0, 0}, gc[6] = {0, 0, 0, 0, 0, 0};
         float m2x = 0.0f, m2y = 0.0f;
-        const bool vis = p.radii[o] > 0;
+        const bool vis = cur.radius > 0;
         if (vis) {
             const float *vw = p.in.views + (size_t)v * LSR_VIEW_FLOATS;
             const float *vm = vw, *pm = vw + 16;
