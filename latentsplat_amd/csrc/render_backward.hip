@@ -20,8 +20,9 @@
 // of the (view, Gaussian) (lsr_internal.h GradLayout).
 //
 // Scheduling as in the forward: one 16-wave workgroup per CU; a unit of work is (tile, part) where
-// `part` selects the wave's PXL of the tile's 4 quadrants; units are ordered by list length, the first unit of every wave is assigned statically (folded over the sorted list so the
-// 4 waves of a SIMD get a balanced total), the rest comes from a global queue.
+// `part` selects the wave's PXL of the tile's 4 quadrants; units are ordered by list length, the
+// first unit of every wave is assigned statically (folded over the sorted list so the 4 waves of a
+// SIMD get a balanced total), the rest comes from a global queue.
 // Spec: SURVEY.md Appendix A.6.
 #include "lsr_blend.h"
 
