@@ -3,7 +3,7 @@ from .cuda_splatting import (DepthRenderingMode, RenderOutput, get_projection_ma
                              render_cuda_orthographic, render_depth_cuda, render_scenes)
 from .decoder import Decoder, DecoderOutput
 from .decoder_splatting_cuda import DecoderSplattingCUDA, DecoderSplattingCUDACfg
-from .types import DiagonalGaussianDistribution, Gaussians
+from .types import DiagonalGaussianDistribution, Gaussians, VariationalGaussians
 
 DECODERS = {"splatting_cuda": DecoderSplattingCUDA}
 

@@ -2,6 +2,8 @@
 
 Counterparts of the reference types (paths relative to /root/reference):
   * ``Gaussians``                      — src/model/types.py:9-15
+  * ``VariationalGaussians``           — src/model/types.py:18-32 (what the encoder returns and
+    ``model_wrapper.py:362`` turns into ``Gaussians`` with ``sample()`` / ``flatten()``)
   * ``DiagonalGaussianDistribution``   — src/model/diagonal_gaussian_distribution.py:8-95
     (only what the decoder path touches: construction from mean/logvar or params, the logvar
     clamp to (-30, 20), ``sample`` / ``mode`` / ``kl`` / ``nll``).
@@ -81,3 +83,22 @@ class DiagonalGaussianDistribution:
         if self.logvar is None:
             return torch.zeros_like(self.mean)
         return 0.5 * (math.log(2.0 * math.pi) + self.logvar + (sample - self.mean) ** 2 / self.var)
+
+
+@dataclass
+class VariationalGaussians(Gaussians):
+    """Gaussians whose latent-feature harmonics are a distribution; the decoder takes one of the
+    three concrete views below."""
+    feature_harmonics: Optional[DiagonalGaussianDistribution] = None
+
+    def _to_gaussians(self, feature_harmonics: Tensor) -> Gaussians:
+        return Gaussians(self.means, self.covariances, self.opacities, self.color_harmonics, feature_harmonics)
+
+    def flatten(self) -> Gaussians:
+        return self._to_gaussians(self.feature_harmonics.params)
+
+    def mode(self) -> Gaussians:
+        return self._to_gaussians(self.feature_harmonics.mode())
+
+    def sample(self) -> Gaussians:
+        return self._to_gaussians(self.feature_harmonics.sample())
