@@ -65,9 +65,20 @@ def cpu_baseline(G, size, seed, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 50:
             break
+    # forward + backward of the same view (configs[2]'s CPU side): few repetitions, the backward's
+    # scatter of per-Gaussian gradients is the slow part of the port
+    import numpy as np
+    o = util.oracle_forward(bi, 0)
+    gf = np.random.default_rng(7).normal(size=(4, size, size)).astype(np.float32)
+    nb, t1 = 0, time.perf_counter()
+    while nb < 3 and (nb == 0 or time.perf_counter() - t1 < 8.0):
+        util.oracle_backward(bi, 0, util.oracle_forward(bi, 0), None, gf)
+        nb += 1
+    el_b = time.perf_counter() - t1
     return dict(value=n / el, unit="views/s", cores=os.cpu_count(), kind="port",
                 sample=f"{n} forward renders of the same {G}-Gaussian {size}x{size} view "
-                       f"(oracle/raster_oracle.c, gcc -O2 -fopenmp, {os.cpu_count()} threads)")
+                       f"(oracle/raster_oracle.c, gcc -O2 -fopenmp, {os.cpu_count()} threads)",
+                fwdbwd_value=nb / el_b, fwdbwd_sample=f"{nb} forward+backward passes of that view")
 
 
 def cpu_baseline_next_rows(budget_s=4.0):
