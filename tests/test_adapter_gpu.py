@@ -179,3 +179,26 @@ def test_adapter_abi_errors(hip_device):
     assert lib.lsr_adapter_forward(C.byref(d), C.byref(inp), C.byref(out), None) == -2   # NULL inputs
     d.raw_stride = 5
     assert lib.lsr_adapter_forward(C.byref(d), C.byref(inp), C.byref(out), None) == -1
+
+
+def test_degenerate_rows_match_oracle(hip_device):
+    """Zero quaternion (normalised to 0 -> identity rotation), saturated scale logits, tiny / huge
+    depths: the kernel follows the reference's arithmetic there too (no NaN, same gradients)."""
+    inp = random_case(1, 8, 2, seed=4)
+    inp["raw_rotations"][0, 0] = 0.0
+    inp["raw_rotations"][0, 1] = [1e-12, 0, 0, 0]
+    inp["raw_scales"][0, 2] = [40.0, -40.0, 0.0]
+    inp["depths"][0, 3] = [1e-4, 1e4]
+    inp["coordinates"][0, 4] = [0.0, 1.0]
+    rng = np.random.default_rng(1)
+    grads = dict(means=rng.normal(size=(1, 8, 2, 3)).astype(np.float32),
+                 covariances=rng.normal(size=(1, 8, 2, 3, 3)).astype(np.float32))
+    out, din = run_kernel(inp, grads, hip_device)
+    ref, dref = ao.adapter_forward_backward(inp, grads, torch.float32)
+    for k in out:
+        assert np.isfinite(out[k]).all(), k
+        np.testing.assert_allclose(out[k], ref[k], rtol=2e-5, atol=1e-6 * max(1.0, float(np.abs(ref[k]).max())), err_msg=k)
+    for k in din:
+        assert np.isfinite(din[k]).all(), k
+        scale = max(1e-6, float(np.abs(dref[k]).max()))
+        assert np.abs(din[k] - dref[k]).max() <= 2e-4 * scale, k

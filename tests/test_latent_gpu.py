@@ -125,3 +125,21 @@ def test_latent_abi_errors(hip_device):
     assert lib.lsr_latent_forward(C.byref(d), C.byref(_lib.LatentInputs()), C.byref(_lib.LatentOutputs()), None) == -2
     d.width = 2000
     assert lib.lsr_latent_forward(C.byref(d), C.byref(_lib.LatentInputs()), C.byref(_lib.LatentOutputs()), None) == -5
+
+
+def test_extreme_masks_and_nan_propagation(hip_device):
+    """mask = 1 (opaque: logvar clamps to -30), mask = 0 (empty: unit variance), and a mask slightly
+    above 1 (cannot come out of the rasterizer, but the reference would give NaN there: so do we)."""
+    from latentsplat_amd.decoder.latent_epilogue import sample_rescale_skip
+    feats = torch.zeros(1, 1, 2, 16, 16, device=hip_device)
+    mask = torch.zeros(1, 1, 16, 16, device=hip_device)
+    mask[0, 0, 0, 0], mask[0, 0, 0, 1], mask[0, 0, 0, 2] = 1.0, 0.0, 1.0 + 1e-3
+    noise = torch.ones(1, 1, 2, 16, 16, device=hip_device)
+    ep = sample_rescale_skip(feats, mask, None, 8, noise=noise)
+    ref = lo.latent_epilogue(feats.cpu(), mask.cpu(), noise.cpu(), None, 8)
+    s, r = ep.latent_sample.cpu(), ref["sample"]
+    assert torch.isnan(s[0, 0, :, 0, 2]).all() and torch.isnan(r[0, 0, :, 0, 2]).all()
+    ok = ~torch.isnan(r)
+    assert torch.allclose(s[ok], r[ok], rtol=2e-5, atol=1e-6)
+    assert float(ep.logvar[0, 0, 0, 0, 0]) == -30.0 and abs(float(ep.logvar[0, 0, 0, 0, 1])) < 1e-6
+    assert abs(float(s[0, 0, 0, 0, 0]) - float(torch.exp(torch.tensor(-15.0)))) < 1e-9     # std = e^-15
