@@ -115,7 +115,7 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror
                        (const uint32_t *)(geom + L.tile_count), (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
                        (uint32_t *)(geom + L.header), host_mirror, (uint32_t *)(geom + L.tile_order), (uint32_t *)(geom + L.tile_lpt), N,
                        getenv("LSR_SPLIT") ? atoi(getenv("LSR_SPLIT")) : 0,
-                       getenv("LSR_LIMIT") ? atoi(getenv("LSR_LIMIT")) : 100000);
+                       getenv("LSR_LIMIT") ? atoi(getenv("LSR_LIMIT")) : 150);
     prof_end(kStTileScan, s);
     return hipGetLastError();
 }

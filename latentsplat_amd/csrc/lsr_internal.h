@@ -106,9 +106,11 @@ inline GradLayout grad_layout(const lsr_dims &d) {
 // Compositing work items: one wave renders the quadrants in `own` of one (view, tile).
 //   item = (view*T + tile) | own << 28.  k_tile_scan emits them costliest-first.  When there are
 //   fewer tiles than wave slots every tile is split into 2 or 4 items (disjoint quadrant sets) to
-//   fill the machine.  Splitting only the LONG lists for balance is implemented but off by
-//   default (LSR_LIMIT=<percent of mean length>): measured on MI355X each extra item re-pays the
-//   per-entry staging cost and the makespan did not improve (experiments).
+//   fill the machine.  Tiles whose list is longer than 1.5x the mean are split as well (LSR_LIMIT =
+//   percent of the mean, default 150): per-item traces on MI355X show that the launch ends with the
+//   ONE wave that walks the longest list (its serial chain, 1.8x the mean list, outlasts every
+//   balanced SIMD total by ~20 %); halving those few items costs a second staging of their entries
+//   and took the 16-view launch from 0.55 to 0.51 ms.  Splitting more (<= 130 %) loses again.
 // Input slice a view reads: its own (per-view strides), its group's, or the shared one (stride 0).
 __host__ __device__ inline int input_slice(const lsr_dims &d, int v) { return d.views_per_group > 1 ? v / d.views_per_group : v; }
 
