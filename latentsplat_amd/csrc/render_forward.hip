@@ -43,7 +43,7 @@ struct RenderFwdParams {
     const uint32_t *items;        // work items, costliest first
     const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t *queue;              // work-queue head (zeroed per forward)
-    unsigned long long *trace;    // debug (LSR_TRACE): per item {start clk, end clk, hw id, entries}
+    unsigned long long *trace;    // debug (LSR_TRACE): per item {start clk, end clk, hw id, evaluations << 32 | entries}
     const float *views;
     const float4 *rec;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
     int rec_f4;
@@ -100,6 +100,7 @@ k_render_fwd(RenderFwdParams p) {
             if (qi >= num_items) break;
         }
         const unsigned long long t_begin = p.trace ? __builtin_readcyclecounter() : 0ull;
+        uint32_t trace_evals = 0;   // debug (LSR_TRACE): (entry, quadrant) evaluations of this item
         const uint32_t item = p.items[qi];
         const uint32_t vt = item & kItemTileMask, own = item >> kItemOwnShift;
         const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
@@ -152,6 +153,10 @@ k_render_fwd(RenderFwdParams p) {
 #pragma unroll
             for (int k = 0; k < PXL; ++k) qbits[k] = __ballot((m >> k) & 1u);
             wave_lds_fence();  // staged records are visible to this wave's reads below
+            if (p.trace) {
+#pragma unroll
+                for (int k = 0; k < PXL; ++k) trace_evals += (uint32_t)__builtin_popcountll(qbits[k]);
+            }
 
             // Walk each quadrant's entries front to back, UNR at a time: the alpha evaluations of
             // the UNR entries are independent; only the short transmittance chain is serial.
@@ -239,7 +244,7 @@ k_render_fwd(RenderFwdParams p) {
             p.trace[4 * (size_t)qi + 0] = t_begin;
             p.trace[4 * (size_t)qi + 1] = __builtin_readcyclecounter();
             p.trace[4 * (size_t)qi + 2] = ((unsigned long long)xcc << 32) | hwid;
-            p.trace[4 * (size_t)qi + 3] = ((unsigned long long)own << 32) | (end - start);
+            p.trace[4 * (size_t)qi + 3] = ((unsigned long long)trace_evals << 32) | (end - start);
         }
     }  // persistent item loop
 }
