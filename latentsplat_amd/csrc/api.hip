@@ -8,6 +8,7 @@
 
 using namespace lsr;
 
+#include <mutex>
 #include <vector>
 
 static thread_local int g_last_hip_error = 0;
@@ -48,6 +49,38 @@ void lsr::prof_end(int stage, hipStream_t s) {
 
 void lsr::note_hip_error(int e) { g_last_hip_error = e; }
 
+// Compute units of the current device, cached per device id (a process may drive several GPUs).
+int lsr::device_cus() {
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            n = 256;   // MI355X
+        }
+        __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
+    }
+    return n;
+}
+
+// Development knobs (LSR_SPLIT, LSR_LIMIT, LSR_PXL_BWD, ...): read from the environment once per
+// process and knob, then served from a table — no getenv on the launch path.
+int lsr::env_int(const char *name, int fallback) {
+    struct Knob { const char *name; int value; };
+    static Knob knobs[16];
+    static int n_knobs = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < n_knobs; ++i)
+        if (!strcmp(knobs[i].name, name)) return knobs[i].value;
+    const char *e = getenv(name);
+    const int v = e ? atoi(e) : fallback;
+    if (n_knobs < 16) knobs[n_knobs++] = {name, v};
+    return v;
+}
+
 static int fail_hip(hipError_t e) {
     g_last_hip_error = (int)e;
     return LSR_ELAUNCH;
@@ -82,7 +115,10 @@ static int check_dims(const lsr_dims *d) {
         if (d->sh_coeffs < (d->sh_degree + 1) * (d->sh_degree + 1)) return LSR_EINVAL;
     }
     if (tiles_x(*d) > 65535 || tiles_y(*d) > 65535) return LSR_EUNSUPPORTED;
-    if ((int64_t)d->num_views * num_tiles(*d) > (int64_t)1 << 30) return LSR_EUNSUPPORTED;
+    // work items pack (view*T + tile) into 28 bits (kItemTileMask)
+    if ((int64_t)d->num_views * num_tiles(*d) >= (int64_t)1 << 28) return LSR_EUNSUPPORTED;
+    // pair counts and tile offsets are 32-bit: every Gaussian can touch every tile
+    if ((int64_t)d->num_views * d->num_gaussians >= (int64_t)1 << 31) return LSR_EUNSUPPORTED;
     // per-view strides: 0 (shared scene) or exactly one dense (G, ...) array per view
     const int64_t G = d->num_gaussians;
     const int64_t color_elems = d->color_mode == LSR_COLOR_SH ? (int64_t)d->sh_coeffs * 3 : 3;

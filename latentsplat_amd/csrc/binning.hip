@@ -21,7 +21,7 @@ constexpr int kScanThreads = 1024;
 
 __global__ void __launch_bounds__(kScanThreads)
 k_tile_scan(const uint32_t *__restrict__ count, const uint32_t *__restrict__ cost, uint32_t *__restrict__ start, uint32_t *header,
-            uint32_t *host_mirror, uint32_t *__restrict__ order, uint32_t *__restrict__ lpt, int N, int force_base, int limit_pct) {
+            uint32_t *host_mirror, uint32_t *__restrict__ order, uint32_t *__restrict__ lpt, int N, int force_base, int limit_pct, uint32_t slots) {
     __shared__ uint32_t s_sum[kScanThreads];
     __shared__ uint32_t s_max[kScanThreads];
     const int tid = threadIdx.x;
@@ -60,7 +60,7 @@ k_tile_scan(const uint32_t *__restrict__ count, const uint32_t *__restrict__ cos
         __syncthreads();
     }
     const uint64_t scale = (uint64_t)s_max[0] + 1u;
-    uint32_t base = (uint32_t)N >= (uint32_t)kWaveSlots ? 1u : (2u * (uint32_t)N >= (uint32_t)kWaveSlots ? 2u : 4u);
+    uint32_t base = (uint32_t)N >= slots ? 1u : (2u * (uint32_t)N >= slots ? 2u : 4u);
     if (force_base) base = (uint32_t)force_base;
     const uint32_t mean = total / (uint32_t)N + 1u;
     const uint32_t limit = (uint32_t)((uint64_t)mean * (uint32_t)limit_pct / 100u) / base + 1u;   // longest list one item may walk
@@ -114,8 +114,7 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
                        (const uint32_t *)(geom + L.tile_count), (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
                        (uint32_t *)(geom + L.header), host_mirror, (uint32_t *)(geom + L.tile_order), (uint32_t *)(geom + L.tile_lpt), N,
-                       getenv("LSR_SPLIT") ? atoi(getenv("LSR_SPLIT")) : 0,
-                       getenv("LSR_LIMIT") ? atoi(getenv("LSR_LIMIT")) : 150);
+                       env_int("LSR_SPLIT", 0), env_int("LSR_LIMIT", 150), (uint32_t)wave_slots(device_cus()));
     prof_end(kStTileScan, s);
     return hipGetLastError();
 }

@@ -62,6 +62,44 @@ __device__ __forceinline__ uint32_t quadrant_mask(float x, float y, float A, flo
            ((uint32_t)(xr && yb) << 3);
 }
 
+// Finer version of the same test: 16-bit mask of the tile's 4x4-pixel sub-blocks the footprint box
+// can reach; bit (4*row + col) <-> sub-block with origin (4*col, 4*row).  The compositing kernels
+// give every 16-lane group of a wave its own sub-block (one pixel per lane), so a staged entry is
+// only evaluated by the lane groups whose sub-block it can touch: on the bench scene 39 pixel
+// evaluations per (Gaussian, tile) pair instead of 77 with 8x8 quadrants (15 of them pass the
+// alpha test).  Same conservative box as quadrant_mask, hence lossless.
+__device__ __forceinline__ uint32_t span_mask4(float lo, float hi) {
+    // cells c = 0..3 cover pixel centres 4c .. 4c+3; cell c is reached iff lo <= 4c+3 && hi >= 4c
+    const int c0 = max(0, (int)__builtin_ceilf((lo - 3.0f) * 0.25f));
+    const int c1 = min(3, (int)__builtin_floorf(hi * 0.25f));
+    return c0 <= c1 ? ((2u << c1) - (1u << c0)) : 0u;
+}
+__device__ __forceinline__ uint32_t subblock_mask(float x, float y, float A, float B, float C, float o,
+                                                  float tile_x0, float tile_y0) {
+    if (!(o >= LSR_ALPHA_MIN)) return 0u;
+    const float det = A * C - B * B;
+    if (!(det > 0.0f) || !(A * C < 1000.0f * det)) return 0xFFFFu;
+    // hardware log2 / rcp / sqrt (1 ulp): the box carries 0.1 % + 0.05 px of slack
+    const float tau = __builtin_amdgcn_logf(255.0f * o) * (0.6931471806f * 1.0001f) + 1e-4f;
+    const float s = 2.0f * tau * __builtin_amdgcn_rcpf(det);
+    const float ex = __builtin_amdgcn_sqrtf(s * C) * 1.001f + 0.05f;
+    const float ey = __builtin_amdgcn_sqrtf(s * A) * 1.001f + 0.05f;
+    const float x0 = x - ex - tile_x0, x1 = x + ex - tile_x0;
+    const float y0 = y - ey - tile_y0, y1 = y + ey - tile_y0;
+    if (!(x0 == x0) || !(x1 == x1) || !(y0 == y0) || !(y1 == y1)) return 0xFFFFu;
+    if (!(x0 <= 15.0f && x1 >= 0.0f && y0 <= 15.0f && y1 >= 0.0f)) return 0u;
+    // clamp before the float -> int conversions (huge footprints)
+    const uint32_t cm = span_mask4(fmaxf(x0, -8.0f), fminf(x1, 24.0f));
+    const uint32_t rm = span_mask4(fmaxf(y0, -8.0f), fminf(y1, 24.0f));
+    return ((rm & 1u) ? cm : 0u) | ((rm & 2u) ? cm << 4 : 0u) | ((rm & 4u) ? cm << 8 : 0u) | ((rm & 8u) ? cm << 12 : 0u);
+}
+// sub-blocks of quadrant q (origin (8*(q&1), 8*(q>>1))): bits {r*4+c : r in 2*(q>>1)+{0,1}, c in 2*(q&1)+{0,1}}
+__host__ __device__ constexpr uint32_t quadrant_subblocks(int q) { return 0x33u << (8 * (q >> 1) + 2 * (q & 1)); }
+__device__ __forceinline__ uint32_t own_subblocks(uint32_t own) {
+    return ((own & 1u) ? quadrant_subblocks(0) : 0u) | ((own & 2u) ? quadrant_subblocks(1) : 0u) |
+           ((own & 4u) ? quadrant_subblocks(2) : 0u) | ((own & 8u) ? quadrant_subblocks(3) : 0u);
+}
+
 // Quadrants owned by wave `part` of a tile for a given pixels-per-lane setting.
 template <int PXL>
 __device__ __forceinline__ int owned_quadrant(int part, int k) {

@@ -116,7 +116,13 @@ __host__ __device__ inline int input_slice(const lsr_dims &d, int v) { return d.
 
 constexpr uint32_t kItemTileMask = 0x0FFFFFFFu;
 constexpr int kItemOwnShift = 28;
-constexpr int kWaveSlots = 256 * 4 * 4;   // CUs x SIMDs x resident compositing waves per SIMD
+// The compositing kernels run one 16-wave workgroup (4 waves per SIMD) per compute unit; the number
+// of CUs is queried per device (api.hip), so a partitioned (CPX) or binned part gets its own static
+// assignment.  wave slots = CUs x SIMDs x resident compositing waves per SIMD.
+int device_cus();                                   // multiProcessorCount of the current device (cached per device)
+inline int wave_slots(int cus) { return cus * 4 * 4; }
+// Environment knobs are development aids; each is read ONCE per process (never on the launch path).
+int env_int(const char *name, int fallback);        // api.hip: latched on first use
 // header words of the geometry workspace
 enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrQueueFwd = 2, kHdrNumItems = 3 };
 

@@ -28,8 +28,6 @@
 
 namespace lsr {
 
-constexpr int kBwdBins = kWaveSlots / 4;
-constexpr int kBwdCUs = kBwdBins / 4;
 
 __device__ __forceinline__ void wave_lds_fence_bwd() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -39,6 +37,7 @@ __device__ __forceinline__ void wave_lds_fence_bwd() {
 
 struct RenderBwdParams {
     int H, W, gx, T, G, C, has_color;
+    int num_cus;                  // workgroups of 16 waves (one per compute unit)
     uint32_t num_units;           // V * T * (4 / PXL)
     const uint32_t *tile_lpt;     // (view*T + tile), costliest first
     uint32_t *queue;              // work-queue head (zeroed with the gradient workspace)
@@ -70,21 +69,22 @@ k_render_bwd(RenderBwdParams p) {
     const int coff = p.has_color ? 3 : 0;
     const size_t HW = (size_t)p.H * p.W;
 
-    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)kBwdCUs);   // 0..15
-    const uint32_t bin = (blockIdx.x % (uint32_t)kBwdCUs) * 4u + (vwave & 3u);
+    const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = simd_bins * 4u;
+    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);   // 0..15
+    const uint32_t bin = (blockIdx.x % (uint32_t)p.num_cus) * 4u + (vwave & 3u);
     const uint32_t j0 = vwave >> 2;
     bool first = true;
     for (;;) {
         uint32_t ui;
         if (first) {
-            ui = (j0 & 1u) ? (j0 + 1u) * (uint32_t)kBwdBins - 1u - bin : j0 * (uint32_t)kBwdBins + bin;
+            ui = (j0 & 1u) ? (j0 + 1u) * simd_bins - 1u - bin : j0 * simd_bins + bin;
             first = false;
             if (ui >= p.num_units) continue;
         } else {
-            if (p.num_units <= (uint32_t)kWaveSlots) break;
+            if (p.num_units <= slots) break;
             uint32_t t = 0;
             if (lane == 0) t = atomicAdd(p.queue, 1u);
-            ui = (uint32_t)kWaveSlots + __builtin_amdgcn_readfirstlane(t);
+            ui = slots + __builtin_amdgcn_readfirstlane(t);
             if (ui >= p.num_units) break;
         }
         const uint32_t vt = p.tile_lpt[ui / NW];
@@ -251,8 +251,8 @@ k_render_bwd(RenderBwdParams p) {
 }
 
 static int pick_pxl_bwd(int nchp, int64_t tiles_total) {
-    if (const char *e = getenv("LSR_PXL_BWD")) {
-        const int x = atoi(e);
+    {
+        const int x = env_int("LSR_PXL_BWD", 0);   // development knob, latched once
         if (x == 1 || x == 2 || x == 4) return nchp > 12 ? 1 : ((nchp > 8 && x == 4) ? 2 : x);
     }
     // aim for >= 4 waves on each of the 1024 SIMDs (the kernel is VALU bound and needs them)
@@ -265,12 +265,10 @@ static int pick_pxl_bwd(int nchp, int64_t tiles_total) {
 template <int NCHP, int PXL, bool DG, int WPB>
 static void launch_variant(const RenderBwdParams &p, hipStream_t s) {
     const size_t shm = (size_t)WPB * LSR_WAVE * (2 + NCHP / 4) * sizeof(float4);
-    static bool attr_set = false;
-    if (!attr_set && shm > 65536) {
+    // function attributes are per device: set on every launch that needs it (a process may drive several GPUs)
+    if (shm > 65536)
         (void)hipFuncSetAttribute((const void *)k_render_bwd<NCHP, PXL, DG, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_render_bwd<NCHP, PXL, DG, WPB>), dim3(kBwdCUs * (16 / WPB)), dim3(LSR_WAVE * WPB), shm, s, p);
+    hipLaunchKernelGGL((k_render_bwd<NCHP, PXL, DG, WPB>), dim3(p.num_cus * (16 / WPB)), dim3(LSR_WAVE * WPB), shm, s, p);
 }
 
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
@@ -284,6 +282,7 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     RenderBwdParams p;
     p.H = d.height; p.W = d.width; p.gx = tiles_x(d); p.T = (int)num_tiles(d); p.G = d.num_gaussians;
     p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE;
+    p.num_cus = device_cus();
     p.views = in.views;
     p.geo = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
     p.tile_start = (const uint32_t *)(geom + L.tile_start);

@@ -4,13 +4,20 @@
 //
 // Execution shape (CDNA4): persistent waves process work items — (view, tile, set of 8x8
 // quadrants), sorted by list length (lsr_internal.h kItem*): the first one per wave by a static
-// balanced assignment, further ones from a global queue.  A lane owns the same position
-// in each of the 4 quadrants (4 pixels per lane); quadrants outside the item's set are simply
-// never touched.  Per 64 staged list entries the wave walks, quadrant by quadrant, only the
-// entries whose alpha >= 1/255 footprint can reach that quadrant (lsr_blend.h), UNR at a time.
-// Measured on MI355X the kernel is bound by f32 VALU issue (~4 cycles per wave64 instruction),
-// so the inner loop keeps per-pixel state decisions in scalar lane masks (SALU) rather than VGPR
-// selects, and the quadrant culling + item splitting exist to cut / balance VALU work.
+// balanced assignment, further ones from a global queue.
+//
+// Inside an item the wave works on one 8x8 quadrant at a time ("round"), and the quadrant is
+// split into four 4x4-pixel SUB-BLOCKS, one per 16-lane group (one pixel per lane, 4 pixels per
+// lane over the four rounds).  The 64 list entries staged per batch are compacted into 16
+// per-sub-block lists in LDS (ballot + mbcnt, entries keep their depth order); in a round every
+// lane group then walks ITS sub-block's list, so one wave instruction evaluates up to four
+// different entries, each only on a sub-block its alpha >= 1/255 footprint can reach
+// (lsr_blend.h subblock_mask, lossless).  Round 1 of this kernel evaluated an entry on whole 8x8
+// quadrants (wave-uniform entry): 77 pixel evaluations per (Gaussian, tile) pair, 19 % of them
+// passing the alpha test; sub-blocks need 39, and the number of lock-step iterations per pair
+// drops from 1.23 to 0.75 (max over the four lists of a round; census in DESIGN.md).
+// The kernel is bound by f32 VALU issue, so that ratio is the speed-up; per-pixel blend / skip /
+// stop decisions stay scalar lane-mask algebra (SALU) — a lane is still exactly one pixel.
 #include <stdio.h>
 
 #include <vector>
@@ -19,15 +26,6 @@
 
 namespace lsr {
 
-// One workgroup of 16 independent waves per CU (4 per SIMD; the waves never synchronise with each
-// other).  Waves w, w+4, w+8, w+12 of a workgroup share a SIMD, which lets the kernel decide
-// WHICH work items share a SIMD: items arrive sorted by cost, and SIMD-bin b takes items
-// b, 2B-1-b, 2B+b, 4B-1-b, ... (B = number of bins) — pairing expensive with cheap tiles so every
-// SIMD gets nearly the same total.  The kernel is VALU-throughput bound, so the makespan is the
-// largest per-SIMD total; with one item per wave and no control over placement it was ~1.4x the
-// mean (measured).
-constexpr int kSimdBins = kWaveSlots / 4;
-constexpr int kCUs = kSimdBins / 4;
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave execute in order; this only stops the compiler from moving LDS
     // accesses across the staging / consuming phases and drains the wave's own LDS queue.
@@ -40,10 +38,11 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 
 struct RenderFwdParams {
     int H, W, gx, T, G, C, has_color;
+    int num_cus;                  // workgroups of 16 waves (one per compute unit)
     const uint32_t *items;        // work items, costliest first
     const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t *queue;              // work-queue head (zeroed per forward)
-    unsigned long long *trace;    // debug (LSR_TRACE): per item {start clk, end clk, hw id, evaluations << 32 | entries}
+    unsigned long long *trace;    // debug builds (LSR_ENABLE_TRACE): per item {start clk, end clk, hw id, iterations << 32 | entries}
     const float *views;
     const float4 *rec;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
     int rec_f4;
@@ -53,63 +52,92 @@ struct RenderFwdParams {
     uint32_t *n_contrib;
 };
 
+// One workgroup of 16 independent waves per CU (4 per SIMD; the waves never synchronise with each
+// other).  Waves w, w+4, w+8, w+12 of a workgroup share a SIMD, which lets the kernel decide
+// WHICH work items share a SIMD: items arrive sorted by cost, and SIMD-bin b takes items
+// b, 2B-1-b, 2B+b, 4B-1-b, ... (B = number of bins) — pairing expensive with cheap tiles so every
+// SIMD gets nearly the same total.
 // WPB = waves per workgroup: 16 (one workgroup per CU) unless the LDS slices do not fit, then 4
 // workgroups of 4 waves stand in for it (same bins, placement then up to the dispatcher).
 template <int NCHP, int UNR, int WPB>
 __global__ void __launch_bounds__(LSR_WAVE * WPB)
 k_render_fwd(RenderFwdParams p) {
     constexpr int PXL = 4;
-    // Staged entries, one record per list entry: (x, y, a2, b2) (c2, log2 o, z, -) payload...
-    // One LDS address per entry (a single VALU add, the parts at immediate offsets); the odd
-    // float4 stride keeps the per-lane staging stores bank-conflict free.  Slot 64 is a null
-    // record (alpha == 0) that pads partial groups.
+    // Staged entries, one record per list entry: (x, y, a2, c2) (b2, log2 o, z, -1) payload...
+    // ((x, y), (a2, c2) and (z, -1) are operand pairs of the packed f32 instructions below)
+    // The odd float4 stride keeps the per-lane staging stores bank-conflict free.  Slot 64 is a
+    // null record (alpha == 0) that pads the sub-block lists.
     constexpr int kEnt = (2 + NCHP / 4) | 1;
-    __shared__ float4 s_ent_all[WPB][LSR_WAVE + 1][kEnt];
+    // One shared object, entries first: the byte offsets kept in the lists are then plain LDS
+    // addresses (base 0 folds into the ds_read immediate, no address arithmetic per entry).
+    struct Lds {
+        float4 ent[WPB][LSR_WAVE + 1][kEnt];
+        uint32_t list[WPB][16][LSR_WAVE];   // list[b][i] = offset of the i-th staged entry that can reach sub-block b
+    };
+    __shared__ Lds s_lds;
 
     const int lane = threadIdx.x & (LSR_WAVE - 1);
-    const int wid = threadIdx.x / LSR_WAVE;
-    float4 (*s_ent)[kEnt] = s_ent_all[wid];
+    // wave-uniform values are made provably so (readfirstlane): loop control, list bounds and the
+    // per-pixel lane masks then live in SGPRs and the item loop is scalar control flow
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / LSR_WAVE);
+    float4 (*s_ent)[kEnt] = s_lds.ent[wid];
+    uint32_t (*s_list)[LSR_WAVE] = s_lds.list[wid];
+    const char *ent_base = (const char *)&s_lds.ent[0][0][0];
+    const uint32_t wave_off = (uint32_t)(wid * (LSR_WAVE + 1) * kEnt * 16);
+    const uint32_t my_off = wave_off + (uint32_t)(lane * kEnt * 16);
+    const uint32_t null_off = wave_off + (uint32_t)(LSR_WAVE * kEnt * 16);
     if (lane == 0) {
         s_ent[LSR_WAVE][0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        s_ent[LSR_WAVE][1] = make_float4(0.0f, -INFINITY, 0.0f, 0.0f);  // log2(opacity) = -inf
+        s_ent[LSR_WAVE][1] = make_float4(0.0f, -INFINITY, 0.0f, -1.0f);  // log2(opacity) = -inf
 #pragma unroll
         for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     const uint32_t num_items = p.header[kHdrNumItems];
     const int coff = p.has_color ? 3 : 0;
     const size_t HW = (size_t)p.H * p.W;
+    // lane group -> sub-block of the round's quadrant; lane -> pixel of the sub-block
+    const int grp = lane >> 4, gcol = grp & 1, grow = grp >> 1;
+    const int gsb = 4 * grow + gcol;   // + 8*(k>>1) + 2*(k&1) = this group's sub-block in round k
+    const int lx = lane & 3, ly = (lane >> 2) & 3;
 
-    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)kCUs);   // 0..15
-    const uint32_t bin = (blockIdx.x % (uint32_t)kCUs) * 4u + (vwave & 3u);
+    const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = simd_bins * 4u;
+    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);   // 0..15
+    const uint32_t bin = (blockIdx.x % (uint32_t)p.num_cus) * 4u + (vwave & 3u);
     // First item of every wave: static, folded (boustrophedon) over the cost-sorted list, so the 4
-    // waves of a SIMD start with a balanced total.  Everything beyond the first kWaveSlots items
+    // waves of a SIMD start with a balanced total.  Everything beyond the first `slots` items
     // is pulled from a global queue (costliest first) as waves become free.
     const uint32_t j0 = vwave >> 2;
     bool first = true;
     for (;;) {
         uint32_t qi;
         if (first) {
-            qi = (j0 & 1u) ? (j0 + 1u) * (uint32_t)kSimdBins - 1u - bin : j0 * (uint32_t)kSimdBins + bin;
+            qi = (j0 & 1u) ? (j0 + 1u) * simd_bins - 1u - bin : j0 * simd_bins + bin;
             first = false;
             if (qi >= num_items) continue;   // fewer items than wave slots: go straight to the queue (empty)
         } else {
-            if (num_items <= (uint32_t)kWaveSlots) break;
+            if (num_items <= slots) break;
             uint32_t t = 0;
             if (lane == 0) t = atomicAdd(p.queue, 1u);
-            qi = (uint32_t)kWaveSlots + __builtin_amdgcn_readfirstlane(t);
+            qi = slots + __builtin_amdgcn_readfirstlane(t);
             if (qi >= num_items) break;
         }
+#ifdef LSR_ENABLE_TRACE
         const unsigned long long t_begin = p.trace ? __builtin_readcyclecounter() : 0ull;
-        uint32_t trace_evals = 0;   // debug (LSR_TRACE): (entry, quadrant) evaluations of this item
+        uint32_t trace_iters = 0;   // lock-step iterations of this item
+#endif
+        qi = __builtin_amdgcn_readfirstlane(qi);
         const uint32_t item = p.items[qi];
         const uint32_t vt = item & kItemTileMask, own = item >> kItemOwnShift;
+        const uint32_t own16 = own_subblocks(own);
         const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
         const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE;
         const size_t vG = (size_t)v * p.G;
         const uint32_t start = p.tile_start[vt], end = p.tile_start[vt + 1];
 
-        float pxf[PXL], pyf[PXL], Tr[PXL], accd[PXL];
-        float acc[PXL][NCHP];
+        // per-pixel state; (x, y), (depth sum, T) and the payload channels two by two are register
+        // pairs so the blend runs on packed f32 instructions
+        float2_t pxy[PXL], dT[PXL];          // pixel centre; (sum alpha T z, transmittance)
+        float2_t acc[PXL][NCHP / 2];
         uint32_t stop_pos[PXL];
         // Per-pixel "finished" flags live in scalar registers as 64-bit lane masks, so the skip /
         // blend / stop decisions are SALU mask algebra instead of per-lane VALU selects.
@@ -117,13 +145,13 @@ k_render_fwd(RenderFwdParams p) {
         bool inside[PXL];
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
-            const int px = tx0 + 8 * (k & 1) + (lane & 7), py = ty0 + 8 * (k >> 1) + (lane >> 3);
-            pxf[k] = (float)px; pyf[k] = (float)py;
+            const int px = tx0 + 8 * (k & 1) + 4 * gcol + lx, py = ty0 + 8 * (k >> 1) + 4 * grow + ly;
+            pxy[k] = float2_t{(float)px, (float)py};
             inside[k] = px < p.W && py < p.H && ((own >> k) & 1u);
             done[k] = __ballot(!inside[k]);
-            Tr[k] = 1.0f; accd[k] = 0.0f; stop_pos[k] = 0;
+            dT[k] = float2_t{0.0f, 1.0f}; stop_pos[k] = 0;
 #pragma unroll
-            for (int c = 0; c < NCHP; ++c) acc[k][c] = 0.0f;
+            for (int c = 0; c < NCHP / 2; ++c) acc[k][c] = float2_t{0.0f, 0.0f};
         }
 
         for (uint32_t base = start; base < end; base += LSR_WAVE) {
@@ -133,79 +161,99 @@ k_render_fwd(RenderFwdParams p) {
             if (all_done == ~0ull) break;
 
             // ---- stage up to 64 list entries (one per lane) ----
+            {   // every list slot starts as the null record; the compaction below overwrites a prefix
+                const uint4 nul = make_uint4(null_off, null_off, null_off, null_off);
+                uint4 *L4 = (uint4 *)&s_list[0][0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) L4[q * LSR_WAVE + lane] = nul;
+            }
             const uint32_t e = base + lane;
             uint32_t m = 0;
             if (e < end) {
                 const uint32_t g = p.point_list[e];
                 const float4 *R = p.rec + (vG + g) * (size_t)p.rec_f4;
                 const float4 a = R[0], b = R[1];  // (x,y,A,B) (C,o,z,-)
-                m = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own;
+                m = subblock_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own16;
                 if (m) {
                     const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
-                    s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.b2);
-                    s_ent[lane][1] = make_float4(f.c2, f.l2o, b.z, 0.0f);
+                    s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
+                    s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z, -1.0f);
 #pragma unroll
                     for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[lane][2 + c4] = R[2 + c4];  // payload, zero padded
                 }
             }
-            // per quadrant: which staged entries can touch it (wave-uniform 64-bit masks)
-            uint64_t qbits[PXL];
+            // compaction: per sub-block, the staged entries that can reach it, in list order
+            uint32_t cnt[16];
 #pragma unroll
-            for (int k = 0; k < PXL; ++k) qbits[k] = __ballot((m >> k) & 1u);
-            wave_lds_fence();  // staged records are visible to this wave's reads below
-            if (p.trace) {
-#pragma unroll
-                for (int k = 0; k < PXL; ++k) trace_evals += (uint32_t)__builtin_popcountll(qbits[k]);
+            for (int b = 0; b < 16; ++b) {
+                cnt[b] = 0;
+                if (!((own16 >> b) & 1u)) continue;   // wave-uniform
+                const uint64_t bal = __ballot((m >> b) & 1u);
+                cnt[b] = (uint32_t)__builtin_popcountll(bal);
+                if (__builtin_amdgcn_inverse_ballot_w64(bal)) {
+                    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    s_list[b][at] = my_off;
+                }
             }
+            wave_lds_fence();  // staged records and lists are visible to this wave's reads below
 
-            // Walk each quadrant's entries front to back, UNR at a time: the alpha evaluations of
-            // the UNR entries are independent; only the short transmittance chain is serial.
+            // One round per quadrant: lane group g walks the list of ITS sub-block, front to back,
+            // UNR entries at a time (independent alpha evaluations; only the short transmittance
+            // chain is serial).  Shorter lists of the round are padded with the null record.
 #pragma unroll
             for (int k = 0; k < PXL; ++k) {
-                uint64_t bits = qbits[k];
-                while (bits) {
-                    int jj[UNR];
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u) {
-                        jj[u] = bits ? __builtin_ctzll(bits) : LSR_WAVE;  // slot 64 = null record
-                        bits &= bits - 1;
-                    }
+                const int b0 = 8 * (k >> 1) + 2 * (k & 1);
+                const uint32_t nk = __builtin_amdgcn_readfirstlane(max(max(cnt[b0], cnt[b0 + 1]), max(cnt[b0 + 4], cnt[b0 + 5])));
+                if (nk == 0 || done[k] == ~0ull) continue;   // wave-uniform
+                const uint32_t *lp = &s_list[b0 + gsb][0];
+#ifdef LSR_ENABLE_TRACE
+                trace_iters += nk;
+#endif
+                for (uint32_t i = 0; i < nk; i += UNR) {
                     float4 a[UNR], b[UNR];
-                    float pay[UNR][NCHP];
+                    float2_t pay[UNR][NCHP / 2];
+                    uint32_t off[UNR];
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) {
-                        a[u] = s_ent[jj[u]][0]; b[u] = s_ent[jj[u]][1];
+                        off[u] = lp[i + u];
+                        const float4 *E = (const float4 *)(ent_base + off[u]);
+                        a[u] = E[0]; b[u] = E[1];
 #pragma unroll
                         for (int c4 = 0; c4 < NCHP / 4; ++c4) {
-                            const float4 t = s_ent[jj[u]][2 + c4];
-                            pay[u][4 * c4] = t.x; pay[u][4 * c4 + 1] = t.y; pay[u][4 * c4 + 2] = t.z; pay[u][4 * c4 + 3] = t.w;
+                            const float4 t = E[2 + c4];
+                            pay[u][2 * c4] = float2_t{t.x, t.y}; pay[u][2 * c4 + 1] = float2_t{t.z, t.w};
                         }
                     }
                     float alpha[UNR];
                     uint64_t ok[UNR];
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) {
-                        const float dx = a[u].x - pxf[k], dy = a[u].y - pyf[k];
-                        const float ex = blend_exponent(dx, dy, a[u].z, a[u].w, b[u].x, b[u].y);
+                        // same operations as blend_exponent (lsr_blend.h), two of them packed
+                        const float2_t d = float2_t{a[u].x, a[u].y} - pxy[k];
+                        const float2_t q = float2_t{a[u].z, a[u].w} * d;              // (a2 dx, c2 dy)
+                        const float p1 = __builtin_fmaf(b[u].x, d.y, q.x);
+                        const float p2 = __builtin_fmaf(q.y, d.y, b[u].y);
+                        const float ex = __builtin_fmaf(p1, d.x, p2);
                         alpha[u] = fminf(LSR_ALPHA_MAX, fast_exp2(ex));
                         // skip if power > 0 or alpha < 1/255 (NaN-safe: comparisons are "keep" tests)
                         ok[u] = __ballot(ex <= b[u].y) & __ballot(alpha[u] >= LSR_ALPHA_MIN);
                     }
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) {
-                        const float aT = alpha[u] * Tr[k];
-                        const float tT = Tr[k] - aT;
+                        const float aT = alpha[u] * dT[k].y;
+                        const float tT = dT[k].y - aT;
                         const uint64_t live = ok[u] & ~done[k];
                         const uint64_t room = __ballot(tT >= LSR_T_EPS);
                         const uint64_t blend = live & room, stop = live & ~room;
                         const float w = __builtin_amdgcn_inverse_ballot_w64(blend) ? aT : 0.0f;
+                        const float2_t ww = float2_t{w, w};
 #pragma unroll
-                        for (int c = 0; c < NCHP; ++c) acc[k][c] = __builtin_fmaf(pay[u][c], w, acc[k][c]);
-                        // (accd, T) += w * (z, -1) as one packed FMA
-                        const float2_t td = __builtin_elementwise_fma(float2_t{b[u].z, -1.0f}, float2_t{w, w}, float2_t{accd[k], Tr[k]});
-                        accd[k] = td.x; Tr[k] = td.y;
+                        for (int c = 0; c < NCHP / 2; ++c) acc[k][c] = __builtin_elementwise_fma(pay[u][c], ww, acc[k][c]);
+                        // (depth sum, T) += w * (z, -1)
+                        dT[k] = __builtin_elementwise_fma(float2_t{b[u].z, b[u].w}, ww, dT[k]);
                         if (stop) {  // rare, wave-uniform: a pixel's transmittance ran out here
-                            const uint32_t pos = base - start + (uint32_t)jj[u] + 1u;
+                            // 1-based list position of the stopping entry, from its staging slot
+                            const uint32_t pos = base - start + 1u + (off[u] - wave_off) / (uint32_t)(kEnt * 16);
                             stop_pos[k] = __builtin_amdgcn_inverse_ballot_w64(stop) ? pos : stop_pos[k];
                             done[k] |= stop;
                         }
@@ -219,24 +267,26 @@ k_render_fwd(RenderFwdParams p) {
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
             if (!inside[k]) continue;
-            const size_t pix = (size_t)pyf[k] * p.W + (size_t)pxf[k];
+            const size_t pix = (size_t)pxy[k].y * p.W + (size_t)pxy[k].x;
             const size_t vp = (size_t)v * HW + pix;
-            p.final_T[vp] = Tr[k];
+            const float Tk = dT[k].y;
+            p.final_T[vp] = Tk;
             // number of leading list entries the backward pass has to consider for this pixel: all
             // of them, or everything before the entry at which the transmittance test stopped it
             p.n_contrib[vp] = stop_pos[k] ? stop_pos[k] - 1u : end - start;
-            p.out_mask[vp] = 1.0f - Tr[k];
-            p.out_depth[vp] = accd[k];
+            p.out_mask[vp] = 1.0f - Tk;
+            p.out_depth[vp] = dT[k].x;
             if (p.has_color) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(Tr[k], vw[37 + c], acc[k][c]);
+                    p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(Tk, vw[37 + c], acc[k][c / 2][c & 1]);
             }
 #pragma unroll
             for (int c = 0; c < NCHP; ++c)
                 if (c >= coff && c - coff < p.C)
-                    p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[k][c];
+                    p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[k][c / 2][c & 1];
         }
+#ifdef LSR_ENABLE_TRACE
         if (p.trace && lane == 0) {
             unsigned hwid, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -244,8 +294,9 @@ k_render_fwd(RenderFwdParams p) {
             p.trace[4 * (size_t)qi + 0] = t_begin;
             p.trace[4 * (size_t)qi + 1] = __builtin_readcyclecounter();
             p.trace[4 * (size_t)qi + 2] = ((unsigned long long)xcc << 32) | hwid;
-            p.trace[4 * (size_t)qi + 3] = ((unsigned long long)trace_evals << 32) | (end - start);
+            p.trace[4 * (size_t)qi + 3] = ((unsigned long long)trace_iters << 32) | (end - start);
         }
+#endif
     }  // persistent item loop
 }
 
@@ -258,6 +309,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     RenderFwdParams p;
     p.H = d.height; p.W = d.width; p.gx = tiles_x(d); p.T = (int)num_tiles(d); p.G = d.num_gaussians;
     p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE;
+    p.num_cus = device_cus();
     p.items = (const uint32_t *)(geom + L.tile_order);
     p.header = (const uint32_t *)(geom + L.header);
     p.queue = (uint32_t *)(geom + L.header) + kHdrQueueFwd;
@@ -269,22 +321,25 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.final_T = (float *)(img + I.final_T); p.n_contrib = (uint32_t *)(img + I.n_contrib);
     const int nch = (p.has_color ? 3 : 0) + d.feat_channels;
     const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));
-    const int64_t max_items = 4 * (int64_t)p.T * d.num_views;
 
     p.trace = nullptr;
+#ifdef LSR_ENABLE_TRACE
+    const int64_t max_items = 4 * (int64_t)p.T * d.num_views;
     const char *trace_path = getenv("LSR_TRACE");
     if (trace_path) {
         (void)hipMalloc((void **)&p.trace, (size_t)max_items * 32);
         (void)hipMemsetAsync(p.trace, 0, (size_t)max_items * 32, s);
     }
+#endif
     prof_begin(kStRenderFwd, s);
-#define LSR_RF(N, U, WPB) hipLaunchKernelGGL((k_render_fwd<N, U, WPB>), dim3(kCUs * (16 / WPB)), dim3(LSR_WAVE * WPB), 0, s, p)
+#define LSR_RF(N, U, WPB) hipLaunchKernelGGL((k_render_fwd<N, U, WPB>), dim3(p.num_cus * (16 / WPB)), dim3(LSR_WAVE * WPB), 0, s, p)
     if (nchp == 4) LSR_RF(4, 2, 16);
     else if (nchp == 8) LSR_RF(8, 2, 16);
     else if (nchp == 12) LSR_RF(12, 2, 16);
     else LSR_RF(36, 1, 4);
 #undef LSR_RF
     prof_end(kStRenderFwd, s);
+#ifdef LSR_ENABLE_TRACE
     if (trace_path) {  // debug only: dump per-item timing of this launch
         std::vector<unsigned long long> host((size_t)max_items * 4);
         (void)hipStreamSynchronize(s);
@@ -292,6 +347,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
         if (FILE *f = fopen(trace_path, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
         (void)hipFree(p.trace);
     }
+#endif
     return hipGetLastError();
 }
 

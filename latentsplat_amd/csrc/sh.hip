@@ -443,11 +443,9 @@ hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom
 
 template <int DEGC, int COFF>
 static void allow_big_lds(size_t shm) {
-    static bool done = false;
-    if (!done && shm > 65536) {
+    // function attributes are per device: set on every launch that needs it (a process may drive several GPUs)
+    if (shm > 65536)
         (void)hipFuncSetAttribute((const void *)k_sh_bwd<DEGC, COFF>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        done = true;
-    }
 }
 
 hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom, const char *grad,
