@@ -26,10 +26,13 @@ struct ImgLayout {
 struct BinLayout {
     size_t keys, point_list, tmp, total;
 };
-// One packed gradient record per (view, Gaussian), accumulated by the compositing backward:
-//   [0] d/dx_pix [1] d/dy_pix [2] d/dA [3] d/dB [4] d/dC (conic) [5] d/dopacity [6] d/dz [7] -
+// One packed gradient record per (view, Gaussian), accumulated by the compositing backward.  With
+// u = opacity * G * dL/dalpha per (pixel, Gaussian) and d = mean_pix - pixel:
+//   [0] sum u dx  [1] sum u dy  [2] sum u dx^2  [3] sum u dx dy  [4] sum u dy^2  [5] sum u  [6] d/dz  [7] -
 //   [8 + c] d/d payload channel c  (rgb first when colour is rendered, then features)
-// 16 floats (one 64-byte line) for <= 8 payload channels, 32 for <= 12, 64 beyond.
+// (k_preprocess_bwd turns the moments into dL/d mean, conic, opacity: the conic and the opacity
+// are constant over a Gaussian's pixels.)  16 floats (one 64-byte line) for <= 8 payload
+// channels, 32 for <= 12, 64 beyond.
 struct GradLayout {
     size_t rec, total;
     int rec_floats;

@@ -63,7 +63,7 @@ k_preprocess_bwd(PreBwdParams p) {
         ViewRec r;
         const size_t o = (size_t)v * G + i;
         const float *rc = p.rec + o * p.rec_floats;
-        r.r0 = *(const float4 *)rc; r.r1 = *(const float4 *)(rc + 4);           // gx gy gA gB | gC go gz -
+        r.r0 = *(const float4 *)rc; r.r1 = *(const float4 *)(rc + 4);           // m1x m1y m2xx m2xy | m2yy m0 gz -
         r.q0 = r.q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (pay16) { r.q0 = *(const float4 *)(rc + 8); r.q1 = *(const float4 *)(rc + 12); }
         r.radius = p.radii[o];
@@ -78,8 +78,13 @@ k_preprocess_bwd(PreBwdParams p) {
         const size_t o = (size_t)v * G + i;
         const float *rc = p.rec + o * p.rec_floats;
         const float4 r0 = cur.r0, r1 = cur.r1;
-        // opacity / features / precomputed colours: plain pass-through of the record
-        if (d.vs_opac != 0) p.g.opacities[(size_t)v * d.vs_opac + i] = r1.y; else aop += r1.y;
+        // opacity: the record holds m0 = sum opacity * G * dL/dalpha; dL/dopacity = m0 / opacity
+        // (m0 != 0 implies opacity >= 1/255)
+        if (d.vs_opac != 0) {
+            const float o_in = p.in.opacities[(size_t)v * d.vs_opac + i];
+            p.g.opacities[(size_t)v * d.vs_opac + i] = r1.y != 0.0f ? r1.y / o_in : 0.0f;
+        } else aop += r1.y;   // shared opacity: one division after the sum over the views
+        // features / precomputed colours: plain pass-through of the record
         if (feat_reg) {
             if (p.rec_floats == 16) {   // the whole payload half of the record as two 16-byte loads
                 const float4 q0 = cur.q0, q1 = cur.q1;
@@ -153,9 +158,18 @@ k_preprocess_bwd(PreBwdParams p) {
             const float b = MS[0][0] * M[1][0] + MS[0][1] * M[1][1] + MS[0][2] * M[1][2];
             const float c = MS[1][0] * M[1][0] + MS[1][1] * M[1][1] + MS[1][2] * M[1][2] + LSR_LOWPASS;
             const float det = a * c - b * b;
-            const float4 gcon = make_float4(r0.z, r0.w, r1.x, 0.0f);
+            // The compositing backward leaves MOMENTS of u = opacity * G * dL/dalpha over the pixels:
+            //   r0 = (sum u dx, sum u dy, sum u dx^2, sum u dx dy), r1.x = sum u dy^2   (d = mean - pixel).
+            // With the conic (A, B, C) = (c, -b, a) / det constant over the pixels:
+            //   dL/dmean_pix = -(A m1x + B m1y, B m1x + C m1y),  dL/d(A, B, C) = -(m2xx / 2, m2xy, m2yy / 2)
+            const float4 gcon = make_float4(-0.5f * r0.z, -r0.w, -0.5f * r1.x, 0.0f);
+            float gpx = 0.0f, gpy = 0.0f;
             float dL_da = 0.0f, dL_db = 0.0f, dL_dc = 0.0f;
             if (det != 0.0f) {
+                const float det_inv = 1.0f / det;
+                const float cA = c * det_inv, cB = -b * det_inv, cC = a * det_inv;
+                gpx = -(cA * r0.x + cB * r0.y);
+                gpy = -(cB * r0.x + cC * r0.y);
                 const float d2 = 1.0f / (det * det);
                 // conic = (c, -b, a) / det
                 dL_da = d2 * (gcon.x * (-c * c) + gcon.y * (b * c) + gcon.z * (det - a * c));
@@ -196,8 +210,8 @@ k_preprocess_bwd(PreBwdParams p) {
             const float h3 = pm[3] * p0 + pm[7] * p1 + pm[11] * p2 + pm[15];
             const float m_w = 1.0f / (h3 + 0.0000001f);
             const float mul1 = h0 * m_w * m_w, mul2 = h1 * m_w * m_w;
-            m2x = r0.x * (0.5f * d.width);   // d pixel / d ndc
-            m2y = r0.y * (0.5f * d.height);
+            m2x = gpx * (0.5f * d.width);   // d pixel / d ndc
+            m2y = gpy * (0.5f * d.height);
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc)
                 gm[cc] += (pm[4 * cc + 0] * m_w - pm[4 * cc + 3] * mul1) * m2x +
@@ -256,7 +270,7 @@ k_preprocess_bwd(PreBwdParams p) {
     }
     if (d.vs_opac == 0) {
         aop = quad_sum<PARTS>(aop);
-        if (writer) p.g.opacities[i] = aop;
+        if (writer) p.g.opacities[i] = aop != 0.0f ? aop / p.in.opacities[i] : 0.0f;
     }
     if (feat_reg) {
 #pragma unroll

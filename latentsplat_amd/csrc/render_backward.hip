@@ -1,5 +1,5 @@
-// render_backward.hip — stage K7: per-pixel gradient of the compositing, with the same quadrant
-// decomposition and culling as the forward (lsr_blend.h).
+// render_backward.hip — stage K7: per-pixel gradient of the compositing, with the same sub-block
+// decomposition, culling and work items as the forward (render_forward.hip, lsr_blend.h).
 //
 // The lists are walked FRONT TO BACK like the forward (the published kernel goes back to front and
 // keeps, per pixel and channel, the colour accumulated behind the current entry: four operations
@@ -7,39 +7,52 @@
 //   R_i = sum_{j>i} w_j (g . c_j)  [+ T_final (g . bg - g_mask)]  =  (g . C_rendered) - prefix_i,
 // seeded from the rendered images of the matching forward; with d_i = g . c_i
 //   dL/dalpha_i = T_i d_i - R_i / (1 - alpha_i),      R_i = R_{i-1} - w_i d_i,   T_{i+1} = T_i (1 - alpha_i)
-// i.e. one dot product and one FMA (payload gradient) per channel.  Half the per-pixel registers,
-// so 8-channel payloads also run 4 pixels per lane.  Cancellation in R only matters when the
-// remaining contribution is already ~1e-7 of the pixel's total — far below the 1e-4 tolerance.
-// Per (entry, pixel): recompute alpha with the forward's exact arithmetic and emit
-//   dL/d(x,y)_pixel, dL/d(A,B,C) conic, dL/d opacity, dL/d payload (rgb / features), dL/d z.
-// The per-lane arithmetic is branch-free: an invalid (pixel, entry) simply has alpha = G = 0, which
-// leaves T, R and every gradient sum unchanged.
-// Per (entry, wave): contributions of the wave's 64*PXL pixels are summed with the transposed
-// butterfly of lsr_blend.h (permlane swaps + DPP, no LDS traffic), which leaves the total of
-// gradient slot s in lane 4s; ONE atomic instruction then adds the whole 64-byte gradient record
-// of the (view, Gaussian) (lsr_internal.h GradLayout).
+// i.e. one dot product and one multiply (payload gradient) per channel.  Cancellation in R only
+// matters when the remaining contribution is already ~1e-7 of the pixel's total — far below the
+// 1e-4 tolerance.
 //
-// Scheduling as in the forward: one 16-wave workgroup per CU; a unit of work is (tile, part) where
-// `part` selects the wave's PXL of the tile's 4 quadrants; units are ordered by list length, the
-// first unit of every wave is assigned statically (folded over the sorted list so the 4 waves of a
-// SIMD get a balanced total), the rest comes from a global queue.
+// Per (entry, pixel) the kernel recomputes alpha with the forward's exact arithmetic and emits the
+// MOMENTS of u = exp2(e) * dL/dalpha (= opacity * G * dL/dalpha) over the entry's pixels:
+//   m0 = sum u,   m1 = sum u (dx, dy),   m2 = sum u (dx^2, dx dy, dy^2),
+// plus w * g per payload channel and w * g_depth.  The conic / opacity factors that turn moments
+// into dL/d(x, y), dL/d(A, B, C), dL/d opacity are applied ONCE per (view, Gaussian) by
+// k_preprocess_bwd (they are constant over the pixels), not per evaluation.
+//
+// Execution shape: one lane = one pixel, one 16-lane group = one 4x4 sub-block walking its own
+// compacted list (as in the forward), so a wave instruction serves up to four different entries.
+// The contributions of a group's 16 pixels are summed by a transposed butterfly INSIDE the DPP row
+// (row_ror / row_half_mirror / quad_perm — full-rate, no permlane, no LDS): afterwards lane s of
+// the group holds gradient slot s, and ONE ds_add_f32 instruction adds the four groups' records
+// into a per-batch LDS table (row = staged entry).  When the batch's four rounds are done the
+// touched rows are flushed with coalesced global atomics, one 64-byte record per 16 lanes: one
+// global record-add per (Gaussian, tile) pair instead of one per (entry, wave) reduction of 64
+// lanes + atomic in round 1 of this kernel (that reduction was ~40 % of its time).
 // Spec: SURVEY.md Appendix A.6.
 #include "lsr_blend.h"
 
 namespace lsr {
 
-
 __device__ __forceinline__ void wave_lds_fence_bwd() {
+    // compiler-only barrier: the LDS slice is private to the wave and its LDS operations execute in
+    // order (a memory fence would also drain the prefetching global loads and the flush atomics)
+#ifdef LSR_X_FENCE
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#endif
 }
+
+typedef float float2_b __attribute__((ext_vector_type(2)));
+typedef float float4_b __attribute__((ext_vector_type(4)));
 
 struct RenderBwdParams {
     int H, W, gx, T, G, C, has_color;
-    int num_cus;                  // workgroups of 16 waves (one per compute unit)
-    uint32_t num_units;           // V * T * (4 / PXL)
-    const uint32_t *tile_lpt;     // (view*T + tile), costliest first
+    int num_cus;                  // workgroups of 4*WPS waves (one per compute unit)
+    const uint32_t *items;        // work items of the forward (view*T + tile | quadrant set << 28), costliest first
+    const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t *queue;              // work-queue head (zeroed with the gradient workspace)
     const float *views;
     const float4 *geo;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
@@ -53,58 +66,137 @@ struct RenderBwdParams {
     int rec_floats;
 };
 
+// ---- transposed reduction inside a DPP row ------------------------------------------------
+// Sums 16 per-lane values over the 16 lanes of a row; every butterfly step halves the number of
+// values a lane still carries and lane l ends up with the row total of value l.
+//   step A  row_ror:8          lane bit 3 selects value i / i+8
+//   step B  row_half_mirror    lane bit 2 selects i / i+4   (partner 7-l: same bit 3, other bit 2)
+//   step C  quad_perm [2,3,0,1] lane bit 1 selects i / i+2
+//   step D  quad_perm [1,0,3,2] lane bit 0 selects i / i+1
+// LIVE = compile-time mask of values that can be non-zero: a pair with one live member costs one
+// DPP add, a dead pair nothing (lanes that end up with a dead value hold junk and do not write).
+// (Values are passed and kept as individual scalars on purpose: as an array the optimiser turns the
+// lane-bit selects into dynamic element extraction — a chain of compares and selects per value.)
+template <int CTRL>
+__device__ __forceinline__ float row_add(float x) {   // x + partner(x)
+    return x + f_from_u((unsigned)__builtin_amdgcn_update_dpp(0, (int)u_from_f(x), CTRL, 0xf, 0xf, false));
+}
+// one butterfly output: lanes with `bit` keep the hi value, the others the lo value; each adds
+// what its partner sends for the kept value
+template <int CTRL, bool LO, bool HI>
+__device__ __forceinline__ float row_step(bool bit, float lo, float hi) {
+    if (LO && HI) {
+        const float keep = bit ? hi : lo, send = bit ? lo : hi;
+        return keep + f_from_u((unsigned)__builtin_amdgcn_update_dpp(0, (int)u_from_f(send), CTRL, 0xf, 0xf, false));
+    }
+    if (LO) return row_add<CTRL>(lo);
+    if (HI) return row_add<CTRL>(hi);
+    return 0.0f;
+}
+template <uint32_t LIVE>
+__device__ __forceinline__ float row_reduce16_transposed(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                                                         float v8, float v9, float v10, float v11, float v12, float v13, float v14, float v15,
+                                                         int l16) {
+    const bool b3 = l16 & 8, b2 = l16 & 4, b1 = l16 & 2, b0 = l16 & 1;
+#define LV(i) ((LIVE >> (i)) & 1u)
+    const float r0 = row_step<0x128, LV(0), LV(8)>(b3, v0, v8), r1 = row_step<0x128, LV(1), LV(9)>(b3, v1, v9);
+    const float r2 = row_step<0x128, LV(2), LV(10)>(b3, v2, v10), r3 = row_step<0x128, LV(3), LV(11)>(b3, v3, v11);
+    const float r4 = row_step<0x128, LV(4), LV(12)>(b3, v4, v12), r5 = row_step<0x128, LV(5), LV(13)>(b3, v5, v13);
+    const float r6 = row_step<0x128, LV(6), LV(14)>(b3, v6, v14), r7 = row_step<0x128, LV(7), LV(15)>(b3, v7, v15);
+    constexpr uint32_t LA = (LIVE | (LIVE >> 8)) & 0xFFu;
+#define LVA(i) ((LA >> (i)) & 1u)
+    const float s0 = row_step<0x141, LVA(0), LVA(4)>(b2, r0, r4), s1 = row_step<0x141, LVA(1), LVA(5)>(b2, r1, r5);
+    const float s2 = row_step<0x141, LVA(2), LVA(6)>(b2, r2, r6), s3 = row_step<0x141, LVA(3), LVA(7)>(b2, r3, r7);
+    constexpr uint32_t LB = (LA | (LA >> 4)) & 0xFu;
+#define LVB(i) ((LB >> (i)) & 1u)
+    const float t0 = row_step<0x4E, LVB(0), LVB(2)>(b1, s0, s2), t1 = row_step<0x4E, LVB(1), LVB(3)>(b1, s1, s3);
+    constexpr uint32_t LC = (LB | (LB >> 2)) & 0x3u;
+    return row_step<0xB1, (LC & 1u) != 0, (LC & 2u) != 0>(b0, t0, t1);
+#undef LV
+#undef LVA
+#undef LVB
+}
+
 __device__ __forceinline__ void atomic_add_f32(float *addr, float v) { unsafeAtomicAdd(addr, v); }
 
-template <int NCHP, int PXL, bool DEPTH_GRAD, int WPB>
-__global__ void __launch_bounds__(LSR_WAVE * WPB)
+// WPS = resident waves per SIMD (workgroup = 4*WPS waves = one compute unit's worth): 4 where the
+// per-wave LDS slice allows it, 3 for the 8-channel payload, 1 for the widest.
+template <int NCHP, bool DEPTH_GRAD, int WPS, int MODE>
+__global__ void __launch_bounds__(LSR_WAVE * 4 * WPS)
 k_render_bwd(RenderBwdParams p) {
-    constexpr int NW = 4 / PXL;
-    extern __shared__ float4 s_dyn[];
+    constexpr int PXL = 4;
+    constexpr int WPB = 4 * WPS;
+    constexpr int kEnt = (2 + NCHP / 4) | 1;                          // float4 per staged entry (odd: conflict-free staging)
+    constexpr int RF = NCHP <= 8 ? 16 : (NCHP <= 12 ? 32 : 64);       // == rec_floats (lsr_internal.h)
+    constexpr int NGRP = RF / 16;                                     // 16-value reduction passes per evaluation
+    struct Lds {
+        float4 ent[WPB][LSR_WAVE + 1][kEnt];   // (x, y, a2, c2) (b2, log2 o, z, list position) payload...; slot 64 = null record
+        float acc[WPB][LSR_WAVE + 1][RF];      // this batch's gradient records, row = staged entry (row 64: dump row of the null record)
+        uint32_t gid[WPB][LSR_WAVE];           // Gaussian index of the staged entry
+        uint16_t list[WPB][16][LSR_WAVE];      // per sub-block: staging slots of the entries that can reach it, in list order
+    };
+    __shared__ Lds s_lds;
+
     const int lane = threadIdx.x & (LSR_WAVE - 1);
-    const int wid = threadIdx.x / LSR_WAVE;
-    // per-wave LDS slice: [64] (x,y,A,B) | [64] (C,o,z,gid) | [64][NCHP/4] payload
-    constexpr int SLICE = LSR_WAVE * (2 + NCHP / 4);
-    float4 *s_q0 = s_dyn + (size_t)wid * SLICE, *s_q1 = s_q0 + LSR_WAVE;
-    float4 (*s_pay)[NCHP / 4] = (float4 (*)[NCHP / 4])(s_q1 + LSR_WAVE);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / LSR_WAVE);
+    float4 (*s_ent)[kEnt] = s_lds.ent[wid];
+    float (*s_acc)[RF] = s_lds.acc[wid];
+    uint32_t *s_gid = s_lds.gid[wid];
+    uint16_t (*s_list)[LSR_WAVE] = s_lds.list[wid];
+    {   // null record + cleared gradient table (rows are re-zeroed by the flush)
+        if (lane == 0) {
+            s_ent[LSR_WAVE][0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            s_ent[LSR_WAVE][1] = make_float4(0.0f, -INFINITY, 0.0f, __uint_as_float(0xFFFFFFFFu));  // log2(opacity) = -inf, position beyond every list
+#pragma unroll
+            for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        float *A = &s_acc[0][0];
+        for (int i = lane; i < (LSR_WAVE + 1) * RF; i += LSR_WAVE) A[i] = 0.0f;
+    }
+    const uint32_t num_items = p.header[kHdrNumItems];
     const int coff = p.has_color ? 3 : 0;
     const size_t HW = (size_t)p.H * p.W;
+    const int grp = lane >> 4, gcol = grp & 1, grow = grp >> 1, l16 = lane & 15;
+    const int gsb = 4 * grow + gcol;
+    const int lx = lane & 3, ly = (lane >> 2) & 3;
 
-    const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = simd_bins * 4u;
-    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);   // 0..15
-    const uint32_t bin = (blockIdx.x % (uint32_t)p.num_cus) * 4u + (vwave & 3u);
+    const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = simd_bins * (uint32_t)WPS;
+    const uint32_t vwave = (uint32_t)wid;                     // 0..WPB-1; waves w, w+4, ... share a SIMD
+    const uint32_t bin = blockIdx.x * 4u + (vwave & 3u);
     const uint32_t j0 = vwave >> 2;
     bool first = true;
     for (;;) {
-        uint32_t ui;
+        uint32_t qi;
         if (first) {
-            ui = (j0 & 1u) ? (j0 + 1u) * simd_bins - 1u - bin : j0 * simd_bins + bin;
+            qi = (j0 & 1u) ? (j0 + 1u) * simd_bins - 1u - bin : j0 * simd_bins + bin;
             first = false;
-            if (ui >= p.num_units) continue;
+            if (qi >= num_items) continue;
         } else {
-            if (p.num_units <= slots) break;
+            if (num_items <= slots) break;
             uint32_t t = 0;
             if (lane == 0) t = atomicAdd(p.queue, 1u);
-            ui = slots + __builtin_amdgcn_readfirstlane(t);
-            if (ui >= p.num_units) break;
+            qi = slots + __builtin_amdgcn_readfirstlane(t);
+            if (qi >= num_items) break;
         }
-        const uint32_t vt = p.tile_lpt[ui / NW];
-        const int part = (int)(ui % NW);
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        const uint32_t item = p.items[qi];
+        const uint32_t vt = item & kItemTileMask, own = item >> kItemOwnShift;
+        const uint32_t own16 = own_subblocks(own);
         const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
         const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE;
         const size_t vG = (size_t)v * p.G;
         const uint32_t start = p.tile_start[vt];
-        const uint32_t own = owned_mask<PXL>(part);
 
-        float pxf[PXL], pyf[PXL], Tr[PXL], Rr[PXL], ddep[PXL];
-        float dpix[PXL][NCHP];
+        float2_b pxy[PXL];
+        float Tr[PXL], Rr[PXL], ddep[PXL];
+        float2_b dpix[PXL][NCHP / 2];
         uint32_t last[PXL];
         uint32_t maxlast = 0;
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
-            const int q = owned_quadrant<PXL>(part, k);
-            const int px = tx0 + 8 * (q & 1) + (lane & 7), py = ty0 + 8 * (q >> 1) + (lane >> 3);
-            pxf[k] = (float)px; pyf[k] = (float)py;
-            const bool inside = px < p.W && py < p.H;
+            const int px = tx0 + 8 * (k & 1) + 4 * gcol + lx, py = ty0 + 8 * (k >> 1) + 4 * grow + ly;
+            pxy[k] = float2_b{(float)px, (float)py};
+            const bool inside = px < p.W && py < p.H && ((own >> k) & 1u);
             const size_t pix = (size_t)py * p.W + px, vp = (size_t)v * HW + pix;
             const float Tfin = inside ? p.final_T[vp] : 1.0f;
             Tr[k] = 1.0f;
@@ -112,26 +204,29 @@ k_render_bwd(RenderBwdParams p) {
             maxlast = max(maxlast, last[k]);
             // R_0 = g . (rendered - T_final * bg)  +  T_final * (g . bg - g_mask)  =  g . rendered - T_final * g_mask
             float r0 = 0.0f;
+            float dp[NCHP];
 #pragma unroll
-            for (int c = 0; c < NCHP; ++c) dpix[k][c] = 0.0f;
+            for (int c = 0; c < NCHP; ++c) dp[c] = 0.0f;
             if (inside) {
                 if (p.has_color && p.g_color) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        dpix[k][c] = p.g_color[((size_t)v * 3 + c) * HW + pix];
-                        r0 = __builtin_fmaf(p.f_color[((size_t)v * 3 + c) * HW + pix], dpix[k][c], r0);
+                        dp[c] = p.g_color[((size_t)v * 3 + c) * HW + pix];
+                        r0 = __builtin_fmaf(p.f_color[((size_t)v * 3 + c) * HW + pix], dp[c], r0);
                     }
                 }
                 if (p.g_feat) {
 #pragma unroll
                     for (int c = 0; c < NCHP; ++c)
                         if (c >= coff && c - coff < p.C) {
-                            dpix[k][c] = p.g_feat[((size_t)v * p.C + (c - coff)) * HW + pix];
-                            r0 = __builtin_fmaf(p.f_feat[((size_t)v * p.C + (c - coff)) * HW + pix], dpix[k][c], r0);
+                            dp[c] = p.g_feat[((size_t)v * p.C + (c - coff)) * HW + pix];
+                            r0 = __builtin_fmaf(p.f_feat[((size_t)v * p.C + (c - coff)) * HW + pix], dp[c], r0);
                         }
                 }
                 if (p.g_mask) r0 = __builtin_fmaf(-Tfin, p.g_mask[vp], r0);  // mask = 1 - T_final
             }
+#pragma unroll
+            for (int c = 0; c < NCHP / 2; ++c) dpix[k][c] = float2_b{dp[2 * c], dp[2 * c + 1]};
             ddep[k] = (DEPTH_GRAD && inside) ? p.g_depth[vp] : 0.0f;
             if (DEPTH_GRAD && inside) r0 = __builtin_fmaf(p.f_depth[vp], ddep[k], r0);
             Rr[k] = r0;
@@ -141,134 +236,222 @@ k_render_bwd(RenderBwdParams p) {
         for (int off = 32; off > 0; off >>= 1) maxlast = max(maxlast, (uint32_t)__shfl_xor((int)maxlast, off));
         maxlast = __builtin_amdgcn_readfirstlane(maxlast);
 
-        for (int chunk = 0; (uint32_t)chunk * LSR_WAVE < maxlast; ++chunk) {
-            const uint32_t rel = (uint32_t)chunk * LSR_WAVE + lane;  // 0-based position in the list
+        // software-pipelined staging as in the forward: records of batch b+1 and list indices of
+        // batch b+2 are in flight while batch b is processed
+        struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t g; };
+        auto load_idx = [&](uint32_t rel) -> uint32_t { return rel < maxlast ? p.point_list[start + rel] : 0u; };
+        auto load_rec = [&](uint32_t rel, uint32_t g) {
+            StageRec r;
+            r.g = g;
+            r.a = r.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (rel < maxlast) {
+                const float4 *R = p.geo + (vG + g) * (size_t)p.rec_f4;
+                r.a = R[0]; r.b = R[1];
+#pragma unroll
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];
+            }
+            return r;
+        };
+        uint32_t g_ahead = load_idx(lane);
+        StageRec nxt = load_rec(lane, g_ahead);
+        g_ahead = load_idx(LSR_WAVE + lane);
+
+        for (uint32_t cbase = 0; cbase < maxlast; cbase += LSR_WAVE) {
+#ifdef LSR_X_NOPIPE
+            const StageRec cur = load_rec(cbase + lane, load_idx(cbase + lane));
+#else
+            const StageRec cur = nxt;
+            nxt = load_rec(cbase + LSR_WAVE + lane, g_ahead);
+            g_ahead = load_idx(cbase + 2 * LSR_WAVE + lane);
+#endif
+            // ---- stage up to 64 list entries (one per lane) ----
+            {   // every list slot starts as the null record's slot
+                const uint32_t n2 = (uint32_t)LSR_WAVE | ((uint32_t)LSR_WAVE << 16);
+                const uint4 nul = make_uint4(n2, n2, n2, n2);
+                uint4 *L4 = (uint4 *)&s_list[0][0];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) L4[q * LSR_WAVE + lane] = nul;
+            }
+            const uint32_t rel = cbase + lane;  // 0-based position in the list
             uint32_t m = 0;
             if (rel < maxlast) {
-                const uint32_t g = p.point_list[start + rel];
-                const float4 *R = p.geo + (vG + g) * (size_t)p.rec_f4;
-                const float4 a = R[0], b = R[1];
-                m = quadrant_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own;
+                const float4 a = cur.a, b = cur.b;
+                m = subblock_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own16;
                 if (m) {
-                    s_q0[lane] = a;
-                    s_q1[lane] = make_float4(b.x, b.y, b.z, __uint_as_float(g));
+                    const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);   // same folding as the forward
+                    s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
+                    s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z, __uint_as_float(rel + 1u));
 #pragma unroll
-                    for (int c4 = 0; c4 < NCHP / 4; ++c4) s_pay[lane][c4] = R[2 + c4];
+                    for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[lane][2 + c4] = cur.pay[c4];
+                    s_gid[lane] = cur.g;
                 }
             }
-            uint64_t qbits[PXL];
+            const uint64_t staged = __ballot(m != 0);
+            // compaction: per sub-block, the staged entries that can reach it, in list order.  An entry
+            // that sits at the SAME position in the lists of two sub-blocks of one quadrant will be
+            // processed by two lane groups in the same iteration; their updates of the entry's table row
+            // are ordered by a rank (number of lower sub-blocks of the quadrant holding the entry at that
+            // position), computed here once per staged entry and stored with the list element:
+            //   list element = staging slot | rank << 8.
+            uint32_t cnt[16], at[16];
 #pragma unroll
-            for (int k = 0; k < PXL; ++k) qbits[k] = __ballot((m >> owned_quadrant<PXL>(part, k)) & 1u);
-            uint64_t todo = __ballot(m != 0);
+            for (int b = 0; b < 16; ++b) {
+                cnt[b] = 0; at[b] = 0xFFFFu;           // 0xFFFF: not in this list
+                if (!((own16 >> b) & 1u)) continue;   // wave-uniform
+                const uint64_t bal = __ballot((m >> b) & 1u);
+                cnt[b] = (uint32_t)__builtin_popcountll(bal);
+                if (__builtin_amdgcn_inverse_ballot_w64(bal))
+                    at[b] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            }
+#pragma unroll
+            for (int k = 0; k < PXL; ++k) {
+                if (!((own >> k) & 1u)) continue;     // wave-uniform
+                const int q0 = 8 * (k >> 1) + 2 * (k & 1);
+                const int sb[4] = {q0, q0 + 1, q0 + 4, q0 + 5};   // lane groups 0..3 of the round
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (at[sb[j]] == 0xFFFFu) continue;
+                    uint32_t rank = 0;
+#pragma unroll
+                    for (int jj = 0; jj < j; ++jj) rank += (uint32_t)(at[sb[jj]] == at[sb[j]]);
+                    s_list[sb[j]][at[sb[j]]] = (uint16_t)((uint32_t)lane | (rank << 8));
+                }
+            }
             wave_lds_fence_bwd();
 
-            while (todo) {
-                const int j = __builtin_ctzll(todo);  // front to back
-                todo &= todo - 1;
-                const float4 a = s_q0[j], b = s_q1[j];
-                const uint32_t pos = (uint32_t)chunk * LSR_WAVE + (uint32_t)j + 1u;
-                float pay[NCHP];
 #pragma unroll
-                for (int c4 = 0; c4 < NCHP / 4; ++c4) {
-                    const float4 t = s_pay[j][c4];
-                    pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
-                }
-                const FoldedConic f2 = fold_conic(a.z, a.w, b.x, b.y);   // same folding as the forward
-                const float inv_o = __builtin_amdgcn_rcpf(b.y);
-                // sums over this wave's pixels (sign / 0.5 factors applied once, after the pixel loop)
-                float sx = 0.0f, sy = 0.0f, sA = 0.0f, sB = 0.0f, sC = 0.0f, go = 0.0f, gz = 0.0f;
-                float gpay[NCHP];
+            for (int k = 0; k < PXL; ++k) {
+                const int b0 = 8 * (k >> 1) + 2 * (k & 1);
+                const uint32_t nk = __builtin_amdgcn_readfirstlane(max(max(cnt[b0], cnt[b0 + 1]), max(cnt[b0 + 4], cnt[b0 + 5])));
+                if (nk == 0) continue;   // wave-uniform
+                const uint16_t *lp = &s_list[b0 + gsb][0];
+                for (uint32_t i = 0; i < nk; ++i) {
+                    const uint32_t lel = lp[i];
+                    const uint32_t slot = lel & 0xFFu, rank = lel >> 8;
+                    const float4_b *E = (const float4_b *)&s_ent[slot][0];
+                    float *row = &s_acc[slot][l16];
+                    float acc_old[NGRP];                             // this lane's word(s) of the entry's table row, read early
 #pragma unroll
-                for (int c = 0; c < NCHP; ++c) gpay[c] = 0.0f;
-                uint64_t any_valid = 0;
+                    for (int gi = 0; gi < NGRP; ++gi) acc_old[gi] = row[16 * gi];
+                    float4_b a = E[0], b = E[1], t4[NCHP / 4];
 #pragma unroll
-                for (int k = 0; k < PXL; ++k) {
-                    if (!(qbits[k] >> j & 1ull)) continue;  // wave-uniform
-                    const float dx = a.x - pxf[k], dy = a.y - pyf[k];
-                    const float ex = blend_exponent(dx, dy, f2.a2, f2.b2, f2.c2, f2.l2o);
+                    for (int c4 = 0; c4 < NCHP / 4; ++c4) t4[c4] = E[2 + c4];
+                    // Two or more lane groups can be at the SAME staged entry in this iteration (44 % of the
+                    // iterations on the bench scene): their read-modify-writes of the entry's table row are
+                    // ordered by the rank stored with the list element.  Rank 0 updates with the early-read
+                    // row; rank r > 0 re-reads the row after rank r-1 has written (a wave's LDS operations
+                    // execute in order).
+                    auto accumulate = [&](float *dst, float old, float tot, bool live) {
+#ifdef LSR_X_RACY
+                        if (live) *dst = old + tot;
+                        return;
+#endif
+                        if (live && rank == 0u) *dst = old + tot;
+                        uint64_t later = __ballot(rank != 0u);
+                        for (uint32_t r = 1; later; ++r) {      // wave-uniform, usually no or one round
+                            wave_lds_fence_bwd();
+                            if (live && rank == r) *dst = *dst + tot;
+                            later &= ~__ballot(rank == r);
+                        }
+                    };
+                    // keep the record reads whole 16-byte LDS loads into aligned register tuples (left alone
+                    // the compiler splits them by use and re-pairs the packed operands with moves)
+                    asm volatile("" : "+v"(a), "+v"(b));
+                    float2_b pay[NCHP / 2];
+#pragma unroll
+                    for (int c4 = 0; c4 < NCHP / 4; ++c4) {
+                        asm volatile("" : "+v"(t4[c4]));
+                        pay[2 * c4] = float2_b{t4[c4].x, t4[c4].y}; pay[2 * c4 + 1] = float2_b{t4[c4].z, t4[c4].w};
+                    }
+                    // same operations as the forward's exponent (two of them packed)
+                    const float2_b d = float2_b{a.x, a.y} - pxy[k];
+                    const float2_b q = float2_b{a.z, a.w} * d;              // (a2 dx, c2 dy)
+                    const float p1 = __builtin_fmaf(b.x, d.y, q.x);
+                    const float p2 = __builtin_fmaf(q.y, d.y, b.y);
+                    const float ex = __builtin_fmaf(p1, d.x, p2);
                     const float araw = fast_exp2(ex);
                     const float aclamp = fminf(LSR_ALPHA_MAX, araw);
-                    const uint64_t valid = __ballot(pos <= last[k]) & __ballot(ex <= f2.l2o) & __ballot(aclamp >= LSR_ALPHA_MIN);
-                    any_valid |= valid;
-                    const bool vb = __builtin_amdgcn_inverse_ballot_w64(valid);
-                    const float alpha = vb ? aclamp : 0.0f;
-                    const float Gv = vb ? araw * inv_o : 0.0f;      // exp(power)
+                    const bool valid = (__float_as_uint(b.w) <= last[k]) & (ex <= b.y) & (aclamp >= LSR_ALPHA_MIN);
+                    const float alpha = valid ? aclamp : 0.0f;
+                    const float av = valid ? araw : 0.0f;           // opacity * exp(power)
                     const float om = 1.0f - alpha;
                     const float rcp1m = __builtin_amdgcn_rcpf(om);
-                    const float Tk = Tr[k];          // transmittance in front of this entry
+                    const float Tk = Tr[k];                          // transmittance in front of this entry
                     const float w = alpha * Tk;
-                    float dsum = 0.0f;               // g . c_i
+                    const float2_b ww = float2_b{w, w};
+                    float2_b ds2 = pay[0] * dpix[k][0];              // g . c_i, two channels at a time
 #pragma unroll
-                    for (int c = 0; c < NCHP; ++c) {
-                        dsum = __builtin_fmaf(pay[c], dpix[k][c], dsum);
-                        gpay[c] = __builtin_fmaf(w, dpix[k][c], gpay[c]);
-                    }
+                    for (int c = 1; c < NCHP / 2; ++c) ds2 = __builtin_elementwise_fma(pay[c], dpix[k][c], ds2);
+                    float dsum = ds2.x + ds2.y;
+                    float2_b gp[NCHP / 2];                           // dL/d payload channel pairs
+#pragma unroll
+                    for (int c = 0; c < NCHP / 2; ++c) gp[c] = dpix[k][c] * ww;
+                    float gz = 0.0f;
                     if (DEPTH_GRAD) {
                         dsum = __builtin_fmaf(b.z, ddep[k], dsum);
-                        gz = __builtin_fmaf(w, ddep[k], gz);
+                        gz = w * ddep[k];
                     }
-                    Rr[k] = __builtin_fmaf(-w, dsum, Rr[k]);      // what is left behind this entry
+                    Rr[k] = __builtin_fmaf(-w, dsum, Rr[k]);         // what is left behind this entry
                     Tr[k] = Tk * om;
                     const float dL_dalpha = __builtin_fmaf(Tk, dsum, -Rr[k] * rcp1m);
-                    const float dL_dG = b.y * dL_dalpha;    // straight through the 0.99 clamp (A.6)
-                    const float tA = Gv * dx * dL_dG, tC = Gv * dy * dL_dG;
-                    sx = __builtin_fmaf(tA, a.z, __builtin_fmaf(tC, a.w, sx));     // -(dL/dx)
-                    sy = __builtin_fmaf(tC, b.x, __builtin_fmaf(tA, a.w, sy));     // -(dL/dy)
-                    sA = __builtin_fmaf(tA, dx, sA);                               // -2 dL/dA
-                    sB = __builtin_fmaf(tA, dy, sB);                               // -  dL/dB
-                    sC = __builtin_fmaf(tC, dy, sC);                               // -2 dL/dC
-                    go = __builtin_fmaf(Gv, dL_dalpha, go);
-                }
-                if (!any_valid) continue;
-                // ---- wave-wide sums, 16 record slots at a time; lane 4s ends up with slot s ----
-                float *rec = p.rec + (size_t)(vG + __float_as_uint(b.w)) * p.rec_floats;
-                {
-                    constexpr uint32_t LIVE = 0x3Fu | (DEPTH_GRAD ? 0x40u : 0u) | (((1u << (NCHP < 8 ? NCHP : 8)) - 1u) << 8);
-                    const float v16[16] = {-sx, -sy, -0.5f * sA, -sB, -0.5f * sC, go, DEPTH_GRAD ? gz : 0.0f, 0.0f,
-                                           gpay[0], gpay[1], gpay[2], gpay[3],
-                                           NCHP > 4 ? gpay[4 % NCHP] : 0.0f, NCHP > 4 ? gpay[5 % NCHP] : 0.0f,
-                                           NCHP > 4 ? gpay[6 % NCHP] : 0.0f, NCHP > 4 ? gpay[7 % NCHP] : 0.0f};
-                    const float tot = wave_reduce16_transposed<LIVE>(v16, lane);
-                    const int slot = lane >> 2;
-                    if ((lane & 3) == 0 && (LIVE >> slot & 1u) && (slot < 8 || slot - 8 < coff + p.C))
-                        atomic_add_f32(rec + slot, tot);
-                }
-                if (NCHP > 8) {
-#pragma unroll
-                    for (int grp = 1; grp * 16 - 8 < NCHP; ++grp) {   // payload channels 16*grp-8 .. 16*grp+7
-                        float v16[16];
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) v16[i] = (16 * grp - 8 + i) < NCHP ? gpay[(16 * grp - 8 + i) % NCHP] : 0.0f;
-                        const float tot = wave_reduce16_transposed<0xFFFFu>(v16, lane);
-                        const int ch = 16 * grp - 8 + (lane >> 2);
-                        if ((lane & 3) == 0 && ch < coff + p.C) atomic_add_f32(rec + 8 + ch, tot);
+                    const float u = av * dL_dalpha;                  // straight through the 0.99 clamp (A.6)
+                    const float2_b t1 = float2_b{u, u} * d;          // u (dx, dy)
+                    const float2_b t2 = t1 * d;                      // u (dx^2, dy^2)
+                    const float mxy = t1.x * d.y;
+                    // ---- sum over the sub-block's 16 pixels; lane s of the group ends up with slot s ----
+                    {
+                        constexpr uint32_t LIVE = 0x3Fu | (DEPTH_GRAD ? 0x40u : 0u) | (((1u << (NCHP < 8 ? NCHP : 8)) - 1u) << 8);
+                        const float tot = row_reduce16_transposed<LIVE>(
+                            t1.x, t1.y, t2.x, mxy, t2.y, u, gz, 0.0f,
+                            gp[0].x, gp[0].y, gp[1].x, gp[1].y,
+                            NCHP > 4 ? gp[2 % (NCHP / 2)].x : 0.0f, NCHP > 4 ? gp[2 % (NCHP / 2)].y : 0.0f,
+                            NCHP > 4 ? gp[3 % (NCHP / 2)].x : 0.0f, NCHP > 4 ? gp[3 % (NCHP / 2)].y : 0.0f, l16);
+                        // plain read-modify-write: only this wave touches its table and a wave's LDS operations
+                        // execute in order (measured: ds_add_f32 costs ~120 LDS cycles per wave instruction; with
+                        // it on every iteration the kernel was LDS bound at 1.44 ms)
+                        if (MODE == 2) {
+                            if ((LIVE >> l16 & 1u) && slot != LSR_WAVE) atomic_add_f32(p.rec + (vG + s_gid[slot]) * (size_t)RF + l16, tot);
+                        } else accumulate(row, acc_old[0], tot, LIVE >> l16 & 1u);
                     }
+#pragma unroll
+                    for (int gi = 1; gi < NGRP; ++gi) {   // payload channels 16 gi - 8 .. 16 gi + 7
+#define GPC(j) ((16 * gi - 8 + (j)) < NCHP ? gp[((16 * gi - 8 + (j)) / 2) % (NCHP / 2)][(j) & 1] : 0.0f)
+                        const float tot = row_reduce16_transposed<0xFFFFu>(GPC(0), GPC(1), GPC(2), GPC(3), GPC(4), GPC(5), GPC(6), GPC(7),
+                                                                            GPC(8), GPC(9), GPC(10), GPC(11), GPC(12), GPC(13), GPC(14), GPC(15), l16);
+#undef GPC
+                        if (MODE == 2) {
+                            if (slot != LSR_WAVE) atomic_add_f32(p.rec + (vG + s_gid[slot]) * (size_t)RF + 16 * gi + l16, tot);
+                        } else accumulate(row + 16 * gi, acc_old[gi], tot, true);
+                    }
+                }
+            }
+            wave_lds_fence_bwd();
+            // ---- flush: one global record-add per staged entry that reached an owned sub-block ----
+#pragma unroll 1
+            for (int e0 = 0; MODE != 2 && e0 < LSR_WAVE; e0 += 4) {
+                if (!((staged >> e0) & 0xFull)) continue;   // wave-uniform
+                const int e = e0 + grp;
+                const bool hit = (staged >> e) & 1ull;
+                const uint32_t g = s_gid[e];
+#pragma unroll
+                for (int gi = 0; gi < NGRP; ++gi) {
+                    const float val = s_acc[e][16 * gi + l16];
+                    s_acc[e][16 * gi + l16] = 0.0f;
+                    if (hit && val != 0.0f) atomic_add_f32(p.rec + (vG + g) * (size_t)RF + 16 * gi + l16, val);
                 }
             }
             wave_lds_fence_bwd();
         }
-    }  // unit loop
+    }  // item loop
 }
 
-static int pick_pxl_bwd(int nchp, int64_t tiles_total) {
-    {
-        const int x = env_int("LSR_PXL_BWD", 0);   // development knob, latched once
-        if (x == 1 || x == 2 || x == 4) return nchp > 12 ? 1 : ((nchp > 8 && x == 4) ? 2 : x);
-    }
-    // aim for >= 4 waves on each of the 1024 SIMDs (the kernel is VALU bound and needs them)
-    int pxl = tiles_total >= 4096 ? 4 : (tiles_total >= 2048 ? 2 : 1);
-    if (nchp > 8 && pxl == 4) pxl = 2;  // per-pixel upstream gradients: PXL * NCHP registers
-    if (nchp > 12) pxl = 1;
-    return pxl;
-}
-
-template <int NCHP, int PXL, bool DG, int WPB>
+template <int NCHP, bool DG, int WPS>
 static void launch_variant(const RenderBwdParams &p, hipStream_t s) {
-    const size_t shm = (size_t)WPB * LSR_WAVE * (2 + NCHP / 4) * sizeof(float4);
-    // function attributes are per device: set on every launch that needs it (a process may drive several GPUs)
-    if (shm > 65536)
-        (void)hipFuncSetAttribute((const void *)k_render_bwd<NCHP, PXL, DG, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL((k_render_bwd<NCHP, PXL, DG, WPB>), dim3(p.num_cus * (16 / WPB)), dim3(LSR_WAVE * WPB), shm, s, p);
+    const int mode = env_int("LSR_BWD_MODE", 0);   // development knob (A/B of the accumulate step), latched once
+    if (mode == 2) hipLaunchKernelGGL((k_render_bwd<NCHP, DG, WPS, 2>), dim3(p.num_cus), dim3(LSR_WAVE * 4 * WPS), 0, s, p);
+    else hipLaunchKernelGGL((k_render_bwd<NCHP, DG, WPS, 0>), dim3(p.num_cus), dim3(LSR_WAVE * 4 * WPS), 0, s, p);
 }
 
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
@@ -283,10 +466,11 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     p.H = d.height; p.W = d.width; p.gx = tiles_x(d); p.T = (int)num_tiles(d); p.G = d.num_gaussians;
     p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE;
     p.num_cus = device_cus();
+    p.items = (const uint32_t *)(geom + L.tile_order);
+    p.header = (const uint32_t *)(geom + L.header);
     p.views = in.views;
     p.geo = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
     p.tile_start = (const uint32_t *)(geom + L.tile_start);
-    p.tile_lpt = (const uint32_t *)(geom + L.tile_lpt);
     p.point_list = (const uint32_t *)(bin + B.point_list);
     p.final_T = (const float *)(img + I.final_T); p.n_contrib = (const uint32_t *)(img + I.n_contrib);
     p.g_color = gout.color; p.g_feat = gout.feature; p.g_mask = gout.mask; p.g_depth = gout.depth;
@@ -296,19 +480,17 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     (void)gin;
     const int nch = (p.has_color ? 3 : 0) + d.feat_channels;
     const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));
-    const int pxl = pick_pxl_bwd(nchp, (int64_t)p.T * d.num_views);
-    p.num_units = (uint32_t)((int64_t)p.T * d.num_views * (4 / pxl));
     const bool dg = gout.depth != nullptr;
     prof_begin(kStRenderBwd, s);
-#define LSR_RB(N, X, W)                                             \
-    do {                                                            \
-        if (dg) launch_variant<N, X, true, W>(p, s);                \
-        else launch_variant<N, X, false, W>(p, s);                  \
+#define LSR_RB(N, W)                                             \
+    do {                                                         \
+        if (dg) launch_variant<N, true, W>(p, s);                \
+        else launch_variant<N, false, W>(p, s);                  \
     } while (0)
-    if (nchp == 4) { if (pxl == 4) LSR_RB(4, 4, 16); else if (pxl == 2) LSR_RB(4, 2, 16); else LSR_RB(4, 1, 16); }
-    else if (nchp == 8) { if (pxl == 4) LSR_RB(8, 4, 16); else if (pxl == 2) LSR_RB(8, 2, 16); else LSR_RB(8, 1, 16); }
-    else if (nchp == 12) { if (pxl == 2) LSR_RB(12, 2, 16); else LSR_RB(12, 1, 16); }
-    else LSR_RB(36, 1, 4);
+    if (nchp == 4) LSR_RB(4, 4);
+    else if (nchp == 8) LSR_RB(8, 3);
+    else if (nchp == 12) LSR_RB(12, 2);
+    else LSR_RB(36, 1);
 #undef LSR_RB
     prof_end(kStRenderBwd, s);
     return hipGetLastError();

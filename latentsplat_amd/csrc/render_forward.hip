@@ -27,11 +27,11 @@
 namespace lsr {
 
 __device__ __forceinline__ void wave_lds_fence() {
-    // LDS operations of one wave execute in order; this only stops the compiler from moving LDS
-    // accesses across the staging / consuming phases and drains the wave's own LDS queue.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // The LDS slice is private to the wave and a wave's LDS operations execute in order, so no
+    // hardware wait is needed between staging and consuming; this is a compiler-only barrier (a
+    // memory fence here would also drain the global loads that prefetch the next batch).
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
@@ -154,12 +154,37 @@ k_render_fwd(RenderFwdParams p) {
             for (int c = 0; c < NCHP / 2; ++c) acc[k][c] = float2_t{0.0f, 0.0f};
         }
 
+        // Software-pipelined staging: while batch b is composited, the records of batch b+1 and the
+        // list indices of batch b+2 are already in flight (two dependent global latencies per batch
+        // otherwise sit on the serial path of the wave that walks the longest list).
+        struct StageRec { float4 a, b, pay[NCHP / 4]; };
+        auto load_idx = [&](uint32_t e) -> uint32_t { return e < end ? p.point_list[e] : 0u; };
+        auto load_rec = [&](uint32_t e, uint32_t g) {
+            StageRec r;
+            r.a = r.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (e < end) {
+                const float4 *R = p.rec + (vG + g) * (size_t)p.rec_f4;
+                r.a = R[0]; r.b = R[1];  // (x,y,A,B) (C,o,z,-)
+#pragma unroll
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];  // payload, zero padded
+            }
+            return r;
+        };
+        uint32_t g_ahead = load_idx(start + lane);
+        StageRec nxt = load_rec(start + lane, g_ahead);
+        g_ahead = load_idx(start + LSR_WAVE + lane);
+
         for (uint32_t base = start; base < end; base += LSR_WAVE) {
             uint64_t all_done = ~0ull;
 #pragma unroll
             for (int k = 0; k < PXL; ++k) all_done &= done[k];
             if (all_done == ~0ull) break;
 
+            const StageRec cur = nxt;
+            nxt = load_rec(base + LSR_WAVE + lane, g_ahead);
+            g_ahead = load_idx(base + 2 * LSR_WAVE + lane);
             // ---- stage up to 64 list entries (one per lane) ----
             {   // every list slot starts as the null record; the compaction below overwrites a prefix
                 const uint4 nul = make_uint4(null_off, null_off, null_off, null_off);
@@ -170,16 +195,14 @@ k_render_fwd(RenderFwdParams p) {
             const uint32_t e = base + lane;
             uint32_t m = 0;
             if (e < end) {
-                const uint32_t g = p.point_list[e];
-                const float4 *R = p.rec + (vG + g) * (size_t)p.rec_f4;
-                const float4 a = R[0], b = R[1];  // (x,y,A,B) (C,o,z,-)
+                const float4 a = cur.a, b = cur.b;
                 m = subblock_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own16;
                 if (m) {
                     const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
                     s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
                     s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z, -1.0f);
 #pragma unroll
-                    for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[lane][2 + c4] = R[2 + c4];  // payload, zero padded
+                    for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[lane][2 + c4] = cur.pay[c4];
                 }
             }
             // compaction: per sub-block, the staged entries that can reach it, in list order
@@ -335,7 +358,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
 #define LSR_RF(N, U, WPB) hipLaunchKernelGGL((k_render_fwd<N, U, WPB>), dim3(p.num_cus * (16 / WPB)), dim3(LSR_WAVE * WPB), 0, s, p)
     if (nchp == 4) LSR_RF(4, 2, 16);
     else if (nchp == 8) LSR_RF(8, 2, 16);
-    else if (nchp == 12) LSR_RF(12, 2, 16);
+    else if (nchp == 12) LSR_RF(12, 1, 16);
     else LSR_RF(36, 1, 4);
 #undef LSR_RF
     prof_end(kStRenderFwd, s);
