@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LSR_ABI_VERSION 3
+#define LSR_ABI_VERSION 4
 #define LSR_TILE 16            /* tile edge in pixels (16x16 = the published algorithm's tile) */
 #define LSR_MAX_FEAT_CHANNELS 32
 #define LSR_MAX_SH_DEGREE 4
@@ -61,6 +61,7 @@ extern "C" {
 
 enum { LSR_COLOR_NONE = 0, LSR_COLOR_SH = 1, LSR_COLOR_PRECOMP = 2 };
 enum { LSR_FEAT_DIRECT = 0, LSR_FEAT_SH = 1 };
+enum { LSR_SH_AXES_3DGS = 0, LSR_SH_AXES_REFERENCE = 1 };
 
 enum {
     LSR_OK = 0,
@@ -105,6 +106,16 @@ typedef struct lsr_dims {
                                DecoderSplattingCUDA.forward receives); num_views % n == 0 and every
                                per-Gaussian input must then be strided (!= 0).  Gradients of strided
                                inputs have one slice per group, summed over the group's views. */
+    int32_t color_sh_convention; /* axis convention of the COLOUR SH basis at degree >= 1 (ABI v4):
+                               LSR_SH_AXES_3DGS (0, default): the published 3DGS rasterizer's basis,
+                                 l=1 terms -C1*y, +C1*z, -C1*x of the unit direction (x,y,z);
+                               LSR_SH_AXES_REFERENCE (1): the reference's own eval_sh naming
+                                 (src/misc/sh_utils.py:62-65: -C1*x, +C1*y, -C1*z), i.e. the same
+                                 polynomials evaluated at (z,x,y) — what the fused latent-feature SH
+                                 path always uses, and what the encoder's rotate_sh (e3nn Wigner-D)
+                                 is consistent with.  Which of the two the external CUDA fork uses for
+                                 colour cannot be determined offline (SURVEY.md Appendix A.4 [UNK];
+                                 tools/dump_fork_vectors.py case fork_probe_sh_axes decides it). */
 } lsr_dims;
 
 typedef struct lsr_inputs {

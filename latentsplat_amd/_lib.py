@@ -17,6 +17,7 @@ _SO = os.environ.get("LSR_LIB") or os.path.join(_CSRC, "liblsr_hip.so")
 VIEW_FLOATS = 44
 COLOR_NONE, COLOR_SH, COLOR_PRECOMP = 0, 1, 2
 FEAT_DIRECT, FEAT_SH = 0, 1
+SH_AXES_3DGS, SH_AXES_REFERENCE = 0, 1   # lsr_dims.color_sh_convention
 MAX_SH_GROUP_FLOATS = 120   # C*Kf the fused latent-SH path supports (LDS budget of sh.hip)
 MAX_FEAT_CHANNELS = 32
 
@@ -32,7 +33,8 @@ class Dims(C.Structure):
                 ("vs_cov", C.c_int64), ("vs_opac", C.c_int64), ("vs_color", C.c_int64),
                 ("vs_feat", C.c_int64), ("cov_elems", C.c_int32), ("feat_mode", C.c_int32),
                 ("feat_sh_degree", C.c_int32), ("feat_sh_coeffs", C.c_int32),
-                ("color_sh_channel_major", C.c_int32), ("views_per_group", C.c_int32)]
+                ("color_sh_channel_major", C.c_int32), ("views_per_group", C.c_int32),
+                ("color_sh_convention", C.c_int32)]
 
 
 class Inputs(C.Structure):
@@ -193,7 +195,7 @@ def load():
     lib.lsr_ply_pack.argtypes = [I64, I32, C.POINTER(PlyInputs), P, P]
     lib.lsr_ply_write_host.restype = C.c_int
     lib.lsr_ply_write_host.argtypes = [C.c_char_p, P, I64]
-    if lib.lsr_abi_version() != 3:
+    if lib.lsr_abi_version() != 4:
         raise LsrError("liblsr_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -137,6 +137,7 @@ static int check_dims(const lsr_dims *d) {
     }
     if (d->color_mode == LSR_COLOR_SH && d->sh_coeffs * 3 > 120) return LSR_EUNSUPPORTED;
     if (d->feat_channels > 0 && d->vs_feat != 0 && d->vs_feat != feat_elems * G) return LSR_EINVAL;
+    if (d->color_sh_convention != LSR_SH_AXES_3DGS && d->color_sh_convention != LSR_SH_AXES_REFERENCE) return LSR_EINVAL;
     if (d->views_per_group < 0) return LSR_EINVAL;
     if (d->views_per_group > 1) {   // view groups: all inputs strided per group
         if (d->num_views % d->views_per_group != 0) return LSR_EINVAL;

@@ -64,7 +64,10 @@ __device__ __forceinline__ void stage_group(float *lds, const ShParams &p, int g
     const int64_t vs = grp == 0 ? p.d.vs_color : p.d.vs_feat;
     const float *src = (grp == 0 ? p.in.color : p.in.features) + (size_t)v * vs + (size_t)g0 * ks;
     float *dst = lds + (grp == 0 ? 0 : p.offF);
-    const int n = rows * ks, n4 = n >> 2;
+    // the 16-byte global->LDS path needs a 16-byte aligned source run: per-view slices are only
+    // aligned when G*ks is a multiple of 4 floats, and a caller's slice (shs[i]) may start anywhere —
+    // otherwise the whole run takes the scalar loop below (block-uniform)
+    const int n = rows * ks, n4 = (((size_t)src & 15u) == 0) ? n >> 2 : 0;
     const int lane = tid & (LSR_WAVE - 1);
     for (int t4 = tid; t4 - lane < n4; t4 += kShThreads) {
         if (t4 < n4)
@@ -136,6 +139,7 @@ k_sh_fwd(ShParams p) {
     const int C = d.feat_channels, K = d.sh_coeffs, Kf = d.feat_sh_coeffs, degF = d.feat_sh_degree;
     const bool hasF = p.has[1] != 0;
     const bool cmaj = d.color_sh_channel_major != 0;
+    const bool cax = d.color_sh_convention == LSR_SH_AXES_REFERENCE;   // colour basis evaluated at (z,x,y)
     const float *my = s_lds + lane * p.ks[0];
     const float *myF = s_lds + p.offF + lane * p.ks[1];
 
@@ -156,7 +160,7 @@ k_sh_fwd(ShParams p) {
             float col[3] = {0.0f, 0.0f, 0.0f};
             if (DEGC >= 0) {
                 float basC[25];
-                sh_basis<DEGC>(DEGC, dir.dx, dir.dy, dir.dz, basC);
+                sh_basis<DEGC>(DEGC, cax ? dir.dz : dir.dx, cax ? dir.dx : dir.dy, cax ? dir.dy : dir.dz, basC);   // LSR_SH_AXES_REFERENCE: B(z,x,y)
                 uint32_t bits = 0;
                 // one channel at a time, each consuming its LDS reads before the next starts (fully
                 // interleaved, the 75 reads cost ~60 more live registers and a wave of occupancy)
@@ -230,6 +234,7 @@ k_sh_bwd(ShParams p) {
     const int nbF = (degF + 1) * (degF + 1);
     const bool hasF = p.has[1] != 0;
     const bool cmaj = d.color_sh_channel_major != 0;
+    const bool cax = d.color_sh_convention == LSR_SH_AXES_REFERENCE;   // colour basis evaluated at (z,x,y)
     const bool shared = sh_shared_scene(p);
     const int chunk = shared ? kShWaves : 1;            // per-view coefficient outputs: one view at a time
     const int ntot = COFF + C, cs = ntot | 1;
@@ -276,9 +281,12 @@ k_sh_bwd(ShParams p) {
                     }
                 }
                 float dbas[nbC > 0 ? nbC : 1][3];
-                sh_basis_grad<DEGC>(DEGC, dir.dx, dir.dy, dir.dz, dbas);
+                sh_basis_grad<DEGC>(DEGC, cax ? dir.dz : dir.dx, cax ? dir.dx : dir.dy, cax ? dir.dy : dir.dz, dbas);
+                float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
 #pragma unroll
-                for (int k = 0; k < nbC; ++k) { ddx += dbas[k][0] * sg[k]; ddy += dbas[k][1] * sg[k]; ddz += dbas[k][2] * sg[k]; }
+                for (int k = 0; k < nbC; ++k) { c0 += dbas[k][0] * sg[k]; c1 += dbas[k][1] * sg[k]; c2 += dbas[k][2] * sg[k]; }
+                // gradient w.r.t. the basis arguments -> w.r.t. the direction (arguments (dz, dx, dy) when cax)
+                ddx += cax ? c1 : c0; ddy += cax ? c2 : c1; ddz += cax ? c0 : c2;
             } else if (COFF == 3) {
                 mg[0] = mg[1] = mg[2] = 0.0f;
             }
@@ -325,7 +333,7 @@ k_sh_bwd(ShParams p) {
             if (vis) dir = sh_direction(p, v, i);
             if (DEGC >= 0) {
                 float basC[nbC > 0 ? nbC : 1];
-                sh_basis<DEGC>(DEGC, dir.dx, dir.dy, dir.dz, basC);
+                sh_basis<DEGC>(DEGC, cax ? dir.dz : dir.dx, cax ? dir.dx : dir.dy, cax ? dir.dy : dir.dz, basC);   // LSR_SH_AXES_REFERENCE: B(z,x,y)
                 float *mb = s_basC + (wave * LSR_WAVE + lane) * kShBasisC;
 #pragma unroll
                 for (int k = 0; k < 26; ++k) mb[k] = (vis && k < nbC) ? basC[k < nbC ? k : 0] : 0.0f;

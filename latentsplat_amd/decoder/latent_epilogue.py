@@ -104,12 +104,17 @@ def get_scaled_size(scale: Fraction, size) -> tuple[int, ...]:
 
 
 def rescale(x: Tensor, scale_factor: Fraction) -> Tensor:
-    """``ModelWrapper.rescale`` (model_wrapper.py:266-274) for downscaling factors: anti-aliased
-    bilinear resize of the last two dimensions."""
+    """``ModelWrapper.rescale`` (model_wrapper.py:266-274): anti-aliased bilinear resize of the last
+    two dimensions.  Downscaling (the training path, 1/supersampling, :374-379) runs on the fused HIP
+    kernel; upscaling (``get_inv(scale_factor)``, video rendering only, :900-901) is the same ATen
+    operator torchvision's ``resize`` dispatches to in the reference — stock PyTorch-ROCm, on the
+    device, nothing to fuse it with."""
     batch_dims, spatial = x.shape[:-2], x.shape[-2:]
     size = get_scaled_size(scale_factor, spatial)
     if size[0] > spatial[0] or size[1] > spatial[1]:
-        raise _lib.LsrError("rescale: only downscaling is implemented on the MI355X path")
+        up = torch.nn.functional.interpolate(x.reshape(1, -1, *spatial), size=tuple(size), mode="bilinear",
+                                             align_corners=False, antialias=True)
+        return up.reshape(*batch_dims, *size)
     planes = x.reshape(1, -1, *spatial)
     _, z, _ = _LatentEpilogue.apply(planes, None, None, None, size, LOGVAR_FROM_MASK, False, False, (-30.0, 20.0))
     return z.reshape(*batch_dims, *size)

@@ -111,6 +111,25 @@ def _stride(t: Optional[Tensor], base_dims: int, V: int, name: str, groups: Opti
 # statistics of the most recent forward (host-side; the pair count is known after prepare())
 LAST_STATS: dict = {}
 
+# Axis convention of the COLOUR SH basis (lsr_dims.color_sh_convention).  The 12-field settings tuple
+# of the reference API has no room for it, so it is a process-wide switch:
+#   "3dgs"      (default) the published 3DGS rasterizer's basis;
+#   "reference" the reference's own eval_sh naming (src/misc/sh_utils.py:62-65), which its rotate_sh
+#               (e3nn) is consistent with and which the fused latent-feature SH path always uses.
+# Which one the external CUDA fork uses is unknown offline (INTEGRATION.md §"Colour SH convention").
+_COLOR_SH_CONVENTION = {"3dgs": _lib.SH_AXES_3DGS, "reference": _lib.SH_AXES_REFERENCE}[
+    __import__("os").environ.get("LSR_COLOR_SH_CONVENTION", "3dgs")]
+
+
+def set_color_sh_convention(name: str) -> None:
+    """``"3dgs"`` or ``"reference"`` — see the comment above; applies to subsequent forward calls."""
+    global _COLOR_SH_CONVENTION
+    _COLOR_SH_CONVENTION = {"3dgs": _lib.SH_AXES_3DGS, "reference": _lib.SH_AXES_REFERENCE}[name]
+
+
+def get_color_sh_convention() -> str:
+    return "reference" if _COLOR_SH_CONVENTION == _lib.SH_AXES_REFERENCE else "3dgs"
+
 
 class _Plan:
     """Everything one forward call hands to the matching backward."""
@@ -150,6 +169,21 @@ class _RasterizeViews(torch.autograd.Function):
             _lib.COLOR_PRECOMP if colors_precomp is not None else _lib.COLOR_NONE)
         Cf = 0 if features is None else (features.shape[-2] if feat_sh else features.shape[-1])
         Kf = features.shape[-1] if feat_sh else 0
+        # every per-Gaussian tensor must agree with means3D on G and carry the documented trailing
+        # dims: the kernels index them by G without bounds checks
+        def _expect(t, name, tail):
+            if t is not None and tuple(t.shape[-len(tail):]) != tuple(tail):
+                raise LsrError(f"{name}: trailing shape {tuple(t.shape[-len(tail):])}, expected {tuple(tail)} "
+                               f"(G = {G} from means3D)")
+        if means3D.shape[-1] != 3:
+            raise LsrError(f"means3D: last dimension {means3D.shape[-1]}, expected 3")
+        _expect(cov3D, "cov3D_precomp", (G, 3, 3) if cov_elems == 9 else (G, 6))
+        _expect(opacities, "opacities", (G, 1))
+        _expect(colors_precomp, "colors_precomp", (G, 3))
+        if shs is not None:
+            _expect(shs, "shs", (G, 3, shs.shape[-1]) if shs_channel_major else (G, shs.shape[-2], 3))
+        if features is not None:
+            _expect(features, "features", (G,) + tuple(features.shape[-2:] if feat_sh else features.shape[-1:]))
         if Cf > _lib.MAX_FEAT_CHANNELS:
             raise LsrError(f"features has {Cf} channels; at most {_lib.MAX_FEAT_CHANNELS} are supported")
         K = 0 if shs is None else (shs.shape[-1] if shs_channel_major else shs.shape[-2])
@@ -166,7 +200,8 @@ class _RasterizeViews(torch.autograd.Function):
                            "carry the scene dimension")
         d = Dims(V, G, H, W, Cf, color_mode, int(sh_degree), K, *strides,
                  cov_elems, _lib.FEAT_SH if feat_sh else _lib.FEAT_DIRECT, max(int(feat_sh_degree), 0), Kf,
-                 1 if (shs is not None and shs_channel_major) else 0, vpg if vpg > 1 else 0)
+                 1 if (shs is not None and shs_channel_major) else 0, vpg if vpg > 1 else 0,
+                 _COLOR_SH_CONVENTION)
         inp = Inputs(_ptr(views), _ptr(means3D), _ptr(cov3D), _ptr(opacities), _ptr(color), _ptr(features))
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         u8 = dict(dtype=torch.uint8, device=dev)

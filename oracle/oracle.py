@@ -39,6 +39,11 @@ def lib():
     return _LIB
 
 
+def set_sh_convention(name: str) -> None:
+    """Colour SH axis convention of the oracle: "3dgs" (default) or "reference" (sh_utils.py naming)."""
+    lib().oracle_set_sh_convention(ctypes.c_int({"3dgs": 0, "reference": 1}[name]))
+
+
 def _p(a: Optional[np.ndarray]):
     if a is None:
         return ctypes.c_void_p(0)

@@ -27,3 +27,35 @@ def hip_device():
     from latentsplat_amd import _lib
     _lib.load()  # fail loudly if the extension is missing
     return torch.device("cuda:0")
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """How much of each compared tensor was actually held to the parity bar (tests/util.py ACCOUNTING):
+    total pixels / rows, those on the strict bar, those on the flip-sized bound next to a fragile
+    evaluation, those exempt.  Also written to gpurun_out/parity_accounting.json when that directory
+    exists (the GPU box), so the numbers can be quoted."""
+    try:
+        from tests import util
+    except Exception:
+        return
+    acc = util.ACCOUNTING
+    if not acc:
+        return
+    tr = terminalreporter
+    tr.section("parity accounting (what was held to the bar)")
+    worst = {}
+    for a in acc:
+        key = (a["kind"], a["what"].split("[")[0])
+        w = worst.setdefault(key, dict(n=0, total=0, strict=0, bounded=0, exempt=0, min_frac=1.0, worst=0.0))
+        w["n"] += 1; w["total"] += a["total"]; w["strict"] += a["held_to_bar"]; w["bounded"] += a["flip_bounded"]
+        w["exempt"] += a["exempt"]; w["worst"] = max(w["worst"], a["worst_strict_err"] / a["scale"])
+        w["min_frac"] = min(w["min_frac"], a["held_to_bar"] / max(a["total"], 1))
+    for (kind, what), w in sorted(worst.items()):
+        tr.write_line(f"{kind:5s} {what:28s} comparisons {w['n']:4d}  elements {w['total']:9d}  strict {w['strict']:9d} "
+                      f"({100.0 * w['strict'] / max(w['total'], 1):6.2f} %, min {100.0 * w['min_frac']:6.2f} %)  "
+                      f"flip-bounded {w['bounded']:6d}  exempt {w['exempt']:5d}  worst strict err/scale {w['worst']:.2e}")
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, "parity_accounting.json"), "w") as f:
+            json.dump(acc, f)

@@ -133,6 +133,49 @@ def _np(t):
     return None if t is None else t.detach().cpu().numpy()
 
 
+def orthographic(out_dir):
+    """render_cuda_orthographic (/root/reference/src/model/decoder/cuda_splatting.py:170-292): the
+    fake-orthographic camera.  The reference only works for batch 1 (it assigns the (batch,) distance
+    to ONE element of a single 4x4 `move_back`, :226-227) and hands TENSOR-valued tanfovx / tanfovy
+    to the settings (:260-261).  Recorded: the boundary (settings + kwargs) with the recording
+    rasterizer, the RenderOutput with the oracle rasterizer, and the `dump` escape hatch."""
+    sc = make_scene(500, image_size=48, views=1, color_sh_degree=2, feature_channels=4, feature_sh_degree=1, seed=77)
+    g = torch.Generator().manual_seed(3)
+    ext = sc.extrinsics.clone()
+    ext[0, :3, 3] = torch.tensor([0.3, -0.2, -1.0])
+    args = dict(extrinsics=ext, width=torch.tensor([3.0]), height=torch.tensor([2.4]), near=sc.near.clone(), far=sc.far.clone(),
+                image_shape=(40, 48), background_features=torch.rand(1, 3, generator=g),
+                gaussian_means=sc.means[None].contiguous(), gaussian_covariances=sc.covariances[None].contiguous(),
+                gaussian_opacities=sc.opacities[None].contiguous(),
+                gaussian_color_sh_coefficients=sc.color_sh[None].contiguous(),
+                gaussian_feature_sh_coefficients=sc.feature_sh[None].contiguous())
+    _install_stubs(_recording_module())
+    dec, cs, tm = _import_reference()
+    RECORD.clear()
+    dump = {}
+    cs.render_cuda_orthographic(**args, dump=dump)
+    assert len(RECORD) == 1
+    s, kw = RECORD[0]
+    rec = {f"in_{k}": _np(v) for k, v in args.items() if torch.is_tensor(v)}
+    rec["in_image_shape"] = np.array(args["image_shape"], np.int32)
+    rec["call0_tanfovx"] = np.float32(float(s.tanfovx)); rec["call0_tanfovy"] = np.float32(float(s.tanfovy))
+    rec["call0_tanfov_is_tensor"] = np.array([torch.is_tensor(s.tanfovx), torch.is_tensor(s.tanfovy)])
+    rec["call0_sh_degree"] = np.int32(s.sh_degree)
+    for fld in ("bg", "viewmatrix", "projmatrix", "campos"):
+        rec[f"call0_{fld}"] = _np(getattr(s, fld))
+    for k, v in kw.items():
+        if v is not None and k != "means2D":
+            rec[f"call0_{k}"] = _np(v)
+    for k, v in dump.items():
+        rec[f"dump_{k}"] = _np(v)
+    _install_stubs(_oracle_module())
+    dec, cs, tm = _import_reference()
+    out = cs.render_cuda_orthographic(**args)
+    np.savez_compressed(os.path.join(out_dir, "orthographic.npz"), **rec, out_color=_np(out.color),
+                        out_feature=_np(out.feature), out_mask=_np(out.mask), out_depth=_np(out.depth))
+    print("orthographic", {k: tuple(getattr(out, k).shape) for k in ("color", "feature", "mask", "depth")})
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
@@ -180,6 +223,8 @@ def main():
             res["posterior_logvar"] = _np(out.feature_posterior.logvar)
         np.savez_compressed(os.path.join(out_dir, f"decoder_{name}.npz"), **res)
         print(name, "calls:", len(RECORD), {k: v.shape for k, v in res.items()})
+
+    orthographic(out_dir)
 
     # ---- helper-level vectors: get_fov / get_projection_matrix / eval_sh ----
     _install_stubs(_recording_module())

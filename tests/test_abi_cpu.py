@@ -27,7 +27,7 @@ def test_header_symbols_are_exported():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert set(names) == set(_lib.EXPORTS)
-    assert lib.lsr_abi_version() == 3
+    assert lib.lsr_abi_version() == 4
 
 
 def _dims(**kw):
@@ -55,7 +55,7 @@ def test_workspace_sizes():
     dict(num_views=0), dict(height=0), dict(feat_channels=33), dict(feat_channels=0, color_mode=0),
     dict(color_mode=1, sh_degree=5, sh_coeffs=36), dict(color_mode=1, sh_degree=2, sh_coeffs=4),
     dict(vs_means=7), dict(vs_feat=5), dict(cov_elems=7), dict(feat_mode=2),
-    dict(feat_mode=1, feat_sh_degree=1, feat_sh_coeffs=3),
+    dict(feat_mode=1, feat_sh_degree=1, feat_sh_coeffs=3), dict(color_sh_convention=2),
 ])
 def test_invalid_dims_are_rejected(bad):
     lib = _lib.load()
@@ -68,7 +68,9 @@ def test_invalid_dims_are_rejected(bad):
 
 def test_unsupported_fused_sh_shapes_are_reported():
     lib = _lib.load()
-    for bad in (dict(feat_mode=1, feat_sh_degree=3, feat_sh_coeffs=16), dict(feat_channels=32, feat_mode=1, feat_sh_degree=2, feat_sh_coeffs=9)):
+    for bad in (dict(feat_mode=1, feat_sh_degree=3, feat_sh_coeffs=16), dict(feat_channels=32, feat_mode=1, feat_sh_degree=2, feat_sh_coeffs=9),
+                dict(num_views=1 << 14, height=4096, width=4096),       # view*tile ids must fit the 28-bit work-item field
+                dict(num_views=1 << 12, num_gaussians=1 << 20)):        # 32-bit pair counts / tile offsets
         d = _dims(**bad)
         npairs, maxtile = C.c_int64(0), C.c_int32(0)
         assert lib.lsr_forward_prepare(C.byref(d), C.byref(Inputs()), None, None, C.byref(npairs), C.byref(maxtile), None) == -5

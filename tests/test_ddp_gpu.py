@@ -1,0 +1,122 @@
+"""The rasterizer autograd op under DistributedDataParallel, as the reference trains
+(/root/reference/src/main.py:93-105: one process per GPU, strategy
+``ddp_find_unused_parameters_true``; gradient all-reduce fired by ``manual_backward``,
+src/model/model_wrapper.py:440).  A tiny ``nn.Linear -> GaussianAdapter -> DecoderSplattingCUDA``
+model is wrapped in DDP over RCCL (backend "nccl"), every rank renders its own batch, and the
+all-reduced parameter gradients must equal the mean of the per-rank gradients computed in ONE
+process.  The rasterizer itself has no parameters and takes part in no collective;
+this pins that its autograd node, streams and workspaces coexist with DDP's hooks and buckets.
+
+Needs >= 2 GPUs: skipped (loudly) on the single-GPU test boxes; the single-GPU half of the same
+model (forward + backward, unused parameter, finite gradients) runs everywhere."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+R, SIZE = 1024, 32
+
+
+class TinySplatModel(nn.Module):
+    def __init__(self):
+        super().__init__()
+        from latentsplat_amd import decoder as dec
+        from latentsplat_amd.gaussian_adapter import GaussianAdapter, GaussianAdapterCfg
+        self.adapter = GaussianAdapter(GaussianAdapterCfg(0.5, 15.0, 1, 1), 4, rotate_sh=lambda sh, rot: sh)
+        self.lin = nn.Linear(16, self.adapter.d_in)
+        self.never_used = nn.Linear(4, 4)          # needs find_unused_parameters=True, as in src/main.py:98
+        self.decoder = dec.get_decoder(dec.DecoderSplattingCUDACfg(name="splatting_cuda"), [0.0, 0.0, 0.0])
+
+    def forward(self, tokens, cams):
+        from latentsplat_amd import decoder as dec
+        raw = self.lin(tokens)                                       # (1,1,R,1,1,d_in)
+        g = self.adapter.forward(cams["ctx_extrinsics"], cams["ctx_intrinsics"], cams["coordinates"], cams["depths"],
+                                 cams["opacities"], raw, (SIZE, SIZE))
+        gauss = dec.Gaussians(g.means.reshape(1, -1, 3), g.covariances.reshape(1, -1, 3, 3), g.opacities.reshape(1, -1),
+                              g.color_harmonics.reshape(1, R, 3, -1), g.feature_harmonics.reshape(1, R, 4, -1))
+        out = self.decoder.forward(gauss, cams["extrinsics"], cams["intrinsics"], cams["near"], cams["far"], (SIZE, SIZE))
+        return (out.color ** 2).mean() + (out.feature_posterior.mean ** 2).mean()
+
+
+def make_batch(seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    ys, xs = torch.meshgrid(torch.arange(SIZE), torch.arange(SIZE), indexing="ij")
+    coords = (torch.stack([xs, ys], -1).reshape(R, 2).float() + 0.5) / SIZE
+    K = torch.tensor([[0.8, 0, 0.5], [0, 0.8, 0.5], [0, 0, 1.0]])
+    ext = torch.eye(4).repeat(2, 1, 1)
+    ext[1, 0, 3] = 0.2
+    cams = dict(ctx_extrinsics=torch.eye(4).reshape(1, 1, 1, 1, 1, 4, 4), ctx_intrinsics=K.reshape(1, 1, 1, 1, 1, 3, 3),
+                coordinates=coords.reshape(1, 1, R, 1, 1, 2), depths=(1.5 + 3 * torch.rand(1, 1, R, 1, 1, generator=g)),
+                opacities=0.2 + 0.6 * torch.rand(1, 1, R, 1, 1, generator=g),
+                extrinsics=ext[None], intrinsics=K.repeat(2, 1, 1)[None], near=torch.full((1, 2), 0.5), far=torch.full((1, 2), 40.0))
+    tokens = torch.randn(1, 1, R, 1, 1, 16, generator=g)
+    return tokens.to(dev), {k: v.to(dev) for k, v in cams.items()}
+
+
+def _local_grads(model, seed, dev):
+    model.zero_grad(set_to_none=True)
+    tokens, cams = make_batch(seed, dev)
+    loss = model(tokens, cams)
+    loss.backward()
+    return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}, float(loss)
+
+
+def test_model_trains_on_one_gpu(hip_device):
+    torch.manual_seed(0)
+    model = TinySplatModel().to(hip_device)
+    grads, loss = _local_grads(model, 100, hip_device)
+    assert loss > 0 and set(grads) == {"lin.weight", "lin.bias"}            # never_used gets no gradient
+    assert all(torch.isfinite(g).all() and float(g.abs().max()) > 0 for g in grads.values())
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    torch.manual_seed(0)
+    model = TinySplatModel().to(dev)
+    ddp = nn.parallel.DistributedDataParallel(model, device_ids=[rank], find_unused_parameters=True)
+    tokens, cams = make_batch(100 + rank, dev)
+    ddp(tokens, cams).backward()
+    torch.cuda.synchronize(dev)
+    got = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    if rank == 0:   # the same two batches in one process, no DDP
+        torch.manual_seed(0)
+        ref = TinySplatModel().to(dev)
+        per_rank = [_local_grads(ref, 100 + r, dev)[0] for r in range(world)]
+        want = {n: sum(g[n] for g in per_rank).cpu() / world for n in per_rank[0]}
+        out.put((got, want))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="DDP over RCCL needs >= 2 GPUs; this box has "
+                    f"{torch.cuda.device_count()} (the driver's multi-GPU tier runs it on the 8-GPU node)")
+def test_ddp_allreduced_grads_equal_single_process_mean():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, want = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert set(got) == set(want) == {"lin.weight", "lin.bias"}
+    for n in want:
+        scale = max(1e-6, float(want[n].abs().max()))
+        assert float((got[n] - want[n]).abs().max()) <= 1e-4 * scale, n

@@ -191,3 +191,29 @@ def test_autograd_oracle_gradcheck_float64():
         return torch.cat([color.flatten(), feat.flatten(), mask.flatten(), depth.flatten()])
 
     assert torch.autograd.gradcheck(f, (means, cov6, opac, shs, feats), eps=1e-6, atol=1e-5, rtol=1e-3, nondet_tol=0)
+
+
+def test_reference_sh_convention_equals_the_references_python_eval_sh():
+    """oracle.set_sh_convention("reference") evaluates the colour SH exactly like the reference's own
+    eval_sh (src/misc/sh_utils.py:42-97; its mirror latentsplat_amd.decoder.geometry.eval_sh is pinned
+    to the reference by tests/golden/helpers.npz) — for all 25 coefficients except #14, where the
+    reference's Python has z*(zz-xx) instead of the harmonic y(zz-xx) (documented in DESIGN.md)."""
+    import torch
+    from latentsplat_amd.decoder import geometry
+    sc = util.make_scene(300, image_size=32, views=1, color_sh_degree=4, feature_channels=None, seed=3)
+    sc.color_sh[:, :, 14] = 0.0
+    bi = util.boundary_inputs(sc, 32, 32)
+    try:
+        orc.set_sh_convention("reference")
+        o_ref = util.oracle_forward(bi, 0)
+        orc.set_sh_convention("3dgs")
+        o_3dgs = util.oracle_forward(bi, 0)
+    finally:
+        orc.set_sh_convention("3dgs")
+    d = bi["means"][0] - bi["cams"].campos[0][None]
+    d = d / d.norm(dim=-1, keepdim=True)
+    want = torch.clamp_min(0.5 + geometry.eval_sh(4, sc.color_sh, d), 0.0).numpy()
+    vis = o_ref["radii"] > 0
+    assert vis.sum() > 50
+    np.testing.assert_allclose(o_ref["rgb"][vis], want[vis], rtol=0, atol=2e-6)
+    assert np.abs(o_3dgs["rgb"][vis] - want[vis]).max() > 1e-3      # the two conventions really differ

@@ -331,3 +331,45 @@ def test_view_group_argument_errors(hip_device):
         rasterize_views(vt, 32, 32, 0, two(m), c, o, features=f)
     out = rasterize_views(vt, 32, 32, 0, two(m), two(c), two(o), features=two(f))
     assert out[1].shape == (4, 4, 32, 32)
+
+
+def test_color_sh_reference_axis_convention(hip_device):
+    """lsr_dims.color_sh_convention = LSR_SH_AXES_REFERENCE (rasterizer.set_color_sh_convention):
+    colours and the gradients w.r.t. SH coefficients and means equal the oracle in the same
+    convention, degree 4; and the default convention is restored / still differs."""
+    from latentsplat_amd import rasterizer as rz
+    from oracle import oracle as orc
+    dev = hip_device
+    sc = util.make_scene(2000, image_size=64, views=2, color_sh_degree=4, feature_channels=4, feature_sh_degree=0)
+    bi = util.boundary_inputs(sc, 64, 64, bg=(0.2, 0.1, 0.3))
+    views = util.view_table(bi, dev)
+    gen = torch.Generator().manual_seed(13)
+    g_color = torch.randn((2, 3, 64, 64), generator=gen)
+
+    def run():
+        req = lambda t: t.to(dev).clone().requires_grad_(True)
+        means, cov6, opac, shs, feats = map(req, (bi["means"], bi["cov6"], bi["opac"], bi["shs"], bi["features"]))
+        color, feat, mask, depth, radii = rz.rasterize_views(views, 64, 64, 4, means, cov6, opac, shs=shs, features=feats)
+        (color * g_color.to(dev)).sum().backward()
+        return color.detach().cpu().numpy(), means.grad.cpu().numpy(), shs.grad.cpu().numpy()
+
+    default_color = run()[0]
+    try:
+        rz.set_color_sh_convention("reference")
+        orc.set_sh_convention("reference")
+        assert rz.get_color_sh_convention() == "reference"
+        color, g_means, g_shs = run()
+        want_shs = np.zeros(tuple(bi["shs"].shape), np.float64)
+        for v in range(2):
+            o = util.oracle_forward(bi, v)
+            util.assert_close_except_fragile(color[v], o["color"], o, ABS_TOL, "colour (reference SH axes)")
+            b = util.oracle_backward(bi, v, o, g_color[v].numpy(), None)
+            direct, behind = util.fragile_gaussians(o, 64)
+            util.assert_grad_close_except_fragile(g_means[v], b["means3D"], direct, behind, ABS_TOL, "dL/dmeans3D (reference SH axes)")
+            want_shs += b["shs"]
+        assert np.abs(g_shs - want_shs).max() <= ABS_TOL * max(1.0, np.abs(want_shs).max())
+    finally:
+        rz.set_color_sh_convention("3dgs")
+        orc.set_sh_convention("3dgs")
+    assert np.abs(color - default_color).max() > 1e-3
+    assert np.array_equal(run()[0], default_color)

@@ -181,6 +181,46 @@ def test_identical_depths_sort_by_index(hip_device):
         assert np.all(np.diff(seg) > 0)           # equal depth -> strictly ascending indices
 
 
+def test_orthographic_matches_reference_wrapper_golden(hip_device):
+    """render_cuda_orthographic on the MI355X == the RenderOutput the REFERENCE's own
+    render_cuda_orthographic (cuda_splatting.py:170-292) produced for the same inputs (with the oracle
+    as its rasterizer; tests/golden/make_golden.py::orthographic).  The camera sits ~1.7e3 units behind
+    the scene with a 0.1 degree field of view: projection entries ~1e3, depths ~1e3."""
+    from latentsplat_amd.decoder import render_cuda_orthographic
+    g = np.load(os.path.join(GOLD, "orthographic.npz"))
+    dev = hip_device
+    t = lambda k: _t(g["in_" + k], dev)
+    out = render_cuda_orthographic(
+        extrinsics=t("extrinsics"), width=t("width"), height=t("height"), near=t("near"), far=t("far"),
+        image_shape=tuple(int(x) for x in g["in_image_shape"]), background_features=t("background_features"),
+        gaussian_means=t("gaussian_means"), gaussian_covariances=t("gaussian_covariances"),
+        gaussian_opacities=t("gaussian_opacities"), gaussian_color_sh_coefficients=t("gaussian_color_sh_coefficients"),
+        gaussian_feature_sh_coefficients=t("gaussian_feature_sh_coefficients"))
+    for k in ("color", "feature", "mask", "depth"):
+        want = g["out_" + k]
+        got = getattr(out, k).cpu().numpy()
+        assert got.shape == want.shape
+        err = np.abs(got - want)
+        tol = 1e-4 * max(1.0, np.abs(want).max())
+        # the 1e3-scale projection amplifies float differences of the pixel position: allow isolated
+        # pixels at alpha-threshold decisions, everything else on the bar
+        assert (err > tol).mean() <= 0.002, f"{k}: {(err > tol).sum()} of {err.size} values off by more than {tol:.1e} (max {err.max():.3e})"
+    # the drop-in module accepts the tensor-valued tan fov the reference passes on this path (:260-261)
+    import diff_gaussian_rasterization as dgr
+    s = dgr.GaussianRasterizationSettings(
+        image_height=int(g["in_image_shape"][0]), image_width=int(g["in_image_shape"][1]),
+        tanfovx=torch.tensor(float(g["call0_tanfovx"]), device=dev), tanfovy=torch.tensor([float(g["call0_tanfovy"])], device=dev),
+        bg=_t(g["call0_bg"], dev), scale_modifier=1.0, viewmatrix=_t(g["call0_viewmatrix"], dev),
+        projmatrix=_t(g["call0_projmatrix"], dev), sh_degree=int(g["call0_sh_degree"]), campos=_t(g["call0_campos"], dev),
+        prefiltered=False, debug=False)
+    means = _t(g["call0_means3D"], dev)
+    image, feature_map, mask, depth, _ = dgr.GaussianRasterizer(s)(
+        means3D=means, means2D=torch.zeros_like(means), shs=_t(g["call0_shs"], dev), colors_precomp=None,
+        features=_t(g["call0_features"], dev), opacities=_t(g["call0_opacities"], dev), cov3D_precomp=_t(g["call0_cov3D_precomp"], dev))
+    err = np.abs(image.cpu().numpy() - g["out_color"][0])
+    assert (err > 1e-4).mean() <= 0.002 and mask.shape == (1,) + tuple(g["in_image_shape"])
+
+
 def test_orthographic_and_depth_modes_run(hip_device):
     from latentsplat_amd.decoder import render_cuda_orthographic, render_depth_cuda
     dev = hip_device
@@ -197,12 +237,15 @@ def test_orthographic_and_depth_modes_run(hip_device):
         assert dm.shape == (2, 48, 48) and torch.isfinite(dm).all()
 
 
-def _exempt_fragile_pixels(err_hw, ofw):
+def _exempt_fragile_pixels(err_hw, ofw, what="full-size image"):
     """Zero the error of pixels where the oracle saw an evaluation within float rounding of one of
-    the algorithm's discontinuities (alpha == 1/255, T == 1e-4): either decision is correct there."""
+    the algorithm's discontinuities (alpha == 1/255, T == 1e-4): either decision is correct there.
+    The number of exempt pixels is bounded (< 0.3 % of the image) and recorded."""
     assert not ofw["fragile_overflow"] and len(ofw["fragile"]) < 200
-    for pix in np.unique(ofw["fragile"][:, 0]):
+    pixels = np.unique(ofw["fragile"][:, 0])
+    for pix in pixels:
         err_hw[pix // err_hw.shape[1], pix % err_hw.shape[1]] = 0
+    util._account("image", what, err_hw.size, err_hw.size - len(pixels), len(pixels), 0, 1e-4, 1.0, err_hw.max())
 
 
 # ------------------------------------------------------------------------------------------
@@ -278,27 +321,17 @@ def test_full_size_backward_against_oracle(hip_device, full_run):
     grads = torch.autograd.grad((out[1] * g.to(dev)).sum(), (m, c, o, f))
     ofw = util.oracle_forward(bi, 0)
     b = util.oracle_backward(bi, 0, ofw, None, g[0].numpy())
-    assert not ofw["fragile_overflow"] and len(ofw["fragile"]) < 200
     # A decision flip at a fragile evaluation changes alpha by 1/255 for ONE (pixel, Gaussian) and
-    # therefore the transmittance of everything behind it in that pixel: the Gaussian itself is
-    # exempt, the other members of that pixel's tile list get the flip-sized bound.
-    fragile_gaussians = np.unique(ofw["fragile"][:, 1])
-    behind = []
-    for pix in np.unique(ofw["fragile"][:, 0]):
-        tile = (pix // 256 // 16) * 16 + (pix % 256) // 16
-        s0, s1 = ofw["ranges"][tile]
-        behind.append(ofw["point_list"][s0:s1])
-    behind = np.unique(np.concatenate(behind)) if behind else np.zeros(0, np.int64)
+    # therefore the transmittance of everything that contributes to that pixel: the Gaussian itself
+    # is exempt, the other contributors of that pixel get the flip-sized bound, everything else
+    # (>= 95 % of the rows, asserted and recorded by the helper) is held to 1e-4 of the scale.
+    direct, behind = util.fragile_gaussians(ofw, 256)
     for name, got, want in (("means3D", grads[0][0], b["means3D"]), ("cov3D", grads[1][0], b["cov3D"]),
                             ("opacities", grads[2], b["opacities"]), ("features", grads[3][0], b["features"])):
         got = got.cpu().numpy()
+        util.assert_grad_close_except_fragile(got, want, direct, behind, 1e-4, f"full-size dL/d{name}")
         err = np.abs(got - want).reshape(got.shape[0], -1).max(1)
-        scale = max(1.0, np.abs(want).max())
-        err[fragile_gaussians] = 0   # evaluations within float rounding of a discontinuity (see oracle)
-        assert err[behind].max(initial=0) <= 5e-3 * scale
-        err[behind] = 0
-        assert err.max() <= 1e-4 * scale, f"{name}: {err.max():.3e} vs scale {scale:.3e} (row {err.argmax()})"
-        assert np.median(err) <= 1e-6 * scale
+        assert np.median(err) <= 1e-6 * max(1.0, np.abs(want).max())
 
 
 def test_device_camera_table_matches_host_math(hip_device):
@@ -353,3 +386,59 @@ def test_single_gaussian_and_single_pixel_images(hip_device):
         np.testing.assert_array_equal(run.radii[0].cpu().numpy(), o["radii"])
         np.testing.assert_allclose(run.feat_out[0].cpu().numpy(), o["feature"], atol=1e-4)
         np.testing.assert_allclose(run.mask_out[0].cpu().numpy(), o["mask"], atol=1e-4)
+
+
+def test_shape_mismatches_are_rejected_before_any_launch(hip_device):
+    """A shared (stride-0) tensor whose G / trailing dims disagree with means3D must raise instead of
+    letting the kernels read out of bounds."""
+    from latentsplat_amd._lib import LsrError
+    from latentsplat_amd.rasterizer import rasterize_views
+    dev = hip_device
+    sc = util.make_scene(500, image_size=32, views=2, color_sh_degree=1, feature_channels=4)
+    bi = util.boundary_inputs(sc, 32, 32)
+    views = util.view_table(bi, dev)
+    m, c, o, sh, f = (bi[k].to(dev) for k in ("means", "cov6", "opac", "shs", "features"))
+    ok = rasterize_views(views, 32, 32, 1, m, c, o, shs=sh, features=f)
+    assert ok[0].shape == (2, 3, 32, 32)
+    for kw in (dict(o=o[:-1]), dict(sh=sh[:-3]), dict(f=f[:, :-1]), dict(c=c[:, :-2]), dict(o=o[:, 0]),
+               dict(sh=sh[:, :, :2]), dict(c=c[..., :5])):
+        a = dict(m=m, c=c, o=o, sh=sh, f=f); a.update(kw)
+        with pytest.raises(LsrError):
+            rasterize_views(views, 32, 32, 1, a["m"], a["c"], a["o"], shs=a["sh"], features=a["f"])
+
+
+def test_odd_gaussian_count_unaligned_sh_slices(hip_device):
+    """G = 2001: per-view SH slices (G*K*3 floats apart) and a caller's shs[i] view are not 16-byte
+    aligned, so the SH kernels must leave the 16-byte LDS-DMA staging path."""
+    from latentsplat_amd.rasterizer import rasterize_views
+    dev = hip_device
+    sc = util.make_scene(2001, image_size=48, views=3, color_sh_degree=2, feature_channels=4, feature_sh_degree=1)
+    bi = util.boundary_inputs(sc, 48, 48)
+    views = util.view_table(bi, dev)
+    V, G = 3, 2001
+    shs_pv = bi["shs"][None].expand(V, -1, -1, -1).contiguous().to(dev).requires_grad_(True)     # (V,G,9,3): odd slice stride
+    m, c, o, f = (bi[k].to(dev) for k in ("means", "cov6", "opac", "features"))
+    color, feat, mask, depth, radii = rasterize_views(views, 48, 48, 2, m, c, o, shs=shs_pv, features=f)
+    g = torch.randn(color.shape, generator=torch.Generator().manual_seed(3))
+    (color * g.to(dev)).sum().backward()
+    for v in range(V):
+        ov = util.oracle_forward(bi, v)
+        util.assert_close_except_fragile(color[v].detach().cpu().numpy(), ov["color"], ov, 1e-4, "colour (odd G)")
+        b = util.oracle_backward(bi, v, ov, g[v].numpy(), None)
+        want = b["shs"]
+        assert np.abs(shs_pv.grad[v].cpu().numpy() - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    # drop-in per-view pattern with a slice that starts at an odd float offset of its storage
+    import diff_gaussian_rasterization as dgr
+    big = torch.zeros(G * 9 * 3 + 1, device=dev)
+    big[1:] = bi["shs"].to(dev).reshape(-1)
+    shs_off = big[1:].view(G, 9, 3)
+    assert shs_off.data_ptr() % 16 != 0
+    c0 = bi["cams"]
+    s = dgr.GaussianRasterizationSettings(image_height=48, image_width=48, tanfovx=float(c0.tan_fov_x[0]), tanfovy=float(c0.tan_fov_y[0]),
+                                          bg=bi["bg"][0].to(dev), scale_modifier=1.0, viewmatrix=c0.view_matrix[0].to(dev),
+                                          projmatrix=c0.full_projection[0].to(dev), sh_degree=2, campos=c0.campos[0].to(dev),
+                                          prefiltered=False, debug=False)
+    img = dgr.GaussianRasterizer(s)(means3D=m[0], means2D=torch.zeros_like(m[0]), shs=shs_off, colors_precomp=None,
+                                    features=None, opacities=o, cov3D_precomp=c[0])[0]
+    o0 = util.oracle_forward(bi, 0)
+    util.assert_close_except_fragile(img.cpu().numpy(), o0["color"], o0, 1e-4, "colour (unaligned shs view)")

@@ -152,48 +152,96 @@ class HipRun:
             self.d.num_views, self.d.height, self.d.width)
 
 
+# ---- accounting of what the parity assertions actually held to the bar -------------------------
+# Every call appends one record; tests/conftest.py prints the table at the end of the session and
+# writes it to tests/_parity_accounting.json (so a reader sees how many pixels / rows were exempt).
+ACCOUNTING: list = []
+
+
+def _account(kind, what, total, strict, bounded, exempt, tol, scale, worst):
+    ACCOUNTING.append(dict(kind=kind, what=what, total=int(total), held_to_bar=int(strict), flip_bounded=int(bounded),
+                           exempt=int(exempt), tol=float(tol), scale=float(scale), worst_strict_err=float(worst)))
+
+
 def assert_close_except_fragile(got, want, oracle_fwd, atol, what=""):
     """|got - want| <= atol on every pixel except those where the oracle saw an evaluation within
     float rounding of one of the algorithm's discontinuities (alpha == 1/255 skip, T == 1e-4 stop):
     there two correct float implementations may legitimately take different branches, which moves
-    the pixel by up to alpha*T*c ~ 4e-3.  At most a handful of pixels may be exempt."""
+    the pixel by up to alpha*T*c ~ 4e-3 (bounded at 2e-2).  Only such pixels may miss `atol` (at most
+    2 % of the image may even be candidates); fragile pixels that meet the bar anyway count as held to
+    it.  The counts are recorded in ACCOUNTING."""
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     err = np.abs(got - want).reshape(-1, got.shape[-2], got.shape[-1]).max(0)
     frag = np.unique(oracle_fwd["fragile"][:, 0]) if len(oracle_fwd["fragile"]) else np.zeros(0, np.int64)
-    assert not oracle_fwd["fragile_overflow"] and len(frag) <= max(8, err.size // 50), f"{what}: too many fragile pixels"
-    if len(frag):
-        assert err.reshape(-1)[frag].max() <= 2e-2, f"{what}: fragile pixel moved more than one alpha step"
-        err.reshape(-1)[frag] = 0
-    assert err.max() <= atol, f"{what}: max abs err {err.max():.3e} > {atol:.1e}"
+    assert not oracle_fwd["fragile_overflow"], f"{what}: fragile list overflow"
+    assert len(frag) <= max(8, err.size // 50), f"{what}: {len(frag)} of {err.size} pixels fragile (> 2 %)"
+    flat = err.reshape(-1)
+    miss = flat > atol
+    allowed = np.zeros(flat.size, bool)
+    allowed[frag] = True
+    stray = miss & ~allowed
+    assert not stray.any(), f"{what}: {int(stray.sum())} non-fragile pixels off by more than {atol:.1e} (max abs err {flat[stray].max():.3e})"
+    assert flat[miss].max(initial=0) <= 2e-2, f"{what}: fragile pixel moved more than one alpha step"
+    _account("image", what, flat.size, flat.size - int(miss.sum()), int(miss.sum()), 0, atol, 1.0, flat[~miss].max(initial=0))
 
 
 def fragile_gaussians(oracle_fwd, W):
-    """(direct, behind): Gaussians of near-discontinuity evaluations, and every member of the tile
-    lists of the affected pixels (their transmittance changes if the decision flips)."""
+    """(direct, behind) for the gradient assertions.
+    direct: Gaussians of the near-discontinuity evaluations themselves (either decision is correct;
+            their own gradient moves by a flip-sized amount).
+    behind: every OTHER Gaussian that contributes (alpha >= 1/255, power <= 0) to a pixel holding such
+            an evaluation — its transmittance / accumulated-behind term changes if the decision flips.
+            Gaussians of the pixel's tile list that do not reach the pixel are NOT affected and stay on
+            the strict bar (round 1 exempted the whole tile list)."""
     fr = oracle_fwd["fragile"]
     if len(fr) == 0:
         return np.zeros(0, np.int64), np.zeros(0, np.int64)
     gx = (W + 15) // 16
+    xy, co = oracle_fwd["xy"].astype(np.float64), oracle_fwd["conic_opacity"].astype(np.float64)
     behind = []
     for pix in np.unique(fr[:, 0]):
+        px, py = float(pix % W), float(pix // W)
         tile = (pix // W // 16) * gx + (pix % W) // 16
         s0, s1 = oracle_fwd["ranges"][tile]
-        behind.append(oracle_fwd["point_list"][s0:s1].astype(np.int64))
-    return np.unique(fr[:, 1]).astype(np.int64), np.unique(np.concatenate(behind))
+        lst = oracle_fwd["point_list"][s0:s1].astype(np.int64)
+        dx, dy = xy[lst, 0] - px, xy[lst, 1] - py
+        power = -0.5 * (co[lst, 0] * dx * dx + co[lst, 2] * dy * dy) - co[lst, 1] * dx * dy
+        alpha = np.minimum(0.99, co[lst, 3] * np.exp(np.minimum(power, 0.0)))
+        behind.append(lst[(power <= 1e-6) & (alpha >= 1.0 / 255.0 - 1e-5)])
+    direct = np.unique(fr[:, 1]).astype(np.int64)
+    behind = np.setdiff1d(np.unique(np.concatenate(behind)), direct)
+    return direct, behind
 
 
-def assert_grad_close_except_fragile(got, want, direct, behind, tol, what=""):
-    """Per-Gaussian gradient rows within tol * scale, except rows of fragile evaluations (exempt)
-    and rows that share a pixel with one (bounded by a flip-sized 5e-3 * scale)."""
+def assert_grad_close_except_fragile(got, want, direct, behind, tol, what="", min_strict=0.95):
+    """Per-Gaussian gradient rows within tol * scale, scale = max(1, max |want|): ABSOLUTE `tol` for
+    gradients whose magnitude stays below 1, relative to the tensor's largest entry otherwise.
+    A row may miss that bar ONLY if it belongs to a fragile evaluation (`direct`: either decision is
+    correct, exempt) or shares a pixel with one (`behind`: flip-sized bound of 5e-3 * scale); rows of
+    those sets that meet the strict bar anyway are counted as held to it.  At least `min_strict` of
+    all rows must be within the strict bar; the counts go to ACCOUNTING."""
     got = np.asarray(got, np.float64).reshape(np.shape(want)[0], -1)
     want = np.asarray(want, np.float64).reshape(got.shape)
     scale = max(1.0, np.abs(want).max())
     err = np.abs(got - want).max(1)
-    assert len(direct) <= max(8, err.size // 100), f"{what}: too many fragile Gaussians"
-    err[direct] = 0
-    assert err[behind].max(initial=0) <= 5e-3 * scale, f"{what}: {err[behind].max():.3e} next to a fragile evaluation"
-    err[behind] = 0
-    assert err.max() <= tol * scale, f"{what}: max err {err.max():.3e} (scale {scale:.3e}, row {err.argmax()})"
+    n = err.size
+    assert len(direct) <= max(8, n // 100), f"{what}: too many fragile Gaussians ({len(direct)} of {n})"
+    miss = err > tol * scale
+    allowed = np.zeros(n, bool)
+    allowed[direct] = True
+    allowed[behind] = True
+    stray = miss & ~allowed
+    assert not stray.any(), (f"{what}: {int(stray.sum())} rows off the {tol:.0e} bar without a fragile evaluation nearby; "
+                             f"max err {err[stray].max():.3e} (scale {scale:.3e}, row {int(np.argmax(np.where(stray, err, 0)))})")
+    is_direct = np.zeros(n, bool)
+    is_direct[direct] = True
+    bounded = miss & ~is_direct
+    assert err[bounded].max(initial=0) <= 5e-3 * scale, f"{what}: {err[bounded].max():.3e} next to a fragile evaluation"
+    n_miss = int(miss.sum())
+    assert n - n_miss >= min_strict * n or n_miss <= 16, \
+        f"{what}: only {n - n_miss} of {n} rows within the {tol:.0e} bar (< {min_strict:.0%})"
+    _account("grad", what, n, n - n_miss, int(bounded.sum()), int((miss & is_direct).sum()), tol, scale,
+             err[~miss].max(initial=0))
 
 
 def to_boundary(views, v, means3D, cov3D_precomp, opacities, shs, colors_precomp, features, feature_sh,
