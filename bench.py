@@ -142,9 +142,17 @@ def timed_region(step, steps, warmup, dist=None, device_sync=lambda: None, reduc
     barrier()
     if dist is not None:
         t = torch.tensor([el], device=reduce_device, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)
+        PER_RANK_SECONDS[:] = [float(x.item()) for x in every]     # last timed region, every rank's own time
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    else:
+        PER_RANK_SECONDS[:] = [el]
     return el
+
+
+PER_RANK_SECONDS: list = []
 
 
 def whole_job_views_per_s(views_per_step, steps, world, elapsed_max):
@@ -291,6 +299,142 @@ def latent_step_timing(dev, steps=20):
     return res
 
 
+def latency_timing(dev, G, S, seed, iters=30):
+    """Latency of small view batches at the configs[1] scene (the reference renders ONE view per
+    rasterizer call, cuda_splatting.py:124-162, and times the decoder per view with a host
+    wall-clock and no device synchronisation inside, src/misc/benchmarker.py:11-37 /
+    model_wrapper.py:542-550).  For V = 1 and V = 4, ms per call with a device synchronisation after
+    EVERY call (latency) and over a stream of calls (throughput), for
+      sync    : lsr_forward_prepare + lsr_forward_render (one host wait for the pair count),
+      nosync  : lsr_forward_nosync with a pair capacity of 1.5x the measured count,
+      graph   : the nosync launch sequence captured once in a hipGraph (torch.cuda.graph) and replayed;
+    plus the zero-touch drop-in: a Python loop constructing GaussianRasterizationSettings /
+    GaussianRasterizer per view exactly like the reference does, seconds per view Benchmarker-style."""
+    import diff_gaussian_rasterization as dgr
+    from latentsplat_amd.rasterizer import last_forward_status, rasterize_views
+    res = {}
+    sync = lambda: torch.cuda.synchronize(dev)
+    for V in (1, 4):
+        inp = build_inputs(G, V, S, dev, seed)
+        call = lambda **kw: rasterize_views(inp["views"], S, S, 0, inp["means"], inp["cov"], inp["opac"], features=inp["features"], **kw)
+        with torch.no_grad():
+            call(); st = last_forward_status()
+            kw = dict(pair_capacity=int(1.5 * st["num_pairs"]), max_tile_hint=int(st["max_tile_pairs"]))
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    call(**kw)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gout = call(**kw)
+            modes = dict(sync=lambda: call(), nosync=lambda: call(**kw), graph=graph.replay)
+            r = {}
+            for name, fn in modes.items():
+                for _ in range(3):
+                    fn()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    fn(); sync()
+                lat = (time.perf_counter() - t0) / iters
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    fn()
+                sync()
+                thr = (time.perf_counter() - t0) / iters
+                r[name] = dict(ms_per_call_synced=1e3 * lat, ms_per_call_streamed=1e3 * thr,
+                               ms_per_view_streamed=1e3 * thr / V)
+            r["overflow_after_graph"] = bool(last_forward_status()["overflow"])
+            res[f"views_{V}"] = r
+            del graph, gout
+    # ---- the reference's own call pattern, untouched: one GaussianRasterizer per view ----
+    from latentsplat_amd.decoder import cuda_splatting as cs
+    from latentsplat_amd.decoder.geometry import get_fov
+    from latentsplat_amd.synthetic import make_scene
+    V = 4
+    sc = make_scene(G, image_size=S, views=V, color_sh_degree=None, feature_channels=4, seed=seed).to(dev)
+    means = sc.means[None].expand(V, -1, -1)
+    covs = sc.covariances[None].expand(V, -1, -1, -1)
+    ext, nr, fr, means, covs = cs._scale_scene(sc.extrinsics, sc.near, sc.far, means, covs)
+    fov_x, fov_y = get_fov(sc.intrinsics).unbind(-1)
+    cams = cs._cameras(ext, nr, fr, fov_x, fov_y)
+    cov6 = cs._pack_covariances(covs).contiguous()
+    feats = (0.5 + 0.28209479177387814 * sc.feature_sh[..., 0]).contiguous()
+    opac = sc.opacities[:, None].contiguous()
+    bg = torch.zeros(3, device=dev)
+
+    def per_view_loop():
+        outs = []
+        for i in range(V):
+            settings = dgr.GaussianRasterizationSettings(
+                image_height=S, image_width=S, tanfovx=cams.tan_fov_x[i].item(), tanfovy=cams.tan_fov_y[i].item(), bg=bg,
+                scale_modifier=1.0, viewmatrix=cams.view_matrix[i], projmatrix=cams.full_projection[i], sh_degree=0,
+                campos=cams.campos[i], prefiltered=False, debug=False)
+            rasterizer = dgr.GaussianRasterizer(settings)
+            image, feature_map, mask, depth_map, _ = rasterizer(
+                means3D=means[i], means2D=torch.zeros_like(means[i]), shs=None, colors_precomp=None, features=feats,
+                opacities=opac, cov3D_precomp=cov6[i])
+            outs.append(feature_map)
+        return torch.stack(outs)
+
+    with torch.no_grad():
+        for _ in range(3):
+            per_view_loop()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            per_view_loop()
+        host = (time.perf_counter() - t0) / (iters * V)       # Benchmarker semantics: host clock, no device sync
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            per_view_loop()
+        sync()
+        full = (time.perf_counter() - t0) / (iters * V)
+    res["dropin_per_view_loop"] = dict(
+        seconds_per_view_benchmarker=host, seconds_per_view_device_complete=full, views=V,
+        note="GaussianRasterizationSettings + GaussianRasterizer constructed per view, two .item() reads per view, "
+             "exactly the call pattern of cuda_splatting.py:124-162; 'benchmarker' = host wall-clock without a final "
+             "device synchronisation (src/misc/benchmarker.py:16-23)")
+    res["config"] = f"configs[1] scene: {G} Gaussians, 4-ch features, {S}x{S}; {iters} calls per figure"
+    return res
+
+
+def cpu_baseline_torch(budget_s=6.0):
+    """Second CPU baseline: the differentiable PyTorch-CPU oracle behind the
+    GaussianRasterizer-shaped API (oracle/torch_oracle.py).  It evaluates pixels x Gaussians densely,
+    so it is timed on a configs[0]-flavoured fixture (2 000 Gaussians, 64x64, RGB SH degree 0), not on
+    the 300 k scene; the C/OpenMP port above is the baseline of the headline workload."""
+    from oracle import torch_oracle as to
+    from tests import util
+    from latentsplat_amd.synthetic import make_scene
+    threads = min(32, os.cpu_count())
+    torch.set_num_threads(threads)
+    sc = make_scene(2000, image_size=64, views=1, color_sh_degree=0, feature_channels=None, seed=5)
+    bi = util.boundary_inputs(sc, 64, 64)
+    c = bi["cams"]
+    args = lambda: (64, 64, float(c.tan_fov_x[0]), float(c.tan_fov_y[0]), bi["bg"][0], c.view_matrix[0], c.full_projection[0],
+                    c.campos[0], 0, bi["means"][0].clone().requires_grad_(True), bi["cov6"][0].clone().requires_grad_(True),
+                    bi["opac"].clone().requires_grad_(True))
+
+    def fwdbwd():
+        a = args()
+        out = to.rasterize(*a, shs=bi["shs"].clone().requires_grad_(True))
+        out[0].sum().backward()
+
+    fwdbwd()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and n < 20:
+        fwdbwd()
+        n += 1
+    el = time.perf_counter() - t0
+    return dict(value=n / el, unit="views/s (forward+backward)", cores=threads, kind="port",
+                sample=f"{n} forward+backward passes of oracle/torch_oracle.py on 2000 Gaussians, 64x64, RGB SH degree 0 "
+                       "(dense pixels x Gaussians autograd restatement; does not scale to the 300k scene)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,6 +482,7 @@ def main():
     _lib.profile_enable(True, only=("render_forward",))   # the roofline kernel: hipEvents over the timed region itself
     _lib.profile_read()
     el_fwd = timed(lambda: fwd(False), args.steps, args.warmup)
+    per_rank_fwd = [1e3 * t / args.steps for t in PER_RANK_SECONDS]
     prof_render = _lib.profile_read()["render_forward"]
     _lib.profile_enable(True)
     timed(lambda: fwd(False), max(5, args.steps // 2), 1)
@@ -346,6 +491,18 @@ def main():
     _lib.profile_enable(False)
     views_total = V * args.steps * world
     value = whole_job_views_per_s(V, args.steps, world, el_fwd)
+    # spread over single steps (outside the timed region: one device synchronisation per step)
+    _lib.profile_enable(False)
+    single = []
+    for _ in range(args.steps):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        fwd(False)
+        torch.cuda.synchronize(dev)
+        single.append(1e3 * (time.perf_counter() - t0))
+    single.sort()
+    step_spread = dict(min=single[0], median=single[len(single) // 2], max=single[-1],
+                       note="each step synchronised on its own (adds the launch-to-idle latency the back-to-back timed region hides)")
 
     # ---- fwd+bwd (configs[2]) ----
     fb = None
@@ -363,6 +520,7 @@ def main():
         prof_fb = _lib.profile_read()
         _lib.profile_enable(False)
         fb = dict(views_per_s=views_total / el_fb, ms_per_view=1e3 * el_fb / (V * args.steps),
+                  ms_per_step=1e3 * el_fb / args.steps,
                   kernel_ms_per_launch={k: (ms / n if n else None) for k, (ms, n) in prof_fb.items()})
 
     # ---- workload statistics for the byte model (outside the timed region) ----
@@ -379,6 +537,8 @@ def main():
     render_ms_per_launch = render_ms / max(render_n, 1)
     roofline = None
     roofline_valu = None
+    roofline_bwd = None
+    stage_roofline = None
     path = None
     if P is not None:
         # algorithmic bytes of ONE render launch (V views): sorted index + gathered record per pair,
@@ -408,6 +568,27 @@ def main():
                                  achieved=n_valu / (render_ms_per_launch * 1e-3) / 1e9, unit="G wave-instr/s",
                                  peak=1024 * 2.4e9 / 4 / 1e9, frac=issue_cycles / peak_cycles,
                                  source="profiles/traffic_render_forward.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_INSTS_VALU_TRANS_F32)")
+        # the backward compositing kernel the same way (configs[2]): sorted index + gathered record +
+        # one 64-byte gradient record per pair, per pixel: final_T, n_contrib, C upstream gradients and
+        # C rendered values in
+        if fb is not None and fb["kernel_ms_per_launch"].get("render_backward"):
+            bwd_ms = fb["kernel_ms_per_launch"]["render_backward"]
+            bwd_bytes = P * (4 + b_rec + 64) + V * S * S * (8 + 4 * C + 4 * C)
+            roofline_bwd = dict(bound="hbm", kernel="k_render_bwd", achieved=bwd_bytes / (bwd_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                                unit="GB/s", frac=bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                                algorithmic_bytes_per_launch=bwd_bytes, launch_ms=bwd_ms)
+        # every stage against the HBM roofline with its own algorithmic bytes
+        stage_bytes = dict(
+            preprocess=V * G * (12 + 36 + 4 + 4 * C) + g_vis * (64 + 16) + V * G * 4,
+            tile_scan=V * (S // 16) * (S // 16) * 12,
+            scatter=V * G * 16 + P * 8,
+            sort_tiles=P * (8 + 4),
+            render_forward=render_bytes)
+        stage_roofline = {}
+        for k, nbytes in stage_bytes.items():
+            ms, n = prof.get(k, (0.0, 0))
+            if n:
+                stage_roofline[k] = dict(ms=ms / n, algorithmic_bytes=nbytes, frac=nbytes / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS)
         # whole forward path per view against the same roofline (SURVEY §8(d) B_fwd)
         B_fwd_step = V * G * b_in + g_vis * b_rec + P * 16 + P * b_rec + V * S * S * b_out
         step_s = el_fwd / args.steps
@@ -418,6 +599,10 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(G, S, 1234)
+        cpu["torch_oracle"] = cpu_baseline_torch()
+    latency = None
+    if rank == 0 and world == 1 and not args.no_bwd:
+        latency = latency_timing(dev, G, S, 1234)
     dec_step = adapter_step = latent_step = None
     if rank == 0 and world == 1 and not args.no_bwd:
         del inp
@@ -442,6 +627,8 @@ def main():
                        "parallelism": f"replicas x{world} (one scene per rank, no data-path collective)"},
             "ms_per_view_fwd": 1e3 * el_fwd / (V * args.steps),
             "kernel_ms_per_launch": {k: (ms / n if n else None) for k, (ms, n) in prof.items()},
+            "per_rank_ms_per_step": per_rank_fwd, "ms_per_step_spread": step_spread,
+            "stage_roofline": stage_roofline, "roofline_bwd": roofline_bwd, "latency": latency,
             "fwdbwd": fb, "decoder_step": dec_step, "adapter_step": adapter_step, "latent_step": latent_step, "roofline": roofline, "roofline_valu": roofline_valu, "roofline_path": path, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

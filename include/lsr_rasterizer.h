@@ -192,6 +192,29 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
                        void *img_ws, int64_t num_pairs, int32_t max_tile_pairs,
                        const lsr_outputs *out, lsr_stream_t stream);
 
+/* ---- forward WITHOUT host synchronisation (latency mode; graph-capturable).  The same stages as
+ * lsr_forward_prepare + lsr_forward_render, but the pair count never travels to the host (upstream's
+ * blocking `num_rendered` read-back, SURVEY.md Appendix A.3 step 3, is what makes the reference's
+ * per-view loop at cuda_splatting.py:124-162 serialise host and device):
+ *   - bin_ws must hold `pair_capacity` pairs:
+ *       lsr_binning_workspace_bytes(d, pair_capacity, INT32_MAX)   (includes the merge scratch);
+ *   - `max_tile_hint` = expected longest tile list (e.g. from the previous frame's
+ *     lsr_forward_status); it only selects the LDS sort variant, longer lists still sort correctly;
+ *   - if the scene produces MORE pairs than `pair_capacity`, the last tile lists are truncated (no
+ *     out-of-bounds access), the images are then wrong and the overflow word is set: check it with
+ *     lsr_forward_status at the next convenient synchronisation point and re-run with more room;
+ *   - lsr_backward takes `num_pairs = pair_capacity` for such a forward.
+ * No allocation, no host wait, no host-visible write: the launch sequence can be captured in a
+ * hipGraph (torch.cuda.graph) and replayed. */
+int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, void *bin_ws, void *img_ws,
+                       int64_t pair_capacity, int32_t max_tile_hint, const lsr_outputs *out,
+                       lsr_stream_t stream);
+
+/* Pair count, longest tile list and overflow flag (0/1) of the most recent forward that used
+ * geom_ws.  Copies 32 bytes to the host and synchronises `stream`. */
+int lsr_forward_status(const lsr_dims *d, const void *geom_ws, int64_t *num_pairs_host,
+                       int32_t *max_tile_pairs_host, int32_t *overflow_host, lsr_stream_t stream);
+
 /* ---- backward. Needs the three workspaces of the matching forward, unmodified, and the images
  * that forward produced (`fwd`: colour / feature / depth are read wherever the corresponding
  * gradient in `gout` is given; mask and radii are not used).  The compositing gradient walks the

@@ -116,7 +116,8 @@ PLY_VERTEX_FLOATS = 17
 EXPORTS = (
     "lsr_abi_version", "lsr_error_string", "lsr_last_hip_error", "lsr_geom_workspace_bytes",
     "lsr_image_workspace_bytes", "lsr_binning_workspace_bytes", "lsr_grad_workspace_bytes",
-    "lsr_get_layout", "lsr_build_views", "lsr_forward_prepare", "lsr_forward_render", "lsr_backward",
+    "lsr_get_layout", "lsr_build_views", "lsr_forward_prepare", "lsr_forward_render", "lsr_forward_nosync",
+    "lsr_forward_status", "lsr_backward",
     "lsr_profile_enable", "lsr_profile_num_stages", "lsr_profile_stage_name", "lsr_profile_read",
     "lsr_adapter_forward", "lsr_adapter_backward", "lsr_latent_forward", "lsr_latent_backward",
     "lsr_ply_pack", "lsr_ply_write_host",
@@ -172,6 +173,10 @@ def load():
     lib.lsr_forward_render.restype = C.c_int
     lib.lsr_forward_render.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, I32,
                                        C.POINTER(Outputs), P]
+    lib.lsr_forward_nosync.restype = C.c_int
+    lib.lsr_forward_nosync.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, I32, C.POINTER(Outputs), P]
+    lib.lsr_forward_status.restype = C.c_int
+    lib.lsr_forward_status.argtypes = [C.POINTER(Dims), P, C.POINTER(I64), C.POINTER(I32), C.POINTER(I32), P]
     lib.lsr_backward.restype = C.c_int
     lib.lsr_backward.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, P, C.POINTER(Outputs),
                                  C.POINTER(OutGrads), P, C.POINTER(InGrads), P]

@@ -232,7 +232,7 @@ const char *lsr_error_string(int code) {
         case LSR_EINVAL: return "invalid dimensions or argument combination";
         case LSR_ENULL: return "required pointer is NULL";
         case LSR_ELAUNCH: return "HIP runtime error (see lsr_last_hip_error)";
-        case LSR_ECAPACITY: return "num_pairs is smaller than the pair count of lsr_forward_prepare";
+        case LSR_ECAPACITY: return "the scene produced more (Gaussian, tile) pairs than the capacity given to lsr_forward_nosync";
         case LSR_EUNSUPPORTED: return "unsupported size";
         default: return "unknown lsr error";
     }
@@ -297,7 +297,7 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
             (void)hipGetLastError();
         }
     }
-    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, h_hdr_dev, s));
+    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, h_hdr_dev, 0xFFFFFFFFu, s));
     uint32_t hdr[2] = {0, 0};
     if (h_hdr) {
         LSR_HIP(hipStreamSynchronize(s));
@@ -335,6 +335,49 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     return LSR_OK;
 }
 
+int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, void *bin_ws, void *img_ws,
+                       int64_t pair_capacity, int32_t max_tile_hint, const lsr_outputs *out, lsr_stream_t stream) {
+    g_last_hip_error = 0;
+    int rc = check_dims(d);
+    if (rc) return rc;
+    rc = check_inputs(d, in);
+    if (rc) return rc;
+    if (!geom_ws || !bin_ws || !img_ws || !out || !out->mask || !out->depth) return LSR_ENULL;
+    if (d->num_gaussians > 0 && !out->radii) return LSR_ENULL;
+    if (d->color_mode != LSR_COLOR_NONE && !out->color) return LSR_ENULL;
+    if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
+    if (pair_capacity < 1 || pair_capacity >= ((int64_t)1 << 32) || max_tile_hint < 0) return LSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    char *geom = (char *)geom_ws;
+    // the same stage sequence as prepare + render; nothing between the launches waits for the device
+    LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, s));
+    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, (uint32_t)pair_capacity, s));
+    rc = for_each_view_group(*d, *in, nullptr, [&](const lsr_dims &dg, const lsr_inputs &ig, const lsr_in_grads &, const lsr_dims *layout, int view0) -> int {
+        LSR_STAGE("sh_forward", s, launch_sh_forward(dg, ig, geom, s, layout, view0));
+        return LSR_OK;
+    });
+    if (rc) return rc;
+    LSR_STAGE("binning", s, launch_binning(*d, geom, (char *)bin_ws, pair_capacity, max_tile_hint, out->radii, s, true));
+    LSR_STAGE("render_forward", s, launch_render_forward(*d, *in, geom, (const char *)bin_ws, pair_capacity, (char *)img_ws, *out, s));
+    return LSR_OK;
+}
+
+int lsr_forward_status(const lsr_dims *d, const void *geom_ws, int64_t *num_pairs_host, int32_t *max_tile_pairs_host,
+                       int32_t *overflow_host, lsr_stream_t stream) {
+    g_last_hip_error = 0;
+    int rc = check_dims(d);
+    if (rc) return rc;
+    if (!geom_ws || !num_pairs_host || !max_tile_pairs_host || !overflow_host) return LSR_ENULL;
+    uint32_t hdr[8] = {};
+    hipStream_t s = (hipStream_t)stream;
+    LSR_HIP(hipMemcpyAsync(hdr, (const char *)geom_ws + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));
+    LSR_HIP(hipStreamSynchronize(s));
+    *num_pairs_host = (int64_t)hdr[kHdrPairs];
+    *max_tile_pairs_host = (int32_t)hdr[kHdrMaxTile];
+    *overflow_host = (int32_t)hdr[kHdrOverflow];
+    return LSR_OK;
+}
+
 int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, const void *bin_ws,
                  const void *img_ws, int64_t num_pairs, const int32_t *radii, const lsr_outputs *fwd,
                  const lsr_out_grads *gout, void *grad_ws, const lsr_in_grads *gin,
@@ -355,7 +398,7 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
     if (num_pairs > 0 && !bin_ws) return LSR_ENULL;
     hipStream_t s = (hipStream_t)stream;
     // zero the packed gradient records the compositing backward accumulates into
-    LSR_HIP(hipMemsetAsync(grad_ws, 0, grad_layout(*d).total, s));
+    LSR_HIP(launch_clear(grad_ws, grad_layout(*d).total, s));
     if (num_pairs > 0)
         LSR_STAGE("render_backward", s, launch_render_backward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs,
                                        (const char *)img_ws, *fwd, *gout, (char *)grad_ws, *gin, s));

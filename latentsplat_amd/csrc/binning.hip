@@ -4,8 +4,8 @@
 //
 //   k_tile_scan : exclusive scan of the per-tile pair counts (V*T entries) -> tile_start,
 //                 total pair count and the longest list (header[0], header[1]); also emits the
-//                 (view,tile) ids ordered longest-list-first (counting sort) — the work queue
-//                 order of the compositing kernels (longest-processing-time-first balancing).
+//                 compositing work items ordered longest-list-first (counting sort) — the work
+//                 queue order of both compositing kernels (longest-processing-time-first balancing).
 //   k_scatter   : every visible Gaussian writes (depth_bits<<32 | index) into each tile segment
 //                 it overlaps.  Slots come from a two-level reservation: LDS counters per block,
 //                 then ONE global atomic per (block, tile).
@@ -18,103 +18,119 @@ namespace lsr {
 
 // ------------------------------------------------------------------------------------------
 constexpr int kScanThreads = 1024;
+constexpr int kScanWaves = kScanThreads / LSR_WAVE;
+
+// Block-wide exclusive prefix sum of one value per thread: wave-level scans in registers (6 shuffles),
+// one LDS hop for the 16 wave totals — two barriers instead of the 20 of a Hillis-Steele ladder over
+// 1024 LDS slots (the kernel is a single workgroup on the critical path of every forward).
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+    const int lane = threadIdx.x & (LSR_WAVE - 1), wid = threadIdx.x / LSR_WAVE;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < LSR_WAVE; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == LSR_WAVE - 1) s_wave[wid] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kScanWaves; ++w) {
+        const uint32_t x = s_wave[w];
+        tot += x;
+        base += w < wid ? x : 0u;
+    }
+    __syncthreads();   // s_wave may be reused
+    total = tot;
+    return base + incl - v;
+}
+__device__ __forceinline__ uint32_t block_max(uint32_t v, uint32_t *s_wave) {
+    const int lane = threadIdx.x & (LSR_WAVE - 1), wid = threadIdx.x / LSR_WAVE;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+    if (lane == 0) s_wave[wid] = v;
+    __syncthreads();
+    uint32_t m = 0;
+#pragma unroll
+    for (int w = 0; w < kScanWaves; ++w) m = max(m, s_wave[w]);
+    __syncthreads();
+    return m;
+}
 
 __global__ void __launch_bounds__(kScanThreads)
-k_tile_scan(const uint32_t *__restrict__ count, const uint32_t *__restrict__ cost, uint32_t *__restrict__ start, uint32_t *header,
-            uint32_t *host_mirror, uint32_t *__restrict__ order, uint32_t *__restrict__ lpt, int N, int force_base, int limit_pct, uint32_t slots) {
-    __shared__ uint32_t s_sum[kScanThreads];
-    __shared__ uint32_t s_max[kScanThreads];
+k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *header,
+            uint32_t *host_mirror, uint32_t *__restrict__ order, int N, int force_base, int limit_pct, uint32_t slots,
+            uint32_t capacity) {
+    __shared__ uint32_t s_wave[kScanWaves];
+    __shared__ uint32_t s_cls[kScanThreads];      // counting-sort classes: histogram -> running offsets
     const int tid = threadIdx.x;
     const int per = (N + kScanThreads - 1) / kScanThreads;
     const int lo = tid * per, hi = min(N, lo + per);
     uint32_t sum = 0, mx = 0;
     for (int i = lo; i < hi; ++i) { const uint32_t c = count[i]; sum += c; mx = max(mx, c); }
-    s_sum[tid] = sum; s_max[tid] = mx;
-    __syncthreads();
-    for (int off = 1; off < kScanThreads; off <<= 1) {  // Hillis-Steele inclusive scan
-        uint32_t a = 0, m = 0;
-        if (tid >= off) { a = s_sum[tid - off]; m = s_max[tid - off]; }
-        __syncthreads();
-        s_sum[tid] += a; s_max[tid] = max(s_max[tid], m);
-        __syncthreads();
-    }
-    uint32_t run = s_sum[tid] - sum;  // exclusive prefix of this thread's chunk
-    for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(sum, s_wave, total);   // exclusive prefix of this thread's chunk
+    const uint32_t maxc = block_max(mx, s_wave);
+    // Offsets are clamped to the capacity of the binning workspace: with exact sizing (capacity =
+    // UINT32_MAX) nothing changes; in the no-sync forward a scene that produces more pairs than the
+    // caller provided for gets its last lists truncated (never an out-of-bounds write) and the
+    // overflow word set — the caller must then discard the result and retry with more room.
+    for (int i = lo; i < hi; ++i) { start[i] = min(run, capacity); run += count[i]; }
     if (tid == kScanThreads - 1) {
-        start[N] = s_sum[tid]; header[kHdrPairs] = s_sum[tid]; header[kHdrMaxTile] = s_max[tid];
+        start[N] = min(total, capacity); header[kHdrPairs] = total; header[kHdrMaxTile] = maxc;
+        header[kHdrOverflow] = total > capacity ? 1u : 0u;
         // the two numbers the host is waiting for go straight into its (mapped, pinned) memory:
         // no copy command between this kernel and the stream synchronisation
-        if (host_mirror) { host_mirror[0] = s_sum[tid]; host_mirror[1] = s_max[tid]; }
+        if (host_mirror) { host_mirror[0] = total; host_mirror[1] = maxc; }
     }
     // ---- work items, costliest first: counting sort on kScanThreads classes of the per-tile cost
-    // (= list length; `cost` aliases `count`.  A finer estimate — quadrants reached per entry,
-    // accumulated by k_preprocess — was measured to schedule no better and was removed) ----
-    const uint32_t maxc = s_max[kScanThreads - 1], total = s_sum[kScanThreads - 1];
-    __syncthreads();
-    uint32_t wmax = 0;
-    for (int i = lo; i < hi; ++i) wmax = max(wmax, cost[i]);
-    s_max[tid] = wmax;
-    __syncthreads();
-    for (int off = kScanThreads / 2; off > 0; off >>= 1) {
-        if (tid < off) s_max[tid] = max(s_max[tid], s_max[tid + off]);
-        __syncthreads();
-    }
-    const uint64_t scale = (uint64_t)s_max[0] + 1u;
+    // (= list length.  A finer estimate — quadrants reached per entry, accumulated by k_preprocess —
+    // was measured to schedule no better and was removed).  Tiles are split into 2 or 4 quadrant-set
+    // items when there are fewer tiles than wave slots, and when their list is much longer than the
+    // mean (lsr_internal.h kItem*). ----
+    const uint64_t scale = (uint64_t)maxc + 1u;
     uint32_t base = (uint32_t)N >= slots ? 1u : (2u * (uint32_t)N >= slots ? 2u : 4u);
     if (force_base) base = (uint32_t)force_base;
     const uint32_t mean = total / (uint32_t)N + 1u;
     const uint32_t limit = (uint32_t)((uint64_t)mean * (uint32_t)limit_pct / 100u) / base + 1u;   // longest list one item may walk
-    (void)maxc;
-    // pass 0: work items of the forward (tiles possibly split into quadrant sets) -> order[]
-    // pass 1: plain tiles, costliest first -> lpt[]   (unit order of the backward)
-    for (int pass = 0; pass < 2; ++pass) {
-        auto nsplit = [&](uint32_t c) -> uint32_t {
-            if (pass == 1) return 1u;
-            uint32_t sp = base;
-            while (sp < 4u && c / sp > limit) sp <<= 1;
-            return sp;
-        };
-        auto cls = [&](uint32_t w, uint32_t sp) -> uint32_t {
-            return kScanThreads - 1 - (uint32_t)(((uint64_t)(w / sp) * kScanThreads) / scale);
-        };
-        __syncthreads();
-        s_sum[tid] = 0;
-        __syncthreads();
-        for (int i = lo; i < hi; ++i) {
-            const uint32_t sp = nsplit(count[i]);
-            atomicAdd(&s_sum[cls(cost[i], sp)], sp);
-        }
-        __syncthreads();
-        const uint32_t mine = s_sum[tid];
-        for (int off = 1; off < kScanThreads; off <<= 1) {
-            uint32_t a = 0;
-            if (tid >= off) a = s_sum[tid - off];
-            __syncthreads();
-            s_sum[tid] += a;
-            __syncthreads();
-        }
-        s_max[tid] = s_sum[tid] - mine;  // exclusive start of class tid
-        if (pass == 0 && tid == kScanThreads - 1) header[kHdrNumItems] = s_sum[tid];
-        __syncthreads();
-        for (int i = lo; i < hi; ++i) {
-            const uint32_t sp = nsplit(count[i]);
-            const uint32_t at = atomicAdd(&s_max[cls(cost[i], sp)], sp);
-            if (pass == 1) lpt[at] = (uint32_t)i;
-            else if (sp == 1) order[at] = (uint32_t)i | (0xFu << kItemOwnShift);
-            else if (sp == 2) { order[at] = (uint32_t)i | (0x3u << kItemOwnShift); order[at + 1] = (uint32_t)i | (0xCu << kItemOwnShift); }
-            else for (uint32_t q = 0; q < 4; ++q) order[at + q] = (uint32_t)i | ((1u << q) << kItemOwnShift);
-        }
+    auto nsplit = [&](uint32_t c) -> uint32_t {
+        uint32_t sp = base;
+        while (sp < 4u && c / sp > limit) sp <<= 1;
+        return sp;
+    };
+    auto cls = [&](uint32_t w, uint32_t sp) -> uint32_t {
+        return kScanThreads - 1 - (uint32_t)(((uint64_t)(w / sp) * kScanThreads) / scale);
+    };
+    s_cls[tid] = 0;
+    __syncthreads();
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t sp = nsplit(count[i]);
+        atomicAdd(&s_cls[cls(count[i], sp)], sp);
+    }
+    __syncthreads();
+    const uint32_t mine = s_cls[tid];
+    uint32_t num_items;
+    const uint32_t first = block_exclusive_scan(mine, s_wave, num_items);   // exclusive start of class tid
+    s_cls[tid] = first;
+    if (tid == 0) header[kHdrNumItems] = num_items;
+    __syncthreads();
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t sp = nsplit(count[i]);
+        const uint32_t at = atomicAdd(&s_cls[cls(count[i], sp)], sp);
+        if (sp == 1) order[at] = (uint32_t)i | (0xFu << kItemOwnShift);
+        else if (sp == 2) { order[at] = (uint32_t)i | (0x3u << kItemOwnShift); order[at + 1] = (uint32_t)i | (0xCu << kItemOwnShift); }
+        else for (uint32_t q = 0; q < 4; ++q) order[at + q] = (uint32_t)i | ((1u << q) << kItemOwnShift);
     }
 }
 
-hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror, hipStream_t s) {
+hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror, uint32_t pair_capacity, hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const int N = d.num_views * (int)num_tiles(d);
     prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
-                       (const uint32_t *)(geom + L.tile_count), (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
-                       (uint32_t *)(geom + L.header), host_mirror, (uint32_t *)(geom + L.tile_order), (uint32_t *)(geom + L.tile_lpt), N,
-                       env_int("LSR_SPLIT", 0), env_int("LSR_LIMIT", 150), (uint32_t)wave_slots(device_cus()));
+                       (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
+                       (uint32_t *)(geom + L.header), host_mirror, (uint32_t *)(geom + L.tile_order), N,
+                       env_int("LSR_SPLIT", 0), env_int("LSR_LIMIT", 150), (uint32_t)wave_slots(device_cus()), pair_capacity);
     prof_end(kStTileScan, s);
     return hipGetLastError();
 }
@@ -123,11 +139,11 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror
 constexpr int kScatThreads = 256;
 constexpr int kScatItems = 8;
 
-template <bool LDS_RESERVE>
+template <bool LDS_RESERVE, bool CHECK>
 __global__ void __launch_bounds__(kScatThreads)
 k_scatter(int G, int gx, int T, const BinRec *__restrict__ binrec,
           const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ tile_cursor,
-          uint64_t *__restrict__ keys) {
+          uint64_t *__restrict__ keys, uint32_t capacity) {
     extern __shared__ uint32_t s_mem[];  // [T] counts, [T] bases
     uint32_t *s_cnt = s_mem, *s_base = s_mem + T;
     const int v = blockIdx.y;
@@ -170,7 +186,7 @@ k_scatter(int G, int gx, int T, const BinRec *__restrict__ binrec,
                 uint32_t pos;
                 if (LDS_RESERVE) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
                 else pos = ts[t] + atomicAdd(&cur[t], 1u);
-                keys[pos] = key;
+                if (!CHECK || pos < capacity) keys[pos] = key;   // CHECK (no-sync forward): tile_scan clamped the offsets to the workspace capacity
             }
     }
 }
@@ -193,7 +209,7 @@ constexpr uint32_t kBucketOverflow = 48;   // longest bucket the insertion sort 
 template <int CAP>
 __global__ void __launch_bounds__(kSortThreads)
 k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
-             uint32_t *__restrict__ point_list) {
+             uint32_t *__restrict__ point_list, uint32_t longer_than) {
     constexpr int NB = CAP < 2048 ? CAP : 2048;          // buckets
     extern __shared__ uint64_t s_keys[];                  // [CAP] sorted keys
     uint32_t *s_cnt = (uint32_t *)(s_keys + CAP);         // [NB] histogram -> bucket end offsets
@@ -203,8 +219,8 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
     const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
     const size_t vt = (size_t)blockIdx.y * T + blockIdx.x;
     const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
-    if (n == 0) return;
-    if (n > (uint32_t)CAP) return;  // handled by the global-memory path
+    if (n == 0 || n <= longer_than) return;   // shorter lists belong to another launch (no-sync forward: two variants)
+    if (n > (uint32_t)CAP) return;  // handled by a larger variant / the global-memory path
     const uint64_t *src = keys + start;
     if (n == 1) { if (tid == 0) point_list[start] = (uint32_t)src[0]; return; }
 
@@ -367,11 +383,12 @@ k_sort_tiles_global(int T, uint32_t cap, const uint32_t *__restrict__ tile_start
 }
 
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
-                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s) {
+                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts) {
     (void)radii;
     if (num_pairs <= 0 || d.num_gaussians == 0) return hipSuccess;
     const GeomLayout L = geom_layout(d);
-    const BinLayout B = bin_layout(d, num_pairs, max_tile_pairs);
+    // no-sync forward: the merge scratch is always part of the layout (the longest list is unknown)
+    const BinLayout B = bin_layout(d, num_pairs, device_counts ? kSortLdsMax + 1 : max_tile_pairs);
     const int T = (int)num_tiles(d), gx = tiles_x(d);
     uint64_t *keys = (uint64_t *)(bin + B.keys);
     uint32_t *plist = (uint32_t *)(bin + B.point_list);
@@ -380,13 +397,13 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         dim3 grid((d.num_gaussians + kScatThreads * kScatItems - 1) / (kScatThreads * kScatItems), d.num_views);
         const bool lds = T <= 8192;
         prof_begin(kStScatter, s);
-        if (lds)
-            hipLaunchKernelGGL((k_scatter<true>), grid, dim3(kScatThreads), (size_t)T * 8, s,
-                               d.num_gaussians, gx, T, (const BinRec *)(geom + L.bin), ts,
-                               (uint32_t *)(geom + L.tile_cursor), keys);
-        else
-            hipLaunchKernelGGL((k_scatter<false>), grid, dim3(kScatThreads), 0, s, d.num_gaussians,
-                               gx, T, (const BinRec *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys);
+        const uint32_t capacity = (uint32_t)(num_pairs < 0xFFFFFFFFll ? num_pairs : 0xFFFFFFFFll);
+#define LSR_SCAT(LDSR, CHK, SHM)                                                                          \
+    hipLaunchKernelGGL((k_scatter<LDSR, CHK>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T,  \
+                       (const BinRec *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity)
+        if (lds) { if (device_counts) LSR_SCAT(true, true, (size_t)T * 8); else LSR_SCAT(true, false, (size_t)T * 8); }
+        else { if (device_counts) LSR_SCAT(false, true, 0); else LSR_SCAT(false, false, 0); }
+#undef LSR_SCAT
         prof_end(kStScatter, s);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -394,6 +411,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     {
         dim3 grid(T, d.num_views);
         int cap;
+        uint32_t longer_than = 0;
         prof_begin(kStSort, s);
 #define LSR_SORT(CAPV)                                                                           \
     do {                                                                                         \
@@ -404,17 +422,25 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
                                       CAPV * 8 + (CAPV < 2048 ? CAPV : 2048) * 4);               \
         hipLaunchKernelGGL((k_sort_tiles<CAPV>), grid, dim3(kSortThreads),                       \
                            (size_t)CAPV * 8 + (size_t)(CAPV < 2048 ? CAPV : 2048) * 4, s,        \
-                           T, ts, (const uint64_t *)keys, plist);                                \
+                           T, ts, (const uint64_t *)keys, plist, longer_than);                   \
     } while (0)
         if (max_tile_pairs <= 1024) LSR_SORT(1024);
         else if (max_tile_pairs <= 2048) LSR_SORT(2048);
         else if (max_tile_pairs <= 4096) LSR_SORT(4096);
         else if (max_tile_pairs <= 8192) LSR_SORT(8192);
         else LSR_SORT(16384);
-#undef LSR_SORT
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        if (max_tile_pairs > cap) {
+        if (device_counts && cap < kSortLdsMax) {
+            // the longest list is only a hint here: lists beyond the chosen variant take the largest
+            // LDS variant (blocks with nothing to do exit at once), anything longer the merge path
+            longer_than = (uint32_t)cap;
+            LSR_SORT(16384);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+#undef LSR_SORT
+        if (device_counts || max_tile_pairs > cap) {
             hipLaunchKernelGGL(k_sort_tiles_global, grid, dim3(kSortThreads), 0, s, T, (uint32_t)cap,
                                ts, keys, (uint64_t *)(bin + B.tmp), plist);
             e = hipGetLastError();

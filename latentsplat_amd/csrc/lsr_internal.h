@@ -17,7 +17,7 @@ namespace lsr {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t header, rec, bin, tile_count, tile_start, tile_cursor, tile_order, tile_lpt, sh_clamp, total;
+    size_t header, rec, bin, tile_count, tile_start, tile_cursor, tile_order, sh_clamp, total;
     int rec_floats;
 };
 struct ImgLayout {
@@ -72,7 +72,6 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     L.tile_cursor = o; o = align_up(o + VT * 4);   // adjacent to tile_count: one memset clears both
     L.tile_start = o; o = align_up(o + (VT + 1) * 4);
     L.tile_order = o; o = align_up(o + 4 * VT * 4);   // work items (see kItem*), costliest first
-    L.tile_lpt = o; o = align_up(o + VT * 4);         // (view,tile) ids, costliest first
     L.sh_clamp = o; o = align_up(o + VG);             // per (view, Gaussian): colour channels clamped at 0 (sh.hip)
     L.total = o;
     return L;
@@ -127,7 +126,7 @@ inline int wave_slots(int cus) { return cus * 4 * 4; }
 // Environment knobs are development aids; each is read ONCE per process (never on the launch path).
 int env_int(const char *name, int fallback);        // api.hip: latched on first use
 // header words of the geometry workspace
-enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrQueueFwd = 2, kHdrNumItems = 3 };
+enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrQueueFwd = 2, kHdrNumItems = 3, kHdrOverflow = 4 };
 
 // ---- optional per-stage hipEvent timing (api.hip); no-ops unless lsr_profile_enable(1) ----
 enum Stage { kStPreprocess = 0, kStTileScan, kStScatter, kStSort, kStRenderFwd, kStRenderBwd, kStPreprocessBwd, kStShFwd, kStShBwd, kStAdapterFwd, kStAdapterBwd, kStLatentFwd, kStLatentBwd, kNumStages };
@@ -135,10 +134,15 @@ void prof_begin(int stage, hipStream_t s);
 void prof_end(int stage, hipStream_t s);
 void note_hip_error(int hip_error);   // what lsr_last_hip_error() returns for this thread
 
+// Workspace clears are kernels, not hipMemsetAsync: captured memset nodes were observed not to clear on
+// back-to-back hipGraph replays (ROCm 7.2), which the latency mode relies on.
+hipError_t launch_clear(void *ptr, size_t bytes, hipStream_t s);
+
 // ---- stage launchers (defined one per .hip file) ----
 hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii,
                              hipStream_t s);
-hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror, hipStream_t s);
+// pair_capacity: pairs the binning workspace can hold (UINT32_MAX = exact sizing after a host read-back)
+hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror, uint32_t pair_capacity, hipStream_t s);
 hipError_t launch_build_views(int V, const float *extrinsics, const float *intrinsics, const float *near,
                               const float *far, const float *bg, int bg_stride, int scale_invariant,
                               float *out, hipStream_t s);
@@ -150,8 +154,10 @@ hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom
                              const lsr_dims *layout = nullptr, int view0 = 0);
 hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom, const char *grad,
                               const lsr_in_grads &gin, hipStream_t s, const lsr_dims *layout = nullptr, int view0 = 0);
+// device_counts: the pair count / longest list are NOT known on the host (no-sync forward):
+// `num_pairs` is then the workspace capacity and `max_tile_pairs` only a hint for the sort variant
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
-                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s);
+                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts = false);
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                  const char *bin, int64_t num_pairs, char *img, const lsr_outputs &out,
                                  hipStream_t s);

@@ -192,13 +192,29 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
     }
 }
 
+__global__ void __launch_bounds__(256) k_clear16(uint4 *p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+// Zero `bytes` (a multiple of 16) at a 16-byte aligned device address.
+hipError_t launch_clear(void *ptr, size_t bytes, hipStream_t s) {
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return hipSuccess;
+    const size_t blocks = (n16 + 255) / 256;
+    hipLaunchKernelGGL(k_clear16, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, (uint4 *)ptr, n16);
+    return hipGetLastError();
+}
+
 hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii,
                              hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const int T = (int)num_tiles(d);
-    // zero header + tile_count + tile_cursor (adjacent)
-    hipError_t e = hipMemsetAsync(geom + L.header, 0, L.tile_start - L.header, s);
-    if (e != hipSuccess) return e;
+    // zero header + tile_count + tile_cursor (adjacent).  A kernel rather than hipMemsetAsync: the
+    // stage sequence is captured into hipGraphs (latency mode), where back-to-back replays of a
+    // captured memset node were observed to leave the counters uncleared on ROCm 7.2.
+    {
+        hipError_t e = launch_clear(geom + L.header, L.tile_start - L.header, s);   // both offsets are 256-byte aligned
+        if (e != hipSuccess) return e;
+    }
     if (d.num_gaussians == 0) return hipSuccess;
     dim3 grid((d.num_gaussians + kPreThreads * kPreItems - 1) / (kPreThreads * kPreItems), d.num_views);
     float *rec = (float *)(geom + L.rec);

@@ -117,6 +117,111 @@ __device__ __forceinline__ float row_reduce16_transposed(float v0, float v1, flo
 #undef LVB
 }
 
+// Hand-scheduled versions of the same reduction for the two hot payload widths (4 and 8 channels, no
+// depth gradient).  Steps A and B select "which half a lane keeps" with the DPP BANK mask (a bank =
+// 4 lanes, exactly lane bits 2-3): the second add of a pair simply overwrites the lanes of the
+// selected banks, so a full pair costs two DPP adds instead of two selects + one DPP add.  Steps C
+// and D select inside a quad, which no DPP mask can express: v_cndmask with constant lane masks.
+// 25 VALU for 10 values (36 as compiled from row_reduce16_transposed), 31 for 14.
+// DPP reads need two wait states after a VALU write of the same register and inline asm is opaque
+// to the hazard recogniser: the instruction order below keeps >= 2 instructions between every
+// write and its DPP read, the two places where that is impossible carry an s_nop.
+#define LSR_DPP_A "row_ror:8 row_mask:0xf "
+#define LSR_DPP_B "row_half_mirror row_mask:0xf "
+#define LSR_DPP_C "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+#define LSR_DPP_D "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+__device__ __forceinline__ float row_reduce_4ch(float a0, float a1, float a2, float a3, float a4, float a5,
+                                                float p0, float p1, float p2, float p3) {
+    // lane l ends with: slots 0..5 = a0..a5, slots 8..11 = p0..p3 (other lanes: junk)
+    float r0, r1, r2, r3, r4, r5, s0, s1, s2, s3, k0, n0, k1, n1, t0, t1, k, n, out;
+    const uint64_t m1 = 0xCCCCCCCCCCCCCCCCull, m0 = 0xAAAAAAAAAAAAAAAAull;   // lanes with bit 1 / bit 0 set
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[r0], %[a0], %[a0] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r1], %[a1], %[a1] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r2], %[a2], %[a2] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r3], %[a3], %[a3] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r4], %[a4], %[a4] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r5], %[a5], %[a5] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r0], %[p0], %[p0] " LSR_DPP_A "bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[r1], %[p1], %[p1] " LSR_DPP_A "bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[r2], %[p2], %[p2] " LSR_DPP_A "bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[r3], %[p3], %[p3] " LSR_DPP_A "bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[s0], %[r0], %[r0] " LSR_DPP_B "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s1], %[r1], %[r1] " LSR_DPP_B "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s2], %[r2], %[r2] " LSR_DPP_B "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s3], %[r3], %[r3] " LSR_DPP_B "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s0], %[r4], %[r4] " LSR_DPP_B "bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[s1], %[r5], %[r5] " LSR_DPP_B "bank_mask:0xa\n\t"
+        "v_cndmask_b32_e64 %[k0], %[s0], %[s2], %[m1]\n\t"
+        "v_cndmask_b32_e64 %[n0], %[s2], %[s0], %[m1]\n\t"
+        "v_cndmask_b32_e64 %[n1], %[s3], %[s1], %[m1]\n\t"
+        "v_cndmask_b32_e64 %[k1], %[s1], %[s3], %[m1]\n\t"
+        "v_add_f32_dpp %[t0], %[n0], %[k0] " LSR_DPP_C "\n\t"
+        "v_add_f32_dpp %[t1], %[n1], %[k1] " LSR_DPP_C "\n\t"
+        "v_cndmask_b32_e64 %[k], %[t0], %[t1], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[n], %[t1], %[t0], %[m0]\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[out], %[n], %[k] " LSR_DPP_D
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [r5] "=&v"(r5),
+          [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2), [s3] "=&v"(s3), [k0] "=&v"(k0), [n0] "=&v"(n0),
+          [k1] "=&v"(k1), [n1] "=&v"(n1), [t0] "=&v"(t0), [t1] "=&v"(t1), [k] "=&v"(k), [n] "=&v"(n), [out] "=&v"(out)
+        : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [a4] "v"(a4), [a5] "v"(a5),
+          [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [m1] "s"(m1), [m0] "s"(m0));
+    return out;
+}
+__device__ __forceinline__ float row_reduce_8ch(float a0, float a1, float a2, float a3, float a4, float a5,
+                                                float p0, float p1, float p2, float p3, float p4, float p5, float p6, float p7) {
+    // slots 0..5 = a0..a5, slots 8..15 = p0..p7
+    float r0, r1, r2, r3, r4, r5, r6, r7, s0, s1, s2, s3, k0, n0, k1, n1, t0, t1, k, n, out;
+    const uint64_t m1 = 0xCCCCCCCCCCCCCCCCull, m0 = 0xAAAAAAAAAAAAAAAAull;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[r0], %[a0], %[a0] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r1], %[a1], %[a1] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r2], %[a2], %[a2] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r3], %[a3], %[a3] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r4], %[a4], %[a4] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r5], %[a5], %[a5] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r6], %[p6], %[p6] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r7], %[p7], %[p7] " LSR_DPP_A "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[r0], %[p0], %[p0] " LSR_DPP_A "bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[r1], %[p1], %[p1] " LSR_DPP_A "bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[r2], %[p2], %[p2] " LSR_DPP_A "bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[r3], %[p3], %[p3] " LSR_DPP_A "bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[r4], %[p4], %[p4] " LSR_DPP_A "bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[r5], %[p5], %[p5] " LSR_DPP_A "bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[s0], %[r0], %[r0] " LSR_DPP_B "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s1], %[r1], %[r1] " LSR_DPP_B "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s2], %[r2], %[r2] " LSR_DPP_B "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s3], %[r3], %[r3] " LSR_DPP_B "bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s0], %[r4], %[r4] " LSR_DPP_B "bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[s1], %[r5], %[r5] " LSR_DPP_B "bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[s2], %[r6], %[r6] " LSR_DPP_B "bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[s3], %[r7], %[r7] " LSR_DPP_B "bank_mask:0xa\n\t"
+        "v_cndmask_b32_e64 %[k0], %[s0], %[s2], %[m1]\n\t"
+        "v_cndmask_b32_e64 %[n0], %[s2], %[s0], %[m1]\n\t"
+        "v_cndmask_b32_e64 %[n1], %[s3], %[s1], %[m1]\n\t"
+        "v_cndmask_b32_e64 %[k1], %[s1], %[s3], %[m1]\n\t"
+        "v_add_f32_dpp %[t0], %[n0], %[k0] " LSR_DPP_C "\n\t"
+        "v_add_f32_dpp %[t1], %[n1], %[k1] " LSR_DPP_C "\n\t"
+        "v_cndmask_b32_e64 %[k], %[t0], %[t1], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[n], %[t1], %[t0], %[m0]\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[out], %[n], %[k] " LSR_DPP_D
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [r5] "=&v"(r5), [r6] "=&v"(r6), [r7] "=&v"(r7),
+          [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2), [s3] "=&v"(s3), [k0] "=&v"(k0), [n0] "=&v"(n0),
+          [k1] "=&v"(k1), [n1] "=&v"(n1), [t0] "=&v"(t0), [t1] "=&v"(t1), [k] "=&v"(k), [n] "=&v"(n), [out] "=&v"(out)
+        : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [a4] "v"(a4), [a5] "v"(a5),
+          [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [p4] "v"(p4), [p5] "v"(p5), [p6] "v"(p6), [p7] "v"(p7),
+          [m1] "s"(m1), [m0] "s"(m0));
+    return out;
+}
+#undef LSR_DPP_A
+#undef LSR_DPP_B
+#undef LSR_DPP_C
+#undef LSR_DPP_D
+
 __device__ __forceinline__ void atomic_add_f32(float *addr, float v) { unsafeAtomicAdd(addr, v); }
 
 // WPS = resident waves per SIMD (workgroup = 4*WPS waves = one compute unit's worth): 4 where the
@@ -403,7 +508,12 @@ k_render_bwd(RenderBwdParams p) {
                     // ---- sum over the sub-block's 16 pixels; lane s of the group ends up with slot s ----
                     {
                         constexpr uint32_t LIVE = 0x3Fu | (DEPTH_GRAD ? 0x40u : 0u) | (((1u << (NCHP < 8 ? NCHP : 8)) - 1u) << 8);
-                        const float tot = row_reduce16_transposed<LIVE>(
+                        float tot;
+                        if (!DEPTH_GRAD && NCHP == 4) tot = row_reduce_4ch(t1.x, t1.y, t2.x, mxy, t2.y, u, gp[0].x, gp[0].y, gp[1].x, gp[1].y);
+                        else if (!DEPTH_GRAD && NCHP == 8)
+                            tot = row_reduce_8ch(t1.x, t1.y, t2.x, mxy, t2.y, u, gp[0].x, gp[0].y, gp[1].x, gp[1].y,
+                                                 gp[2 % (NCHP / 2)].x, gp[2 % (NCHP / 2)].y, gp[3 % (NCHP / 2)].x, gp[3 % (NCHP / 2)].y);
+                        else tot = row_reduce16_transposed<LIVE>(
                             t1.x, t1.y, t2.x, mxy, t2.y, u, gz, 0.0f,
                             gp[0].x, gp[0].y, gp[1].x, gp[1].y,
                             NCHP > 4 ? gp[2 % (NCHP / 2)].x : 0.0f, NCHP > 4 ? gp[2 % (NCHP / 2)].y : 0.0f,

@@ -38,7 +38,8 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 
 struct RenderFwdParams {
     int H, W, gx, T, G, C, has_color;
-    int num_cus;                  // workgroups of 16 waves (one per compute unit)
+    int num_cus;                  // compute units (one workgroup of WPB waves each, or several smaller ones)
+    int waves_per_cu;             // resident compositing waves per CU the launch provides (16, or 12: see launch)
     const uint32_t *items;        // work items, costliest first
     const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t *queue;              // work-queue head (zeroed per forward)
@@ -59,8 +60,8 @@ struct RenderFwdParams {
 // SIMD gets nearly the same total.
 // WPB = waves per workgroup: 16 (one workgroup per CU) unless the LDS slices do not fit, then 4
 // workgroups of 4 waves stand in for it (same bins, placement then up to the dispatcher).
-template <int NCHP, int UNR, int WPB>
-__global__ void __launch_bounds__(LSR_WAVE * WPB)
+template <int NCHP, int UNR, int WPB, int MINB = 1>
+__global__ void __launch_bounds__(LSR_WAVE * WPB, MINB)
 k_render_fwd(RenderFwdParams p) {
     constexpr int PXL = 4;
     // Staged entries, one record per list entry: (x, y, a2, c2) (b2, log2 o, z, -1) payload...
@@ -100,7 +101,7 @@ k_render_fwd(RenderFwdParams p) {
     const int gsb = 4 * grow + gcol;   // + 8*(k>>1) + 2*(k&1) = this group's sub-block in round k
     const int lx = lane & 3, ly = (lane >> 2) & 3;
 
-    const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = simd_bins * 4u;
+    const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = (uint32_t)p.num_cus * (uint32_t)p.waves_per_cu;
     const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);   // 0..15
     const uint32_t bin = (blockIdx.x % (uint32_t)p.num_cus) * 4u + (vwave & 3u);
     // First item of every wave: static, folded (boustrophedon) over the cost-sorted list, so the 4
@@ -355,8 +356,16 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     }
 #endif
     prof_begin(kStRenderFwd, s);
-#define LSR_RF(N, U, WPB) hipLaunchKernelGGL((k_render_fwd<N, U, WPB>), dim3(p.num_cus * (16 / WPB)), dim3(LSR_WAVE * WPB), 0, s, p)
-    if (nchp == 4) LSR_RF(4, 2, 16);
+#define LSR_RF(N, U, WPB) hipLaunchKernelGGL((k_render_fwd<N, U, WPB>), dim3(p.num_cus * ((WPB) >= 12 ? 1 : 16 / (WPB))), dim3(LSR_WAVE * WPB), 0, s, p)
+    p.waves_per_cu = 16;
+    const int wps = env_int("LSR_FWD_WPS", 4);
+    if (nchp == 4 && wps == 5) {
+        p.waves_per_cu = 20;
+        hipLaunchKernelGGL((k_render_fwd<4, 2, 4, 5>), dim3(p.num_cus * 5), dim3(LSR_WAVE * 4), 0, s, p);
+    } else if (nchp == 4 && wps == 6) {
+        p.waves_per_cu = 20;
+        hipLaunchKernelGGL((k_render_fwd<4, 1, 4, 5>), dim3(p.num_cus * 5), dim3(LSR_WAVE * 4), 0, s, p);
+    } else if (nchp == 4) LSR_RF(4, 2, 16);
     else if (nchp == 8) LSR_RF(8, 2, 16);
     else if (nchp == 12) LSR_RF(12, 1, 16);
     else LSR_RF(36, 1, 4);

@@ -141,7 +141,7 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, views, means3D, means2D, cov3D, opacities, shs, colors_precomp, features,
                 H: int, W: int, sh_degree: int, debug: bool, feat_sh_degree: int = -1,
-                shs_channel_major: bool = False):
+                shs_channel_major: bool = False, pair_capacity: int = 0, max_tile_hint: int = 0):
         lib = _lib.load()
         ctx.set_materialize_grads(False)  # unused outputs (mask / depth ...) arrive as None, not zeros
         dev = means3D.device
@@ -222,13 +222,22 @@ class _RasterizeViews(torch.autograd.Function):
             out_mask = torch.empty((V, H, W), **f32)
             out_depth = torch.empty((V, H, W), **f32)
             outs = Outputs(_ptr(out_color), _ptr(out_feat), _ptr(out_mask), _ptr(out_depth), _ptr(radii))
-            _lib.check(lib.lsr_forward_prepare(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii),
-                                               C.byref(npairs), C.byref(maxtile), stream),
-                       "lsr_forward_prepare")
-            binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), npairs.value, maxtile.value), **u8)
-            _lib.check(lib.lsr_forward_render(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img),
-                                              npairs.value, maxtile.value, C.byref(outs), stream),
-                       "lsr_forward_render")
+            if pair_capacity > 0:
+                # latency mode: no host synchronisation; the pair count stays on the device
+                # (last_forward_status() reads it back when the caller wants to check for overflow)
+                npairs.value, maxtile.value = int(pair_capacity), int(max_tile_hint)
+                binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), npairs.value, 2 ** 31 - 1), **u8)
+                _lib.check(lib.lsr_forward_nosync(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img),
+                                                  npairs.value, maxtile.value, C.byref(outs), stream),
+                           "lsr_forward_nosync")
+            else:
+                _lib.check(lib.lsr_forward_prepare(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii),
+                                                   C.byref(npairs), C.byref(maxtile), stream),
+                           "lsr_forward_prepare")
+                binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), npairs.value, maxtile.value), **u8)
+                _lib.check(lib.lsr_forward_render(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img),
+                                                  npairs.value, maxtile.value, C.byref(outs), stream),
+                           "lsr_forward_render")
             if debug:
                 torch.cuda.synchronize(dev)
         plan = _Plan()
@@ -236,7 +245,10 @@ class _RasterizeViews(torch.autograd.Function):
         plan.num_pairs, plan.radii = npairs.value, radii
         plan.V, plan.G, plan.H, plan.W, plan.C, plan.color_mode, plan.K = V, G, H, W, Cf, color_mode, K
         ctx.plan = plan
-        LAST_STATS.update(num_pairs=npairs.value, max_tile_pairs=maxtile.value, views=V, gaussians=G)
+        LAST_STATS.update(num_pairs=None if pair_capacity > 0 else npairs.value, max_tile_pairs=maxtile.value, views=V,
+                          gaussians=G, pair_capacity=int(pair_capacity))
+        global _LAST_PLAN
+        _LAST_PLAN = plan
         ctx.debug = debug
         ctx.m2d_shape = None if means2D is None else tuple(means2D.shape)
         ctx.has = (shs is not None, colors_precomp is not None, features is not None)
@@ -296,14 +308,15 @@ class _RasterizeViews(torch.autograd.Function):
         # order: views, means3D, means2D, cov3D, opacities, shs, colors_precomp, features, H, W, deg,
         #        debug, feat_sh_degree, shs_channel_major
         return (None, d_means, d_m2d, d_cov, d_opac, d_color if has_shs else None,
-                d_color if has_cp else None, d_feat, None, None, None, None, None, None)
+                d_color if has_cp else None, d_feat, None, None, None, None, None, None, None, None)
 
 
 def rasterize_views(views: Tensor, image_height: int, image_width: int, sh_degree: int, means3D: Tensor,
                     cov3D_precomp: Tensor, opacities: Tensor, shs: Optional[Tensor] = None,
                     colors_precomp: Optional[Tensor] = None, features: Optional[Tensor] = None,
                     means2D: Optional[Tensor] = None, debug: bool = False,
-                    feature_sh: Optional[Tensor] = None, shs_channel_major: bool = False):
+                    feature_sh: Optional[Tensor] = None, shs_channel_major: bool = False,
+                    pair_capacity: Optional[int] = None, max_tile_hint: int = 4096):
     """Render V views in one call.  ``views`` is the (V,44) table of :func:`make_view_table`; every
     per-Gaussian tensor is either shared ``(G,...)`` or per view ``(V,G,...)``.
     Returns ``(color (V,3,H,W)|None, feature (V,C,H,W)|None, mask (V,H,W), depth (V,H,W), radii (V,G))``.
@@ -313,7 +326,14 @@ def rasterize_views(views: Tensor, image_height: int, image_width: int, sh_degre
     ``feature_sh (..., C, Kf)`` (instead of ``features``) makes the kernel evaluate the latent
     features ``0.5 + eval_sh(dir)`` itself (degree <= 2, C*Kf <= 120); ``shs`` may be passed in
     the stored ``(...,3,K)`` layout with ``shs_channel_major=True``; the per-view scene scale
-    lives in the view table."""
+    lives in the view table.
+
+    Latency mode: with ``pair_capacity`` (number of (Gaussian, tile) pairs the binning workspace
+    is sized for, e.g. 1.5 x the count of an earlier frame from :func:`last_forward_status`) the
+    forward never waits for the device (``lsr_forward_nosync``) and can be captured in a
+    ``torch.cuda.graph``.  A scene that needs more pairs renders truncated lists and raises the
+    overflow flag reported by :func:`last_forward_status` — check it at a synchronisation point of
+    your choice."""
     V = views.shape[0]
     feat_sh_degree = -1
     if feature_sh is not None:
@@ -325,8 +345,27 @@ def rasterize_views(views: Tensor, image_height: int, image_width: int, sh_degre
     color, feat, mask, depth, radii = _RasterizeViews.apply(
         views, means3D, means2D, cov3D_precomp, opacities, shs, colors_precomp, features,
         int(image_height), int(image_width), int(sh_degree), bool(debug), int(feat_sh_degree),
-        bool(shs_channel_major))
+        bool(shs_channel_major), int(pair_capacity or 0), int(max_tile_hint))
     return (color if color.numel() else None, feat if feat.numel() else None, mask, depth, radii)
+
+
+_LAST_PLAN = None
+
+
+def last_forward_status() -> dict:
+    """``{num_pairs, max_tile_pairs, overflow}`` of the most recent forward of this process, read back
+    from its geometry workspace (synchronises the current stream).  After a graph replay it reports
+    the replayed forward (the workspace addresses are static)."""
+    if _LAST_PLAN is None:
+        raise LsrError("no forward has run yet")
+    lib = _lib.load()
+    plan = _LAST_PLAN
+    dev = plan.geom.device
+    n, mt, ov = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+    with torch.cuda.device(dev):
+        _lib.check(lib.lsr_forward_status(C.byref(plan.dims), _ptr(plan.geom), C.byref(n), C.byref(mt), C.byref(ov),
+                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "lsr_forward_status")
+    return dict(num_pairs=n.value, max_tile_pairs=mt.value, overflow=bool(ov.value))
 
 
 def fused_feature_sh_supported(feature_sh: Optional[Tensor]) -> bool:

@@ -31,7 +31,7 @@ def _worker(rank, world, port, out):
     el = bench.timed_region(step, steps=5, warmup=2, dist=dist)
     seeds = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(seeds, torch.tensor([bench.rank_seed(1234, rank)]))
-    out.put((rank, el, len(calls), [int(s) for s in seeds]))
+    out.put((rank, el, len(calls), [int(s) for s in seeds], list(bench.PER_RANK_SECONDS)))
     dist.destroy_process_group()
 
 
@@ -47,7 +47,8 @@ def test_two_rank_timing_and_aggregation():
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    (r0, el0, n0, seeds0), (r1, el1, n1, seeds1) = res
+    (r0, el0, n0, seeds0, pr0), (r1, el1, n1, seeds1, pr1) = res
+    assert pr0 == pr1 and len(pr0) == 2 and max(pr0) == el0 and pr0[1] > 2 * pr0[0]   # every rank's own time is reported too
     assert n0 == n1 == 7                      # 2 warm-up + exactly 5 timed steps on every rank
     assert el0 == el1                         # MAX over ranks is what every rank reports
     assert el0 >= 5 * 0.03 * 0.9              # ... and it is the slow rank's time

@@ -1,0 +1,107 @@
+"""Latency mode (lsr_forward_nosync): the forward without the host read-back of the pair count
+(upstream's blocking `num_rendered` copy), its overflow behaviour,
+the backward on top of it, and hipGraph capture / replay through torch.cuda.graph."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(dev, G=20000, V=2, size=128, seed=7, sh=2):
+    sc = util.make_scene(G, image_size=size, views=V, color_sh_degree=sh, feature_channels=4, feature_sh_degree=0, seed=seed)
+    bi = util.boundary_inputs(sc, size, size, bg=(0.1, 0.2, 0.3))
+    t = {k: bi[k].to(dev) for k in ("means", "cov6", "opac", "shs", "features")}
+    return bi, util.view_table(bi, dev), t, size
+
+
+def _render(views, t, size, deg, **kw):
+    from latentsplat_amd.rasterizer import rasterize_views
+    return rasterize_views(views, size, size, deg, t["means"], t["cov6"], t["opac"], shs=t["shs"], features=t["features"], **kw)
+
+
+def test_nosync_forward_equals_synchronous_forward(hip_device):
+    from latentsplat_amd.rasterizer import last_forward_status
+    bi, views, t, size = _inputs(hip_device)
+    ref = _render(views, t, size, 2)
+    st = last_forward_status()
+    assert st["num_pairs"] > 20000 and not st["overflow"]
+    for hint in (64, st["max_tile_pairs"], 16384):        # the hint only picks the sort variant
+        out = _render(views, t, size, 2, pair_capacity=int(1.5 * st["num_pairs"]), max_tile_hint=hint)
+        st2 = last_forward_status()
+        assert st2 == st
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+
+
+def test_nosync_overflow_is_flagged_and_harmless(hip_device):
+    from latentsplat_amd.rasterizer import last_forward_status
+    bi, views, t, size = _inputs(hip_device)
+    ref = _render(views, t, size, 2)
+    P = last_forward_status()["num_pairs"]
+    out = _render(views, t, size, 2, pair_capacity=P // 2, max_tile_hint=1024)
+    st = last_forward_status()
+    assert st["overflow"] and st["num_pairs"] == P           # the true count is still reported
+    assert all(torch.isfinite(x).all() for x in out[:4])
+    assert not torch.equal(out[2], ref[2])                   # truncated lists: the result is NOT to be used
+    again = _render(views, t, size, 2, pair_capacity=P + 1, max_tile_hint=1024)     # exactly enough room
+    assert not last_forward_status()["overflow"] and torch.equal(again[0], ref[0])
+
+
+def test_backward_after_nosync_forward(hip_device):
+    from latentsplat_amd.rasterizer import last_forward_status
+    bi, views, t, size = _inputs(hip_device, G=8000, size=64)
+    g = torch.randn((2, 3, size, size), generator=torch.Generator().manual_seed(2)).to(hip_device)
+
+    def grads(**kw):
+        leaf = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+        out = _render(views, leaf, size, 2, **kw)
+        ((out[0] * g).sum() + (out[1] ** 2).sum()).backward()
+        return {k: v.grad for k, v in leaf.items()}
+
+    ref = grads()
+    P = last_forward_status()["num_pairs"]
+    got = grads(pair_capacity=2 * P, max_tile_hint=512)
+    for k in ref:
+        scale = max(1.0, float(ref[k].abs().max()))
+        assert float((got[k] - ref[k]).abs().max()) <= 1e-5 * scale, k        # atomic-add ordering only
+
+
+def test_graph_capture_and_replay(hip_device):
+    """The no-sync forward is a pure launch sequence: captured once, replayed with new scene contents
+    in the static input tensors, equal to the eager result."""
+    from latentsplat_amd.rasterizer import last_forward_status
+    dev = hip_device
+    bi, views, t, size = _inputs(dev, G=30000, V=1, size=128, seed=11)
+    _render(views, t, size, 2)
+    P = last_forward_status()["num_pairs"]
+    static = {k: v.clone() for k, v in t.items()}
+    kw = dict(pair_capacity=2 * P, max_tile_hint=2048)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            _render(views, static, size, 2, **kw)           # warm-up on the capture stream
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = _render(views, static, size, 2, **kw)
+    graph.replay()
+    torch.cuda.synchronize(dev)
+    eager = _render(views, t, size, 2)
+    for a, b in zip(out, eager):
+        assert torch.equal(a, b)
+    # new scene contents, same shapes: refill the static tensors and replay
+    bi2, views2, t2, _ = _inputs(dev, G=30000, V=1, size=128, seed=12)
+    for k in static:
+        static[k].copy_(t2[k])
+    graph.replay()
+    torch.cuda.synchronize(dev)
+    assert not last_forward_status()["overflow"]
+    eager2 = _render(views, t2, size, 2)                     # same cameras (the view table was captured by address)
+    for a, b in zip(out, eager2):
+        assert torch.equal(a, b)
+    o = util.oracle_forward(bi2, 0)
+    util.assert_close_except_fragile(out[0][0].cpu().numpy(), o["color"], o, 1e-4, "graph replay colour")
