@@ -445,6 +445,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bwd", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the V=1 / V=4 latency section (profiling runs: keeps one launch shape per kernel)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -601,7 +602,7 @@ def main():
         cpu = cpu_baseline(G, S, 1234)
         cpu["torch_oracle"] = cpu_baseline_torch()
     latency = None
-    if rank == 0 and world == 1 and not args.no_bwd:
+    if rank == 0 and world == 1 and not args.no_bwd and not args.no_latency:
         latency = latency_timing(dev, G, S, 1234)
     dec_step = adapter_step = latent_step = None
     if rank == 0 and world == 1 and not args.no_bwd:

@@ -65,6 +65,8 @@ int lsr::device_cus() {
     return n;
 }
 
+bool lsr::deterministic_backward() { return env_int("LSR_DETERMINISTIC", 0) != 0; }
+
 // Development knobs (LSR_SPLIT, LSR_LIMIT, LSR_PXL_BWD, ...): read from the environment once per
 // process and knob, then served from a table — no getenv on the launch path.
 int lsr::env_int(const char *name, int fallback) {

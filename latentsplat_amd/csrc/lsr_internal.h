@@ -34,7 +34,7 @@ struct BinLayout {
 // are constant over a Gaussian's pixels.)  16 floats (one 64-byte line) for <= 8 payload
 // channels, 32 for <= 12, 64 beyond.
 struct GradLayout {
-    size_t rec, total;
+    size_t rec, fixed, total;
     int rec_floats;
 };
 inline int grad_rec_floats(const lsr_dims &d);
@@ -96,12 +96,18 @@ inline BinLayout bin_layout(const lsr_dims &d, int64_t num_pairs, int32_t max_ti
     return L;
 }
 inline int grad_rec_floats(const lsr_dims &d) { return rec_floats(d); }
+// LSR_DETERMINISTIC=1 (debugging aid, read once per process): the compositing backward's cross-tile
+// sums go through 64-bit FIXED-POINT integer atomics (order independent => bitwise reproducible
+// gradients) in a second record array behind the float records, converted back by one extra kernel.
+bool deterministic_backward();
+constexpr double kFixedPointScale = 1073741824.0;   // 2^30: 9.3e-10 resolution, +-8.6e9 range per record slot
 inline GradLayout grad_layout(const lsr_dims &d) {
     GradLayout L;
     const size_t VG = (size_t)d.num_views * (size_t)d.num_gaussians;
     L.rec_floats = grad_rec_floats(d);
     L.rec = 0;
-    L.total = align_up(VG * (size_t)L.rec_floats * 4 + 256);
+    L.fixed = align_up(VG * (size_t)L.rec_floats * 4 + 256);   // [V*G][rec_floats] int64, deterministic mode only
+    L.total = L.fixed + (deterministic_backward() ? align_up(VG * (size_t)L.rec_floats * 8) : 0);
     return L;
 }
 

@@ -35,14 +35,8 @@ namespace lsr {
 __device__ __forceinline__ void wave_lds_fence_bwd() {
     // compiler-only barrier: the LDS slice is private to the wave and its LDS operations execute in
     // order (a memory fence would also drain the prefetching global loads and the flush atomics)
-#ifdef LSR_X_FENCE
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#else
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-#endif
 }
 
 typedef float float2_b __attribute__((ext_vector_type(2)));
@@ -63,6 +57,7 @@ struct RenderBwdParams {
     const float *g_color, *g_feat, *g_mask, *g_depth;  // dL/d outputs (any may be NULL)
     const float *f_color, *f_feat, *f_depth;           // images rendered by the matching forward
     float *rec;         // [V*G][rec_floats] packed gradient records (zeroed by the caller)
+    long long *rec_fixed;   // deterministic mode: the same records as 2^30 fixed point (zeroed by the caller), else NULL
     int rec_floats;
 };
 
@@ -226,7 +221,7 @@ __device__ __forceinline__ void atomic_add_f32(float *addr, float v) { unsafeAto
 
 // WPS = resident waves per SIMD (workgroup = 4*WPS waves = one compute unit's worth): 4 where the
 // per-wave LDS slice allows it, 3 for the 8-channel payload, 1 for the widest.
-template <int NCHP, bool DEPTH_GRAD, int WPS, int MODE>
+template <int NCHP, bool DEPTH_GRAD, int WPS>
 __global__ void __launch_bounds__(LSR_WAVE * 4 * WPS)
 k_render_bwd(RenderBwdParams p) {
     constexpr int PXL = 4;
@@ -364,13 +359,9 @@ k_render_bwd(RenderBwdParams p) {
         g_ahead = load_idx(LSR_WAVE + lane);
 
         for (uint32_t cbase = 0; cbase < maxlast; cbase += LSR_WAVE) {
-#ifdef LSR_X_NOPIPE
-            const StageRec cur = load_rec(cbase + lane, load_idx(cbase + lane));
-#else
             const StageRec cur = nxt;
             nxt = load_rec(cbase + LSR_WAVE + lane, g_ahead);
             g_ahead = load_idx(cbase + 2 * LSR_WAVE + lane);
-#endif
             // ---- stage up to 64 list entries (one per lane) ----
             {   // every list slot starts as the null record's slot
                 const uint32_t n2 = (uint32_t)LSR_WAVE | ((uint32_t)LSR_WAVE << 16);
@@ -449,10 +440,6 @@ k_render_bwd(RenderBwdParams p) {
                     // row; rank r > 0 re-reads the row after rank r-1 has written (a wave's LDS operations
                     // execute in order).
                     auto accumulate = [&](float *dst, float old, float tot, bool live) {
-#ifdef LSR_X_RACY
-                        if (live) *dst = old + tot;
-                        return;
-#endif
                         if (live && rank == 0u) *dst = old + tot;
                         uint64_t later = __ballot(rank != 0u);
                         for (uint32_t r = 1; later; ++r) {      // wave-uniform, usually no or one round
@@ -521,9 +508,7 @@ k_render_bwd(RenderBwdParams p) {
                         // plain read-modify-write: only this wave touches its table and a wave's LDS operations
                         // execute in order (measured: ds_add_f32 costs ~120 LDS cycles per wave instruction; with
                         // it on every iteration the kernel was LDS bound at 1.44 ms)
-                        if (MODE == 2) {
-                            if ((LIVE >> l16 & 1u) && slot != LSR_WAVE) atomic_add_f32(p.rec + (vG + s_gid[slot]) * (size_t)RF + l16, tot);
-                        } else accumulate(row, acc_old[0], tot, LIVE >> l16 & 1u);
+                        accumulate(row, acc_old[0], tot, LIVE >> l16 & 1u);
                     }
 #pragma unroll
                     for (int gi = 1; gi < NGRP; ++gi) {   // payload channels 16 gi - 8 .. 16 gi + 7
@@ -531,16 +516,14 @@ k_render_bwd(RenderBwdParams p) {
                         const float tot = row_reduce16_transposed<0xFFFFu>(GPC(0), GPC(1), GPC(2), GPC(3), GPC(4), GPC(5), GPC(6), GPC(7),
                                                                             GPC(8), GPC(9), GPC(10), GPC(11), GPC(12), GPC(13), GPC(14), GPC(15), l16);
 #undef GPC
-                        if (MODE == 2) {
-                            if (slot != LSR_WAVE) atomic_add_f32(p.rec + (vG + s_gid[slot]) * (size_t)RF + 16 * gi + l16, tot);
-                        } else accumulate(row + 16 * gi, acc_old[gi], tot, true);
+                        accumulate(row + 16 * gi, acc_old[gi], tot, true);
                     }
                 }
             }
             wave_lds_fence_bwd();
             // ---- flush: one global record-add per staged entry that reached an owned sub-block ----
 #pragma unroll 1
-            for (int e0 = 0; MODE != 2 && e0 < LSR_WAVE; e0 += 4) {
+            for (int e0 = 0; e0 < LSR_WAVE; e0 += 4) {
                 if (!((staged >> e0) & 0xFull)) continue;   // wave-uniform
                 const int e = e0 + grp;
                 const bool hit = (staged >> e) & 1ull;
@@ -549,7 +532,12 @@ k_render_bwd(RenderBwdParams p) {
                 for (int gi = 0; gi < NGRP; ++gi) {
                     const float val = s_acc[e][16 * gi + l16];
                     s_acc[e][16 * gi + l16] = 0.0f;
-                    if (hit && val != 0.0f) atomic_add_f32(p.rec + (vG + g) * (size_t)RF + 16 * gi + l16, val);
+                    if (hit && val != 0.0f) {
+                        const size_t at = (vG + g) * (size_t)RF + 16 * gi + l16;
+                        if (p.rec_fixed)   // order-independent integer sum (LSR_DETERMINISTIC)
+                            atomicAdd((unsigned long long *)p.rec_fixed + at, (unsigned long long)__double2ll_rn((double)val * kFixedPointScale));
+                        else atomic_add_f32(p.rec + at, val);
+                    }
                 }
             }
             wave_lds_fence_bwd();
@@ -557,11 +545,14 @@ k_render_bwd(RenderBwdParams p) {
     }  // item loop
 }
 
+__global__ void __launch_bounds__(256) k_fixed_to_float(const long long *__restrict__ in, float *__restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = (float)((double)in[i] * (1.0 / kFixedPointScale));
+}
+
 template <int NCHP, bool DG, int WPS>
 static void launch_variant(const RenderBwdParams &p, hipStream_t s) {
-    const int mode = env_int("LSR_BWD_MODE", 0);   // development knob (A/B of the accumulate step), latched once
-    if (mode == 2) hipLaunchKernelGGL((k_render_bwd<NCHP, DG, WPS, 2>), dim3(p.num_cus), dim3(LSR_WAVE * 4 * WPS), 0, s, p);
-    else hipLaunchKernelGGL((k_render_bwd<NCHP, DG, WPS, 0>), dim3(p.num_cus), dim3(LSR_WAVE * 4 * WPS), 0, s, p);
+    hipLaunchKernelGGL((k_render_bwd<NCHP, DG, WPS>), dim3(p.num_cus), dim3(LSR_WAVE * 4 * WPS), 0, s, p);
 }
 
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
@@ -586,7 +577,9 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     p.g_color = gout.color; p.g_feat = gout.feature; p.g_mask = gout.mask; p.g_depth = gout.depth;
     p.f_color = fwd.color; p.f_feat = fwd.feature; p.f_depth = fwd.depth;
     p.rec = (float *)(grad + R.rec); p.rec_floats = R.rec_floats;
-    p.queue = (uint32_t *)(grad + R.total - 256);   // inside the zeroed tail of the gradient workspace
+    const bool det = deterministic_backward();
+    p.rec_fixed = det ? (long long *)(grad + R.fixed) : nullptr;
+    p.queue = (uint32_t *)(grad + R.fixed - 256);   // the zeroed slack behind the float records
     (void)gin;
     const int nch = (p.has_color ? 3 : 0) + d.feat_channels;
     const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));
@@ -602,6 +595,12 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     else if (nchp == 12) LSR_RB(12, 2);
     else LSR_RB(36, 1);
 #undef LSR_RB
+    if (det) {   // fixed-point sums -> the float records the next stages read
+        const size_t n = (size_t)d.num_views * (size_t)d.num_gaussians * (size_t)R.rec_floats;
+        const size_t blocks = (n + 255) / 256;
+        hipLaunchKernelGGL(k_fixed_to_float, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s,
+                           (const long long *)(grad + R.fixed), p.rec, n);
+    }
     prof_end(kStRenderBwd, s);
     return hipGetLastError();
 }

@@ -60,8 +60,8 @@ struct RenderFwdParams {
 // SIMD gets nearly the same total.
 // WPB = waves per workgroup: 16 (one workgroup per CU) unless the LDS slices do not fit, then 4
 // workgroups of 4 waves stand in for it (same bins, placement then up to the dispatcher).
-template <int NCHP, int UNR, int WPB, int MINB = 1>
-__global__ void __launch_bounds__(LSR_WAVE * WPB, MINB)
+template <int NCHP, int UNR, int WPB>
+__global__ void __launch_bounds__(LSR_WAVE * WPB)
 k_render_fwd(RenderFwdParams p) {
     constexpr int PXL = 4;
     // Staged entries, one record per list entry: (x, y, a2, c2) (b2, log2 o, z, -1) payload...
@@ -358,14 +358,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     prof_begin(kStRenderFwd, s);
 #define LSR_RF(N, U, WPB) hipLaunchKernelGGL((k_render_fwd<N, U, WPB>), dim3(p.num_cus * ((WPB) >= 12 ? 1 : 16 / (WPB))), dim3(LSR_WAVE * WPB), 0, s, p)
     p.waves_per_cu = 16;
-    const int wps = env_int("LSR_FWD_WPS", 4);
-    if (nchp == 4 && wps == 5) {
-        p.waves_per_cu = 20;
-        hipLaunchKernelGGL((k_render_fwd<4, 2, 4, 5>), dim3(p.num_cus * 5), dim3(LSR_WAVE * 4), 0, s, p);
-    } else if (nchp == 4 && wps == 6) {
-        p.waves_per_cu = 20;
-        hipLaunchKernelGGL((k_render_fwd<4, 1, 4, 5>), dim3(p.num_cus * 5), dim3(LSR_WAVE * 4), 0, s, p);
-    } else if (nchp == 4) LSR_RF(4, 2, 16);
+    if (nchp == 4) LSR_RF(4, 2, 16);
     else if (nchp == 8) LSR_RF(8, 2, 16);
     else if (nchp == 12) LSR_RF(12, 1, 16);
     else LSR_RF(36, 1, 4);

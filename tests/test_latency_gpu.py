@@ -105,3 +105,38 @@ def test_graph_capture_and_replay(hip_device):
         assert torch.equal(a, b)
     o = util.oracle_forward(bi2, 0)
     util.assert_close_except_fragile(out[0][0].cpu().numpy(), o["color"], o, 1e-4, "graph replay colour")
+
+
+def test_deterministic_backward_mode(hip_device):
+    """LSR_DETERMINISTIC=1 (read once per process, hence a subprocess): the cross-tile gradient sums use
+    64-bit fixed-point atomics, so two runs give bitwise identical gradients, which agree with the
+    default (float atomic) mode to the fixed-point resolution."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch, hashlib
+sys.path.insert(0, %r)
+from tests.test_latency_gpu import _inputs, _render
+dev = torch.device("cuda:0")
+bi, views, t, size = _inputs(dev, G=8000, size=64)
+g = torch.randn((2, 3, size, size), generator=torch.Generator().manual_seed(2)).to(dev)
+def grads():
+    leaf = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+    out = _render(views, leaf, size, 2)
+    ((out[0] * g).sum() + (out[1] ** 2).sum()).backward()
+    return torch.cat([v.grad.reshape(-1) for v in leaf.values()])
+a, b = grads(), grads()
+print("EQUAL", bool(torch.equal(a, b)), hashlib.sha1(a.cpu().numpy().tobytes()).hexdigest(), float(a.abs().max()))
+torch.save(a.cpu(), sys.argv[1])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for det in ("1", "0"):
+        path = f"/tmp/lsr_det_{det}.pt"
+        env = dict(os.environ, LSR_DETERMINISTIC=det)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[det] = (r.stdout.strip().splitlines()[-1], torch.load(path))
+    assert outs["1"][0].startswith("EQUAL True"), outs["1"][0]          # bitwise reproducible
+    a, b = outs["1"][1], outs["0"][1]
+    assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))

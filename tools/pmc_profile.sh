@@ -5,7 +5,7 @@
 # usage: tools/pmc_profile.sh <tag> [bench args...]      (PMC_CMD="python tools/bench_decoder.py" profiles another workload)
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline --no-latency}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
