@@ -180,6 +180,14 @@ int lsr_build_views(int32_t num_views, const float *extrinsics, const float *int
                     const float *far, const float *bg, int32_t bg_view_stride, int32_t scale_invariant,
                     float *views_out, lsr_stream_t stream);
 
+/* ---- one view record straight from the 12-field `GaussianRasterizationSettings` of the reference's
+ * per-view call (cuda_splatting.py:132-145): device pointers to `viewmatrix` [16], `projmatrix` [16],
+ * `campos` [3], `bg` [3]; tan(fov) by value, or as device scalars when the caller holds tensors (the
+ * orthographic path, :260-261 — no host read-back then).  Scene scale 1.  Async, one tiny launch. */
+int lsr_pack_view(const float *viewmatrix, const float *projmatrix, const float *campos, const float *bg,
+                  float tanfovx, float tanfovy, const float *tanfovx_dev, const float *tanfovy_dev,
+                  float *view_out, lsr_stream_t stream);
+
 /* ---- forward, phase 1: per-Gaussian preprocess + per-tile counting + tile offset scan.
  * Writes radii.  Synchronises `stream` once to return the pair count and the longest tile list
  * through the two host pointers (both required). */

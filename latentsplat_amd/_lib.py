@@ -116,7 +116,7 @@ PLY_VERTEX_FLOATS = 17
 EXPORTS = (
     "lsr_abi_version", "lsr_error_string", "lsr_last_hip_error", "lsr_geom_workspace_bytes",
     "lsr_image_workspace_bytes", "lsr_binning_workspace_bytes", "lsr_grad_workspace_bytes",
-    "lsr_get_layout", "lsr_build_views", "lsr_forward_prepare", "lsr_forward_render", "lsr_forward_nosync",
+    "lsr_get_layout", "lsr_build_views", "lsr_pack_view", "lsr_forward_prepare", "lsr_forward_render", "lsr_forward_nosync",
     "lsr_forward_status", "lsr_backward",
     "lsr_profile_enable", "lsr_profile_num_stages", "lsr_profile_stage_name", "lsr_profile_read",
     "lsr_adapter_forward", "lsr_adapter_backward", "lsr_latent_forward", "lsr_latent_backward",
@@ -167,6 +167,8 @@ def load():
     lib.lsr_get_layout.argtypes = [C.POINTER(Dims), I64, C.POINTER(Layout)]
     lib.lsr_build_views.restype = C.c_int
     lib.lsr_build_views.argtypes = [I32, P, P, P, P, P, I32, I32, P, P]
+    lib.lsr_pack_view.restype = C.c_int
+    lib.lsr_pack_view.argtypes = [P, P, P, P, C.c_float, C.c_float, P, P, P, P]
     lib.lsr_forward_prepare.restype = C.c_int
     lib.lsr_forward_prepare.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, C.POINTER(I64),
                                         C.POINTER(I32), P]

@@ -272,6 +272,16 @@ int lsr_build_views(int32_t num_views, const float *extrinsics, const float *int
     return LSR_OK;
 }
 
+int lsr_pack_view(const float *viewmatrix, const float *projmatrix, const float *campos, const float *bg,
+                  float tanfovx, float tanfovy, const float *tanfovx_dev, const float *tanfovy_dev, float *view_out,
+                  lsr_stream_t stream) {
+    g_last_hip_error = 0;
+    if (!viewmatrix || !projmatrix || !campos || !bg || !view_out) return LSR_ENULL;
+    LSR_HIP(launch_pack_view(viewmatrix, projmatrix, campos, bg, tanfovx, tanfovy, tanfovx_dev, tanfovy_dev, view_out,
+                             (hipStream_t)stream));
+    return LSR_OK;
+}
+
 int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii,
                         int64_t *num_pairs_host, int32_t *max_tile_pairs_host, lsr_stream_t stream) {
     g_last_hip_error = 0;

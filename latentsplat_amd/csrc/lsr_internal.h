@@ -149,6 +149,9 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
                              hipStream_t s);
 // pair_capacity: pairs the binning workspace can hold (UINT32_MAX = exact sizing after a host read-back)
 hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror, uint32_t pair_capacity, hipStream_t s);
+hipError_t launch_pack_view(const float *viewmatrix, const float *projmatrix, const float *campos, const float *bg,
+                            float tanfovx, float tanfovy, const float *tanfovx_dev, const float *tanfovy_dev, float *out,
+                            hipStream_t s);
 hipError_t launch_build_views(int V, const float *extrinsics, const float *intrinsics, const float *near,
                               const float *far, const float *bg, int bg_stride, int scale_invariant,
                               float *out, hipStream_t s);

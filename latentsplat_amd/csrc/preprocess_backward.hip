@@ -36,7 +36,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 
 template <int PARTS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k_preprocess_bwd(PreBwdParams p) {
     const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int part = gt % PARTS;
@@ -54,9 +54,10 @@ k_preprocess_bwd(PreBwdParams p) {
     const bool feat_direct = d.feat_channels > 0 && d.feat_mode == LSR_FEAT_DIRECT;
     const bool feat_reg = feat_direct && d.vs_feat == 0 && d.feat_channels <= kPreBwdFeat;
     const bool feat_rmw = feat_direct && d.vs_feat == 0 && !feat_reg;   // many shared channels: one lane, memory accumulate
-    // The record (one 64-byte line) and the radius of the NEXT view of this lane are loaded before
-    // the current view is processed: the per-view stores below keep the compiler from hoisting
-    // loads across iterations on its own, and the loop is bound by memory latency.
+    // Occupancy, not prefetching, hides the memory latency here: holding the NEXT view's record in
+    // registers (round 1) cost 175 VGPRs = 2 waves per SIMD; without it the kernel fits 127 VGPRs =
+    // 4 waves per SIMD (launch bounds) and runs 0.155 -> 0.137 ms per 16 views (forcing 128 VGPRs WITH
+    // the prefetch spills 43 registers: 0.23 ms).
     struct ViewRec { float4 r0, r1, q0, q1; int radius; };
     const bool pay16 = feat_reg && p.rec_floats == 16;
     auto load_view = [&](int v) {
@@ -70,11 +71,8 @@ k_preprocess_bwd(PreBwdParams p) {
         return r;
     };
     const int v_first = feat_rmw ? 0 : part, v_step = feat_rmw ? 1 : PARTS, v_end = (live && !(feat_rmw && part != 0)) ? V : 0;
-    ViewRec nxt;
-    if (v_first < v_end) nxt = load_view(v_first);
     for (int v = v_first; v < v_end; v += v_step) {
-        const ViewRec cur = nxt;
-        if (v + v_step < v_end) nxt = load_view(v + v_step);
+        const ViewRec cur = load_view(v);
         const size_t o = (size_t)v * G + i;
         const float *rc = p.rec + o * p.rec_floats;
         const float4 r0 = cur.r0, r1 = cur.r1;

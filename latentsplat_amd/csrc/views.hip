@@ -93,4 +93,30 @@ hipError_t launch_build_views(int V, const float *extrinsics, const float *intri
     return hipGetLastError();
 }
 
+// One view record from the 12-field settings tuple of the reference API (the per-view call pattern of
+// cuda_splatting.py:132-158): a single 64-thread launch instead of ~8 small PyTorch ops per view.
+__global__ void __launch_bounds__(64)
+k_pack_view(const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, const float *__restrict__ campos,
+            const float *__restrict__ bg, float tanfovx, float tanfovy, const float *tanfovx_dev, const float *tanfovy_dev,
+            float *__restrict__ out) {
+    const int t = threadIdx.x;
+    float v = 0.0f;
+    if (t < 16) v = viewmatrix[t];
+    else if (t < 32) v = projmatrix[t - 16];
+    else if (t < 35) v = campos[t - 32];
+    else if (t == 35) v = tanfovx_dev ? tanfovx_dev[0] : tanfovx;
+    else if (t == 36) v = tanfovy_dev ? tanfovy_dev[0] : tanfovy;
+    else if (t < 40) v = bg[t - 37];
+    else if (t == 40) v = 1.0f;     // scene scale: the caller of this API has scaled the scene itself
+    if (t < LSR_VIEW_FLOATS) out[t] = v;
+}
+
+hipError_t launch_pack_view(const float *viewmatrix, const float *projmatrix, const float *campos, const float *bg,
+                            float tanfovx, float tanfovy, const float *tanfovx_dev, const float *tanfovy_dev, float *out,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_view, dim3(1), dim3(64), 0, s, viewmatrix, projmatrix, campos, bg, tanfovx, tanfovy,
+                       tanfovx_dev, tanfovy_dev, out);
+    return hipGetLastError();
+}
+
 }  // namespace lsr

@@ -389,6 +389,26 @@ def _covariance_from_scale_rotation(scales: Tensor, rotations: Tensor, modifier:
     return torch.stack([S[..., 0, 0], S[..., 0, 1], S[..., 0, 2], S[..., 1, 1], S[..., 1, 2], S[..., 2, 2]], -1)
 
 
+def _pack_view(rs: GaussianRasterizationSettings, dev) -> Tensor:
+    """(1,44) view record of one settings tuple: one small launch (lsr_pack_view) instead of ~8 PyTorch
+    ops; tan(fov) goes by value when it is a Python number and stays on the device when it is a tensor."""
+    if dev.type != "cuda":
+        raise LsrError("latentsplat_amd rasterizer runs on MI355X only: tensors must be on a ROCm ('cuda') device; "
+                       "there is no CPU fallback")
+    lib = _lib.load()
+    f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    vm, pm, cp, bg = f(rs.viewmatrix), f(rs.projmatrix), f(rs.campos), f(rs.bg)
+    tx, ty = rs.tanfovx, rs.tanfovy
+    txd = f(tx).reshape(-1) if torch.is_tensor(tx) else None
+    tyd = f(ty).reshape(-1) if torch.is_tensor(ty) else None
+    out = torch.empty((1, _lib.VIEW_FLOATS), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.lsr_pack_view(_ptr(vm), _ptr(pm), _ptr(cp), _ptr(bg), 0.0 if txd is not None else float(tx),
+                                     0.0 if tyd is not None else float(ty), _ptr(txd), _ptr(tyd), _ptr(out),
+                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "lsr_pack_view")
+    return out
+
+
 class GaussianRasterizer(nn.Module):
     """Drop-in for ``diff_gaussian_rasterization.GaussianRasterizer`` (one view per call)."""
 
@@ -406,8 +426,7 @@ class GaussianRasterizer(nn.Module):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         if cov3D_precomp is None:
             cov3D_precomp = _covariance_from_scale_rotation(scales, rotations, float(rs.scale_modifier))
-        views = make_view_table(rs.viewmatrix[None], rs.projmatrix[None], rs.campos[None],
-                                rs.tanfovx, rs.tanfovy, rs.bg[None])
+        views = _pack_view(rs, means3D.device)
         color, feat, mask, depth, radii = _RasterizeViews.apply(
             views, means3D, means2D, cov3D_precomp, opacities, shs, colors_precomp, features,
             int(rs.image_height), int(rs.image_width), int(rs.sh_degree), bool(rs.debug), -1, False)

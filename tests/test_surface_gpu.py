@@ -43,9 +43,13 @@ def test_decoder_matches_reference_wrapper_outputs(hip_device, name, fkw, variat
     else:
         assert out.color is None
     np.testing.assert_allclose(out.feature_posterior.mean.cpu().numpy(), want["posterior_mean"], atol=1e-4, rtol=0)
+    # logvar = log(1 - mask) (or the rendered logvar half): compared where it is well conditioned through
+    # what it encodes — exp(logvar) = 1 - mask must agree to the same 1e-4 as the mask itself, everywhere
+    # (saturated pixels included: exp maps the clamp floor -30 to 0) — and directly away from saturation.
     lv, lw = out.feature_posterior.logvar.cpu().numpy(), want["posterior_logvar"]
-    sel = lw > -8   # log(1 - mask) amplifies 1e-4 mask differences once mask -> 1
-    np.testing.assert_allclose(lv[sel], lw[sel], atol=0.35, rtol=0)
+    np.testing.assert_allclose(np.exp(np.minimum(lv, 20.0)), np.exp(np.minimum(lw, 20.0)), atol=1e-4 * max(1.0, float(np.exp(np.minimum(lw, 20.0)).max())), rtol=0)
+    sel = lw > -4   # d logvar = d mask / (1 - mask): 1e-4 in the mask is < 6e-3 here
+    np.testing.assert_allclose(lv[sel], lw[sel], atol=6e-3, rtol=0)
 
 
 # ------------------------------------------------------------------------------------------
