@@ -19,13 +19,18 @@ __device__ __forceinline__ float ndc2pix(float v, int S) {
 }
 
 constexpr int kPreThreads = 256;
-constexpr int kPreItems = 8;  // Gaussians per thread => 2048 per block, one histogram flush each
+constexpr int kPreItems = 8;  // (Gaussian, view) items per thread: 2048 per block, one histogram flush each
 
-template <int COLOR_MODE, bool LDS_HIST>
+// VB = views per block.  Views that read the same input slice (a shared scene, or the views of one
+// group) are processed by ONE block: a thread loads its Gaussian once and loops over the block's VB
+// views, so a shared scene is read V / VB times instead of V times (269 of the kernel's
+// 578 MB were per-view re-reads of the scene from L2/MALL).  Items per thread shrink by the same
+// factor, so the grid keeps its size.
+template <int COLOR_MODE, bool LDS_HIST, int VB>
 __global__ void __launch_bounds__(kPreThreads)
 k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec *__restrict__ binrec,
              int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
-    extern __shared__ uint32_t s_hist[];
+    extern __shared__ uint32_t s_hist[];   // [VB][T] pair counts
     // 64-byte records are staged here and stored by the whole block as one contiguous run
     // (lane-contiguous 16-byte stores) instead of 4 strided partial-line stores per thread.
     // Layout [k][thread] with a row stride of kPreThreads + 4 float4: the per-thread stores (fixed k,
@@ -34,160 +39,171 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
     constexpr int kRecRow = kPreThreads + 4;
     __shared__ float4 s_rec[kRecRow * 4];
     const bool staged = RF == 16;
-    const int v = blockIdx.y;
+    const int v0 = blockIdx.y * VB;
     const int G = d.num_gaussians;
     const int gx = (d.width + LSR_TILE - 1) / LSR_TILE, gy = (d.height + LSR_TILE - 1) / LSR_TILE;
     const int T = gx * gy;
     if (LDS_HIST) {
-        for (int t = threadIdx.x; t < T; t += kPreThreads) s_hist[t] = 0;   // [T] pair counts
+        for (int t = threadIdx.x; t < VB * T; t += kPreThreads) s_hist[t] = 0;
         __syncthreads();
     }
-    const float *vw = in.views + (size_t)v * LSR_VIEW_FLOATS;
-    float vm[16], pm[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { vm[k] = vw[k]; pm[k] = vw[16 + k]; }
-    const float tanfovx = vw[35], tanfovy = vw[36];
-    const float focal_x = d.width / (2.0f * tanfovx);
-    const float focal_y = d.height / (2.0f * tanfovy);
-    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
-    const float scale = vw[40], scale2 = scale * scale;   // scene scale (1/near), applied like the reference does
     const int ce = d.cov_elems;
-    const size_t sl = (size_t)input_slice(d, v);   // which per-view / per-group input slice this view reads
+    const size_t sl = (size_t)input_slice(d, v0);   // the input slice all views of this block read
     const float *means = in.means3D + sl * d.vs_means;
     const float *covs = in.cov3D + sl * d.vs_cov;
     const float *opac = in.opacities + sl * d.vs_opac;
-    uint32_t *tc = tile_count + (size_t)v * T;
+    constexpr int coff = COLOR_MODE == LSR_COLOR_NONE ? 0 : 3;
+    const bool direct_feat = d.feat_mode == LSR_FEAT_DIRECT;
 
-    const int base = blockIdx.x * (kPreThreads * kPreItems);
+    constexpr int kItems = kPreItems / VB;
+    const int base = blockIdx.x * (kPreThreads * kItems);
 #pragma unroll 1
-    for (int it = 0; it < kPreItems; ++it) {
+    for (int it = 0; it < kItems; ++it) {
         const int chunk0 = base + it * kPreThreads;
         if (chunk0 >= G) break;   // block-uniform
         const int i = chunk0 + threadIdx.x;
         const bool in_range = i < G;
-        const size_t o = (size_t)v * G + (in_range ? i : 0);
         const size_t ii = in_range ? (size_t)i : 0;
-        const float p0 = means[3 * ii] * scale, p1 = means[3 * ii + 1] * scale, p2 = means[3 * ii + 2] * scale;
-        float4 rr[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-        int32_t out_radius = 0;
-        float out_depth = 0.0f;
-        ushort4 out_rect = make_ushort4(0, 0, 0, 0);
-        do {
-            if (!in_range) break;
-            const float t0 = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
-            const float t1 = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
-            const float t2 = vm[2] * p0 + vm[6] * p1 + vm[10] * p2 + vm[14];
-            if (t2 <= LSR_NEAR_CULL) break;
-            const float h0 = pm[0] * p0 + pm[4] * p1 + pm[8] * p2 + pm[12];
-            const float h1 = pm[1] * p0 + pm[5] * p1 + pm[9] * p2 + pm[13];
-            const float h3 = pm[3] * p0 + pm[7] * p1 + pm[11] * p2 + pm[15];
-            const float p_w = 1.0f / (h3 + 0.0000001f);
-            const float ndc_x = h0 * p_w, ndc_y = h1 * p_w;
-
-            const float txtz = t0 / t2, tytz = t1 / t2;
-            const float tx = fmin_sel(limx, fmax_sel(-limx, txtz)) * t2;
-            const float ty = fmin_sel(limy, fmax_sel(-limy, tytz)) * t2;
-            const float tz = t2;
-            const float j00 = focal_x / tz, j02 = -(focal_x * tx) / (tz * tz);
-            const float j11 = focal_y / tz, j12 = -(focal_y * ty) / (tz * tz);
-            const float m00 = j00 * vm[0] + j02 * vm[2];
-            const float m01 = j00 * vm[4] + j02 * vm[6];
-            const float m02 = j00 * vm[8] + j02 * vm[10];
-            const float m10 = j11 * vm[1] + j12 * vm[2];
-            const float m11 = j11 * vm[5] + j12 * vm[6];
-            const float m12 = j11 * vm[9] + j12 * vm[10];
-            const float *c6 = covs + (size_t)ce * (size_t)i;
-            const float s0 = c6[0] * scale2, s1 = c6[1] * scale2, s2 = c6[2] * scale2;
-            const float s3 = c6[ce == 9 ? 4 : 3] * scale2, s4 = c6[ce == 9 ? 5 : 4] * scale2, s5 = c6[ce == 9 ? 8 : 5] * scale2;
-            const float v00 = s0 * m00 + s1 * m01 + s2 * m02;
-            const float v01 = s1 * m00 + s3 * m01 + s4 * m02;
-            const float v02 = s2 * m00 + s4 * m01 + s5 * m02;
-            const float v10 = s0 * m10 + s1 * m11 + s2 * m12;
-            const float v11 = s1 * m10 + s3 * m11 + s4 * m12;
-            const float v12 = s2 * m10 + s4 * m11 + s5 * m12;
-            const float ca = (m00 * v00 + m01 * v01 + m02 * v02) + LSR_LOWPASS;
-            const float cb = m00 * v10 + m01 * v11 + m02 * v12;
-            const float cc = (m10 * v10 + m11 * v11 + m12 * v12) + LSR_LOWPASS;
-            const float det = ca * cc - cb * cb;
-            if (det == 0.0f) break;
-            const float det_inv = 1.0f / det;
-            const float conic_a = cc * det_inv, conic_b = -cb * det_inv, conic_c = ca * det_inv;
-            const float mid = 0.5f * (ca + cc);
-            const float disc = sqrtf(fmax_sel(0.1f, mid * mid - det));
-            const float lambda1 = mid + disc, lambda2 = mid - disc;
-            const float my_radius = ceilf(3.0f * sqrtf(fmax_sel(lambda1, lambda2)));
-            const float px = ndc2pix(ndc_x, d.width), py = ndc2pix(ndc_y, d.height);
-            const int rminx = imin_sel(gx, imax_sel(0, (int)((px - my_radius) / LSR_TILE)));
-            const int rminy = imin_sel(gy, imax_sel(0, (int)((py - my_radius) / LSR_TILE)));
-            const int rmaxx = imin_sel(gx, imax_sel(0, (int)((px + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
-            const int rmaxy = imin_sel(gy, imax_sel(0, (int)((py + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
-            if ((rmaxx - rminx) * (rmaxy - rminy) == 0) break;
-
-            float4 *R = (float4 *)(rec + o * (size_t)RF);
-            const uint32_t clampbits = 0;
-            float pay[3] = {0.0f, 0.0f, 0.0f};
-            if (COLOR_MODE == LSR_COLOR_SH) {
-                // filled by k_sh (sh.hip) for visible Gaussians
-            } else if (COLOR_MODE == LSR_COLOR_PRECOMP) {
-                const float *cp = in.color + sl * d.vs_color + 3 * (size_t)i;
-                pay[0] = cp[0]; pay[1] = cp[1]; pay[2] = cp[2];
-            }
-            out_radius = (int32_t)my_radius;
-            out_rect = make_ushort4((unsigned short)rminx, (unsigned short)rminy,
-                                    (unsigned short)rmaxx, (unsigned short)rmaxy);
-            out_depth = tz;
-            rr[0] = make_float4(px, py, conic_a, conic_b);
-            rr[1] = make_float4(conic_c, opac[i], tz, __uint_as_float(clampbits));
-            if (!staged) { R[0] = rr[0]; R[1] = rr[1]; }
-            {   // payload slots 8.. : rgb (if any) then the feature channels, zero padded
-                constexpr int coff = COLOR_MODE == LSR_COLOR_NONE ? 0 : 3;
-                const bool direct_feat = d.feat_mode == LSR_FEAT_DIRECT;
-                const float *fp = in.features + sl * d.vs_feat + (size_t)i * d.feat_channels;
-                for (int c4 = 0; c4 < (RF - 8) / 4; ++c4) {
-                    float w[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int c = 4 * c4 + k;
-                        w[k] = c < coff ? pay[c < 3 ? c : 0]
-                                        : ((direct_feat && c - coff < d.feat_channels) ? fp[c - coff] : 0.0f);
-                    }
-                    if (staged) rr[c4 < 2 ? 2 + c4 : 2] = make_float4(w[0], w[1], w[2], w[3]);
-                    else R[2 + c4] = make_float4(w[0], w[1], w[2], w[3]);
-                }
-            }
-            // per-tile pair counts (also the compositing kernels' scheduling key: a finer work
-            // estimate — quadrants reached per entry — was measured to schedule no better)
-            for (int y = rminy; y < rmaxy; ++y)
-                for (int x = rminx; x < rmaxx; ++x) {
-                    if (LDS_HIST) atomicAdd(&s_hist[y * gx + x], 1u);
-                    else atomicAdd(&tc[y * gx + x], 1u);
-                }
-        } while (0);
-        if (in_range) {
-            radii[o] = out_radius;
-            BinRec br; br.rect = out_rect; br.depth = out_depth; br.radius = out_radius;
-            binrec[o] = br;
+        // ---- the Gaussian, once for all views of the block ----
+        const float q0 = means[3 * ii], q1 = means[3 * ii + 1], q2 = means[3 * ii + 2];
+        const float *c6 = covs + (size_t)ce * ii;
+        const float r0 = c6[0], r1 = c6[1], r2 = c6[2];
+        const float r3 = c6[ce == 9 ? 4 : 3], r4 = c6[ce == 9 ? 5 : 4], r5 = c6[ce == 9 ? 8 : 5];
+        const float opacity = opac[ii];
+        float pay_in[3] = {0.0f, 0.0f, 0.0f};
+        if (COLOR_MODE == LSR_COLOR_PRECOMP) {
+            const float *cp = in.color + sl * d.vs_color + 3 * ii;
+            pay_in[0] = cp[0]; pay_in[1] = cp[1]; pay_in[2] = cp[2];
         }
-        if (staged) {
+        const float *fp = in.features + sl * d.vs_feat + ii * d.feat_channels;
+
+#pragma unroll 1
+        for (int vb = 0; vb < VB; ++vb) {
+            const int v = v0 + vb;
+            if (v >= d.num_views) break;   // block-uniform
+            const float *vw = in.views + (size_t)v * LSR_VIEW_FLOATS;
+            float vm[16], pm[16];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s_rec[k * kRecRow + threadIdx.x] = rr[k];
-            __syncthreads();
-            float4 *dst = (float4 *)(rec + ((size_t)v * G + chunk0) * 16);
-            const int nrec = G - chunk0 < kPreThreads ? G - chunk0 : kPreThreads;
+            for (int k = 0; k < 16; ++k) { vm[k] = vw[k]; pm[k] = vw[16 + k]; }
+            const float tanfovx = vw[35], tanfovy = vw[36];
+            const float focal_x = d.width / (2.0f * tanfovx);
+            const float focal_y = d.height / (2.0f * tanfovy);
+            const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+            const float scale = vw[40], scale2 = scale * scale;   // scene scale (1/near), applied like the reference does
+            uint32_t *tc = tile_count + (size_t)v * T;
+            uint32_t *hist = s_hist + vb * T;
+            const size_t o = (size_t)v * G + ii;
+            const float p0 = q0 * scale, p1 = q1 * scale, p2 = q2 * scale;
+            float4 rr[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+            int32_t out_radius = 0;
+            float out_depth = 0.0f;
+            ushort4 out_rect = make_ushort4(0, 0, 0, 0);
+            do {
+                if (!in_range) break;
+                const float t0 = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
+                const float t1 = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
+                const float t2 = vm[2] * p0 + vm[6] * p1 + vm[10] * p2 + vm[14];
+                if (t2 <= LSR_NEAR_CULL) break;
+                const float h0 = pm[0] * p0 + pm[4] * p1 + pm[8] * p2 + pm[12];
+                const float h1 = pm[1] * p0 + pm[5] * p1 + pm[9] * p2 + pm[13];
+                const float h3 = pm[3] * p0 + pm[7] * p1 + pm[11] * p2 + pm[15];
+                const float p_w = 1.0f / (h3 + 0.0000001f);
+                const float ndc_x = h0 * p_w, ndc_y = h1 * p_w;
+
+                const float txtz = t0 / t2, tytz = t1 / t2;
+                const float tx = fmin_sel(limx, fmax_sel(-limx, txtz)) * t2;
+                const float ty = fmin_sel(limy, fmax_sel(-limy, tytz)) * t2;
+                const float tz = t2;
+                const float j00 = focal_x / tz, j02 = -(focal_x * tx) / (tz * tz);
+                const float j11 = focal_y / tz, j12 = -(focal_y * ty) / (tz * tz);
+                const float m00 = j00 * vm[0] + j02 * vm[2];
+                const float m01 = j00 * vm[4] + j02 * vm[6];
+                const float m02 = j00 * vm[8] + j02 * vm[10];
+                const float m10 = j11 * vm[1] + j12 * vm[2];
+                const float m11 = j11 * vm[5] + j12 * vm[6];
+                const float m12 = j11 * vm[9] + j12 * vm[10];
+                const float s0 = r0 * scale2, s1 = r1 * scale2, s2 = r2 * scale2;
+                const float s3 = r3 * scale2, s4 = r4 * scale2, s5 = r5 * scale2;
+                const float v00 = s0 * m00 + s1 * m01 + s2 * m02;
+                const float v01 = s1 * m00 + s3 * m01 + s4 * m02;
+                const float v02 = s2 * m00 + s4 * m01 + s5 * m02;
+                const float v10 = s0 * m10 + s1 * m11 + s2 * m12;
+                const float v11 = s1 * m10 + s3 * m11 + s4 * m12;
+                const float v12 = s2 * m10 + s4 * m11 + s5 * m12;
+                const float ca = (m00 * v00 + m01 * v01 + m02 * v02) + LSR_LOWPASS;
+                const float cb = m00 * v10 + m01 * v11 + m02 * v12;
+                const float cc = (m10 * v10 + m11 * v11 + m12 * v12) + LSR_LOWPASS;
+                const float det = ca * cc - cb * cb;
+                if (det == 0.0f) break;
+                const float det_inv = 1.0f / det;
+                const float conic_a = cc * det_inv, conic_b = -cb * det_inv, conic_c = ca * det_inv;
+                const float mid = 0.5f * (ca + cc);
+                const float disc = sqrtf(fmax_sel(0.1f, mid * mid - det));
+                const float lambda1 = mid + disc, lambda2 = mid - disc;
+                const float my_radius = ceilf(3.0f * sqrtf(fmax_sel(lambda1, lambda2)));
+                const float px = ndc2pix(ndc_x, d.width), py = ndc2pix(ndc_y, d.height);
+                const int rminx = imin_sel(gx, imax_sel(0, (int)((px - my_radius) / LSR_TILE)));
+                const int rminy = imin_sel(gy, imax_sel(0, (int)((py - my_radius) / LSR_TILE)));
+                const int rmaxx = imin_sel(gx, imax_sel(0, (int)((px + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
+                const int rmaxy = imin_sel(gy, imax_sel(0, (int)((py + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
+                if ((rmaxx - rminx) * (rmaxy - rminy) == 0) break;
+
+                float4 *R = (float4 *)(rec + o * (size_t)RF);
+                out_radius = (int32_t)my_radius;
+                out_rect = make_ushort4((unsigned short)rminx, (unsigned short)rminy,
+                                        (unsigned short)rmaxx, (unsigned short)rmaxy);
+                out_depth = tz;
+                rr[0] = make_float4(px, py, conic_a, conic_b);
+                rr[1] = make_float4(conic_c, opacity, tz, 0.0f);
+                if (!staged) { R[0] = rr[0]; R[1] = rr[1]; }
+                {   // payload slots 8.. : rgb (if any; SH colour is filled in by sh.hip) then the feature channels, zero padded
+                    for (int c4 = 0; c4 < (RF - 8) / 4; ++c4) {
+                        float w[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = k * kPreThreads + threadIdx.x;      // float4 index inside the run
-                // culled Gaussians (view z == 0 in their staged record) are never read: skip them
-                if (idx < nrec * 4 && s_rec[kRecRow + (idx >> 2)].z > 0.0f) dst[idx] = s_rec[(idx & 3) * kRecRow + (idx >> 2)];
+                        for (int k = 0; k < 4; ++k) {
+                            const int c = 4 * c4 + k;
+                            w[k] = c < coff ? pay_in[c < 3 ? c : 0]
+                                            : ((direct_feat && c - coff < d.feat_channels) ? fp[c - coff] : 0.0f);
+                        }
+                        if (staged) rr[c4 < 2 ? 2 + c4 : 2] = make_float4(w[0], w[1], w[2], w[3]);
+                        else R[2 + c4] = make_float4(w[0], w[1], w[2], w[3]);
+                    }
+                }
+                // per-tile pair counts (also the compositing kernels' scheduling key: a finer work
+                // estimate — quadrants reached per entry — was measured to schedule no better)
+                for (int y = rminy; y < rmaxy; ++y)
+                    for (int x = rminx; x < rmaxx; ++x) {
+                        if (LDS_HIST) atomicAdd(&hist[y * gx + x], 1u);
+                        else atomicAdd(&tc[y * gx + x], 1u);
+                    }
+            } while (0);
+            if (in_range) {
+                radii[o] = out_radius;
+                BinRec br; br.rect = out_rect; br.depth = out_depth; br.radius = out_radius;
+                binrec[o] = br;
             }
-            __syncthreads();
+            if (staged) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s_rec[k * kRecRow + threadIdx.x] = rr[k];
+                __syncthreads();
+                float4 *dst = (float4 *)(rec + ((size_t)v * G + chunk0) * 16);
+                const int nrec = G - chunk0 < kPreThreads ? G - chunk0 : kPreThreads;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int idx = k * kPreThreads + threadIdx.x;      // float4 index inside the run
+                    // culled Gaussians (view z == 0 in their staged record) are never read: skip them
+                    if (idx < nrec * 4 && s_rec[kRecRow + (idx >> 2)].z > 0.0f) dst[idx] = s_rec[(idx & 3) * kRecRow + (idx >> 2)];
+                }
+                __syncthreads();
+            }
         }
     }
     if (LDS_HIST) {
         __syncthreads();
-        for (int t = threadIdx.x; t < T; t += kPreThreads) {
+        for (int t = threadIdx.x; t < VB * T; t += kPreThreads) {
+            const int v = v0 + t / T;
             const uint32_t c = s_hist[t];
-            if (c) atomicAdd(&tc[t], c);
+            if (c && v < d.num_views) atomicAdd(&tile_count[(size_t)v * T + (t % T)], c);
         }
     }
 }
@@ -216,25 +232,31 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
         if (e != hipSuccess) return e;
     }
     if (d.num_gaussians == 0) return hipSuccess;
-    dim3 grid((d.num_gaussians + kPreThreads * kPreItems - 1) / (kPreThreads * kPreItems), d.num_views);
+    // views per block: 4 (or 2) when that many consecutive views read the same input slice
+    const bool shared = d.vs_means == 0 && d.vs_cov == 0 && d.vs_opac == 0 && (d.color_mode != LSR_COLOR_PRECOMP || d.vs_color == 0) &&
+                        (d.feat_channels == 0 || d.vs_feat == 0);
+    const int span = shared ? d.num_views : (d.views_per_group > 1 ? d.views_per_group : 1);   // views per input slice
+    const int vb = (span % 4 == 0 || (shared && span >= 4)) ? 4 : ((span % 2 == 0 || (shared && span >= 2)) ? 2 : 1);
+    const int items = kPreItems / vb;
+    dim3 grid((d.num_gaussians + kPreThreads * items - 1) / (kPreThreads * items), (d.num_views + vb - 1) / vb);
     float *rec = (float *)(geom + L.rec);
     BinRec *binrec = (BinRec *)(geom + L.bin);
     const int RF = L.rec_floats;
     uint32_t *tc = (uint32_t *)(geom + L.tile_count);
-    const bool lds = T <= 4096;
-    const size_t shm = lds ? (size_t)T * 4 : 0;
+    const bool lds = (size_t)T * vb <= 4096;
+    const size_t shm = lds ? (size_t)T * vb * 4 : 0;
+#define LSR_PRE2(CM, LH, VBV) hipLaunchKernelGGL((k_preprocess<CM, LH, VBV>), grid, dim3(kPreThreads), shm, s, d, in, rec, RF, binrec, radii, tc)
 #define LSR_PRE(CM)                                                                              \
     do {                                                                                         \
-        if (lds) hipLaunchKernelGGL((k_preprocess<CM, true>), grid, dim3(kPreThreads), shm, s,   \
-                                    d, in, rec, RF, binrec, radii, tc);                         \
-        else hipLaunchKernelGGL((k_preprocess<CM, false>), grid, dim3(kPreThreads), 0, s, d, in, \
-                                rec, RF, binrec, radii, tc);                                    \
+        if (lds) { if (vb == 4) LSR_PRE2(CM, true, 4); else if (vb == 2) LSR_PRE2(CM, true, 2); else LSR_PRE2(CM, true, 1); } \
+        else { if (vb == 4) LSR_PRE2(CM, false, 4); else if (vb == 2) LSR_PRE2(CM, false, 2); else LSR_PRE2(CM, false, 1); } \
     } while (0)
     prof_begin(kStPreprocess, s);
     if (d.color_mode == LSR_COLOR_SH) LSR_PRE(LSR_COLOR_SH);
     else if (d.color_mode == LSR_COLOR_PRECOMP) LSR_PRE(LSR_COLOR_PRECOMP);
     else LSR_PRE(LSR_COLOR_NONE);
 #undef LSR_PRE
+#undef LSR_PRE2
     prof_end(kStPreprocess, s);
     return hipGetLastError();
 }
