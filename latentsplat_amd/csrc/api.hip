@@ -31,14 +31,19 @@ struct Prof {
     }
 };
 Prof g_prof;
+std::mutex g_prof_mu;   // the measurement hook is process-wide state; calls may come from several host threads
 }  // namespace
 void lsr::prof_begin(int stage, hipStream_t s) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (!g_prof.wants(stage)) return;
     hipEvent_t e = g_prof.get();
     (void)hipEventRecord(e, s);
     g_prof.open_ev[stage] = e;
 }
 void lsr::prof_end(int stage, hipStream_t s) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (!g_prof.open_ev[stage]) return;
     hipEvent_t e = g_prof.get();
     (void)hipEventRecord(e, s);
@@ -196,6 +201,7 @@ extern "C" {
 int lsr_abi_version(void) { return LSR_ABI_VERSION; }
 
 int lsr_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof.on = (unsigned)on;
     return LSR_OK;
 }
@@ -208,6 +214,7 @@ const char *lsr_profile_stage_name(int stage) {
 }
 int lsr_profile_read(double *ms_out, int64_t *launches_out) {
     if (!ms_out || !launches_out) return LSR_ENULL;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (int st = 0; st < lsr::kNumStages; ++st) {
         for (auto &pr : g_prof.pending[st]) {
             float t = 0.0f;

@@ -226,12 +226,20 @@ __global__ void __launch_bounds__(LSR_WAVE * 4 * WPS)
 k_render_bwd(RenderBwdParams p) {
     constexpr int PXL = 4;
     constexpr int WPB = 4 * WPS;
-    constexpr int kEnt = (2 + NCHP / 4) | 1;                          // float4 per staged entry (odd: conflict-free staging)
+    // float4 per staged entry: odd (conflict-free staging stores) except for the 8-channel payload, whose
+    // 16 floats are stored at a 64-byte stride (2-way conflicts in the staging stores only) so that the
+    // slice fits 16 waves per CU — with 12 (3 per SIMD) this VALU-bound kernel ran 32 % slower (measured
+    // on the 4-channel variant: 0.92 -> 1.21 ms)
+    constexpr int kEnt = NCHP == 8 ? 4 : ((2 + NCHP / 4) | 1);
     constexpr int RF = NCHP <= 8 ? 16 : (NCHP <= 12 ? 32 : 64);       // == rec_floats (lsr_internal.h)
     constexpr int NGRP = RF / 16;                                     // 16-value reduction passes per evaluation
+    // words per row of the LDS gradient table: the record without its two never-written slots (6 unless the
+    // depth gradient is on, 7) for the 8-channel payload (same LDS budget), the full record otherwise
+    constexpr bool kPackRow = NCHP == 8 && !DEPTH_GRAD;
+    constexpr int RT = kPackRow ? 14 : RF;
     struct Lds {
         float4 ent[WPB][LSR_WAVE + 1][kEnt];   // (x, y, a2, c2) (b2, log2 o, z, list position) payload...; slot 64 = null record
-        float acc[WPB][LSR_WAVE + 1][RF];      // this batch's gradient records, row = staged entry (row 64: dump row of the null record)
+        float acc[WPB][LSR_WAVE + 1][RT];      // this batch's gradient records, row = staged entry (row 64: dump row of the null record)
         uint32_t gid[WPB][LSR_WAVE];           // Gaussian index of the staged entry
         uint16_t list[WPB][16][LSR_WAVE];      // per sub-block: staging slots of the entries that can reach it, in list order
     };
@@ -240,7 +248,7 @@ k_render_bwd(RenderBwdParams p) {
     const int lane = threadIdx.x & (LSR_WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / LSR_WAVE);
     float4 (*s_ent)[kEnt] = s_lds.ent[wid];
-    float (*s_acc)[RF] = s_lds.acc[wid];
+    float (*s_acc)[RT] = s_lds.acc[wid];
     uint32_t *s_gid = s_lds.gid[wid];
     uint16_t (*s_list)[LSR_WAVE] = s_lds.list[wid];
     {   // null record + cleared gradient table (rows are re-zeroed by the flush)
@@ -251,12 +259,13 @@ k_render_bwd(RenderBwdParams p) {
             for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         float *A = &s_acc[0][0];
-        for (int i = lane; i < (LSR_WAVE + 1) * RF; i += LSR_WAVE) A[i] = 0.0f;
+        for (int i = lane; i < (LSR_WAVE + 1) * RT; i += LSR_WAVE) A[i] = 0.0f;
     }
     const uint32_t num_items = p.header[kHdrNumItems];
     const int coff = p.has_color ? 3 : 0;
     const size_t HW = (size_t)p.H * p.W;
     const int grp = lane >> 4, gcol = grp & 1, grow = grp >> 1, l16 = lane & 15;
+    const int tcol = kPackRow ? (l16 < 8 ? l16 : l16 - 2) : l16;   // this lane's record slot -> column of the table row (slots 6, 7 unused when packed)
     const int gsb = 4 * grow + gcol;
     const int lx = lane & 3, ly = (lane >> 2) & 3;
 
@@ -427,7 +436,7 @@ k_render_bwd(RenderBwdParams p) {
                     const uint32_t lel = lp[i];
                     const uint32_t slot = lel & 0xFFu, rank = lel >> 8;
                     const float4_b *E = (const float4_b *)&s_ent[slot][0];
-                    float *row = &s_acc[slot][l16];
+                    float *row = &s_acc[slot][tcol];
                     float acc_old[NGRP];                             // this lane's word(s) of the entry's table row, read early
 #pragma unroll
                     for (int gi = 0; gi < NGRP; ++gi) acc_old[gi] = row[16 * gi];
@@ -530,8 +539,9 @@ k_render_bwd(RenderBwdParams p) {
                 const uint32_t g = s_gid[e];
 #pragma unroll
                 for (int gi = 0; gi < NGRP; ++gi) {
-                    const float val = s_acc[e][16 * gi + l16];
-                    s_acc[e][16 * gi + l16] = 0.0f;
+                    const bool mine = !kPackRow || ((l16 & 14) != 6);   // slots 6 and 7 have no column in a packed row
+                    const float val = mine ? s_acc[e][16 * gi + tcol] : 0.0f;
+                    if (mine) s_acc[e][16 * gi + tcol] = 0.0f;
                     if (hit && val != 0.0f) {
                         const size_t at = (vG + g) * (size_t)RF + 16 * gi + l16;
                         if (p.rec_fixed)   // order-independent integer sum (LSR_DETERMINISTIC)
@@ -591,7 +601,8 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
         else launch_variant<N, false, W>(p, s);                  \
     } while (0)
     if (nchp == 4) LSR_RB(4, 4);
-    else if (nchp == 8) LSR_RB(8, 3);
+    else if (nchp == 8 && !dg) launch_variant<8, false, 4>(p, s);   // packed table rows: 16 waves per CU fit
+    else if (nchp == 8) launch_variant<8, true, 3>(p, s);
     else if (nchp == 12) LSR_RB(12, 2);
     else LSR_RB(36, 1);
 #undef LSR_RB

@@ -247,8 +247,13 @@ class _RasterizeViews(torch.autograd.Function):
         ctx.plan = plan
         LAST_STATS.update(num_pairs=None if pair_capacity > 0 else npairs.value, max_tile_pairs=maxtile.value, views=V,
                           gaussians=G, pair_capacity=int(pair_capacity))
-        global _LAST_PLAN
-        _LAST_PLAN = plan
+        # what last_forward_status() reports: the host already knows the counts of a synchronous forward;
+        # a no-sync forward keeps its (caller-requested) plan alive so the header can be read back later
+        global _LAST_PLAN, _LAST_STATUS
+        if pair_capacity > 0:
+            _LAST_PLAN, _LAST_STATUS = plan, None
+        else:
+            _LAST_PLAN, _LAST_STATUS = None, dict(num_pairs=npairs.value, max_tile_pairs=maxtile.value, overflow=False)
         ctx.debug = debug
         ctx.m2d_shape = None if means2D is None else tuple(means2D.shape)
         ctx.has = (shs is not None, colors_precomp is not None, features is not None)
@@ -349,13 +354,17 @@ def rasterize_views(views: Tensor, image_height: int, image_width: int, sh_degre
     return (color if color.numel() else None, feat if feat.numel() else None, mask, depth, radii)
 
 
-_LAST_PLAN = None
+_LAST_PLAN = None      # plan of the most recent NO-SYNC forward (holds its workspaces), else None
+_LAST_STATUS = None    # host-side counts of the most recent synchronous forward, else None
 
 
 def last_forward_status() -> dict:
-    """``{num_pairs, max_tile_pairs, overflow}`` of the most recent forward of this process, read back
-    from its geometry workspace (synchronises the current stream).  After a graph replay it reports
-    the replayed forward (the workspace addresses are static)."""
+    """``{num_pairs, max_tile_pairs, overflow}`` of the most recent forward of this process.  For a
+    synchronous forward these are the counts the host already holds; for a no-sync forward they are
+    read back from its geometry workspace (synchronises the current stream) — after a graph replay
+    that is the replayed forward (the workspace addresses are static)."""
+    if _LAST_STATUS is not None:
+        return dict(_LAST_STATUS)
     if _LAST_PLAN is None:
         raise LsrError("no forward has run yet")
     lib = _lib.load()
