@@ -9,10 +9,17 @@
 //   k_scatter   : every visible Gaussian writes (depth_bits<<32 | index) into each tile segment
 //                 it overlaps.  Slots come from a two-level reservation: LDS counters per block,
 //                 then ONE global atomic per (block, tile).
-//   k_sort_tiles: per-tile sort of the 64-bit keys in LDS (bucket sort, bitonic fallback).  Ascending (depth bits, index)
+//   k_sort_tiles: per-tile sort of the 64-bit keys in LDS (bucket sort with parallel in-bucket ranking, bitonic
+//                 fallback).  Ascending (depth bits, index)
 //                 == the published stable sort by depth with ties in emission (= index) order,
 //                 so lists are bit-exact whatever order the scatter produced.
 #include "lsr_internal.h"
+#include <algorithm>
+#ifdef LSR_ENABLE_TRACE
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#endif
 
 namespace lsr {
 
@@ -137,51 +144,75 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror
 
 // ------------------------------------------------------------------------------------------
 constexpr int kScatThreads = 256;
-constexpr int kScatItems = 8;
+constexpr int kScatItems = 12;   // most (view, Gaussian) items of one thread; the launcher picks the count
 
 template <bool LDS_RESERVE, bool CHECK>
-__global__ void __launch_bounds__(kScatThreads)
+__global__ void __launch_bounds__(kScatThreads, 8)
 k_scatter(int G, int gx, int T, const BinRec *__restrict__ binrec,
           const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ tile_cursor,
-          uint64_t *__restrict__ keys, uint32_t capacity) {
+          uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, unsigned long long *trace) {
+#ifdef LSR_ENABLE_TRACE
+#define LSR_STAMP(k) do { if (trace && threadIdx.x == 0) trace[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define LSR_STAMP(k) do { } while (0)
+#endif
+    LSR_STAMP(0);
     extern __shared__ uint32_t s_mem[];  // [T] counts, [T] bases
     uint32_t *s_cnt = s_mem, *s_base = s_mem + T;
-    const int v = blockIdx.y;
+    const uint32_t unit = blockIdx.x;   // view-major (view, chunk)
+    const int v = (int)(unit / chunks);
     const size_t vo = (size_t)v * G;
     const uint32_t *ts = tile_start + (size_t)v * T;
     uint32_t *cur = tile_cursor + (size_t)v * T;
-    const int base = blockIdx.x * (kScatThreads * kScatItems);
-    ushort4 r[kScatItems];
+    const int base = (int)(unit % chunks) * (kScatThreads * items);
+    // rectangles stay PACKED in registers (x0 | y0 << 16, x1 | y1 << 16) between the two passes; the
+    // empty asm makes each pass unpack its own copy instead of keeping four coordinates per item live
+    uint32_t lo16[kScatItems], hi16[kScatItems];
     float dep[kScatItems];
+    // unconditional loads at clamped addresses (all in flight together; a load under a per-lane condition
+    // makes the compiler wait for each one), invalid items become empty rectangles afterwards
+    const BinRec *bv = binrec + vo;
 #pragma unroll
     for (int it = 0; it < kScatItems; ++it) {
-        const int i = base + it * kScatThreads + threadIdx.x;
-        BinRec br; br.rect = make_ushort4(0, 0, 0, 0); br.depth = 0.0f;
-        if (i < G) br = binrec[vo + i];
-        r[it] = br.rect; dep[it] = br.depth;
+        const int i = base + min(it, items - 1) * kScatThreads + (int)threadIdx.x;
+        const uint3 br = *(const uint3 *)(bv + min(i, G - 1));   // rectangle + depth bits (the radius word is not needed)
+        const bool valid = it < items && i < G;
+        lo16[it] = br.x; hi16[it] = valid ? br.y : 0u; dep[it] = __uint_as_float(br.z);
     }
     if (LDS_RESERVE) {
         for (int t = threadIdx.x; t < T; t += kScatThreads) s_cnt[t] = 0;
         __syncthreads();
+        LSR_STAMP(1);
 #pragma unroll
-        for (int it = 0; it < kScatItems; ++it)
-            for (int y = r[it].y; y < r[it].w; ++y)
-                for (int x = r[it].x; x < r[it].z; ++x) atomicAdd(&s_cnt[y * gx + x], 1u);
+        for (int it = 0; it < kScatItems; ++it) {
+            uint32_t a = lo16[it], b = hi16[it];
+            asm volatile("" : "+v"(a), "+v"(b));
+            const int x0 = a & 0xffff, y0 = a >> 16, x1 = b & 0xffff, y1 = b >> 16;
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) atomicAdd(&s_cnt[y * gx + x], 1u);
+        }
         __syncthreads();
+        LSR_STAMP(2);
         for (int t = threadIdx.x; t < T; t += kScatThreads) {
             const uint32_t c = s_cnt[t];
             if (c) s_base[t] = ts[t] + atomicAdd(&cur[t], c);
             s_cnt[t] = 0;
         }
         __syncthreads();
+        LSR_STAMP(3);
     }
+    uint32_t tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));   // recomputed per item below rather than kept (or spilled) across the passes
 #pragma unroll
     for (int it = 0; it < kScatItems; ++it) {
-        const int i = base + it * kScatThreads + threadIdx.x;
-        if (r[it].z <= r[it].x || r[it].w <= r[it].y) continue;
-        const uint64_t key = ((uint64_t)__float_as_uint(dep[it]) << 32) | (uint32_t)i;
-        for (int y = r[it].y; y < r[it].w; ++y)
-            for (int x = r[it].x; x < r[it].z; ++x) {
+        const uint32_t i = (uint32_t)(base + it * kScatThreads) + tid2;
+        uint32_t a = lo16[it], b = hi16[it];
+        asm volatile("" : "+v"(a), "+v"(b));
+        const int x0 = a & 0xffff, y0 = a >> 16, x1 = b & 0xffff, y1 = b >> 16;
+        if (x1 <= x0 || y1 <= y0) continue;
+        const uint64_t key = ((uint64_t)__float_as_uint(dep[it]) << 32) | i;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
                 const int t = y * gx + x;
                 uint32_t pos;
                 if (LDS_RESERVE) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
@@ -189,6 +220,19 @@ k_scatter(int G, int gx, int T, const BinRec *__restrict__ binrec,
                 if (!CHECK || pos < capacity) keys[pos] = key;   // CHECK (no-sync forward): tile_scan clamped the offsets to the workspace capacity
             }
     }
+    LSR_STAMP(4);
+#ifdef LSR_ENABLE_TRACE
+    __builtin_amdgcn_s_waitcnt(0);   // stores drained
+    __syncthreads();
+    LSR_STAMP(5);
+    if (trace && threadIdx.x == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trace[8 * (size_t)blockIdx.x + 7] = ((unsigned long long)(xcc & 0xff) << 32) | hwid;
+    }
+#endif
+#undef LSR_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -196,36 +240,49 @@ constexpr int kSortThreads = 512;
 
 // One workgroup per (tile, view); list length n <= CAP, keys sorted inside LDS.
 //
-// Fast path — order-preserving bucket sort: bucket = (key - min) >> shift is monotone in the key,
-// so a histogram + scan + scatter puts every key into its final neighbourhood and a tiny
-// insertion sort per bucket (about one key per bucket on average) finishes the job: ~10 LDS
-// operations per key instead of the ~log^2(n) compare-exchange passes of a sorting network.
-// Because the low 32 key bits are the (distinct) Gaussian indices, even identical depths spread
-// over the buckets; only a heavy cluster plus a far outlier can overfill a bucket, and such tiles
-// take the bitonic network below (same LDS array).  Both paths produce the same total order of
-// distinct 64-bit keys, i.e. the bit-exact published ordering.
-constexpr uint32_t kBucketOverflow = 48;   // longest bucket the insertion sort may get
+// Order-preserving bucket sort: bucket = (key - min) >> shift is monotone in the key, so a histogram +
+// scan puts every key into its final neighbourhood; inside a bucket (about one key on average) a
+// key's place is the number of smaller members.  Because the low 32 key bits are the (distinct)
+// Gaussian indices, even identical depths spread over the buckets; only a heavy cluster plus a far
+// outlier can overfill a bucket, and such tiles take the bitonic network below (same LDS array).
+// Both paths produce the same total order of distinct 64-bit keys, i.e. the bit-exact published
+// ordering.
+//
+// Lists up to 4096 keys (REG): the list is read from memory once into registers; the returning
+// histogram atomic is the key's arrival rank in its bucket, so after the scan every key is placed
+// with a plain LDS write, and its final position is found by EVERY KEY IN PARALLEL (count the smaller
+// members of its bucket, four per step).  The round-1 version finished buckets with a serial
+// insertion sort, four buckets per thread: a chain of dependent LDS round trips that was half of
+// the kernel (phase trace: 5.1 of 10.2 us per workgroup).  All LDS scratch lives in the dynamic
+// allocation (the reduction scratch aliases the key array before keys are placed) so that four
+// 4096-key workgroups share a CU's 160 KB.
+constexpr uint32_t kBucketOverflow = 48;   // longest bucket the in-bucket pass may get
 
 template <int CAP>
 __global__ void __launch_bounds__(kSortThreads)
 k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
-             uint32_t *__restrict__ point_list, uint32_t longer_than) {
+             uint32_t *__restrict__ point_list, uint32_t longer_than, unsigned long long *trace) {
+#ifdef LSR_ENABLE_TRACE
+#define LSR_STAMP(k) do { if (trace && threadIdx.x == 0) trace[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define LSR_STAMP(k) do { } while (0)
+#endif
+    LSR_STAMP(0);
     constexpr int NB = CAP < 2048 ? CAP : 2048;          // buckets
-    extern __shared__ uint64_t s_keys[];                  // [CAP] sorted keys
-    uint32_t *s_cnt = (uint32_t *)(s_keys + CAP);         // [NB] histogram -> bucket end offsets
-    __shared__ uint64_t s_red[2 * (kSortThreads / LSR_WAVE)];
-    __shared__ uint32_t s_wsum[kSortThreads / LSR_WAVE];
-    __shared__ uint32_t s_flag;
+    constexpr int kWaves = kSortThreads / LSR_WAVE;
+    extern __shared__ uint64_t s_keys[];                  // [CAP] keys grouped by bucket / sorted
+    uint32_t *s_cnt = (uint32_t *)(s_keys + CAP);         // [NB] histogram -> bucket offsets
+    uint64_t *s_red = s_keys;                             // [2 * kWaves] range reduction  } alias the key array:
+    uint32_t *s_wsum = (uint32_t *)(s_keys + 2 * kWaves); // [kWaves] scan partials        } dead before the
+    uint32_t *s_flag = s_wsum + kWaves;                   // bucket overflow               } first key is placed
     const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
-    const size_t vt = (size_t)blockIdx.y * T + blockIdx.x;
+    const size_t vt = blockIdx.x;   // view-major (view, tile)
     const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
     if (n == 0 || n <= longer_than) return;   // shorter lists belong to another launch (no-sync forward: two variants)
     if (n > (uint32_t)CAP) return;  // handled by a larger variant / the global-memory path
     const uint64_t *src = keys + start;
     if (n == 1) { if (tid == 0) point_list[start] = (uint32_t)src[0]; return; }
 
-    // ---- the list is read from memory ONCE, all loads of a thread in flight together; lists up
-    // to 4096 entries then live in registers for the range / histogram / scatter passes ----
     constexpr bool REG = CAP <= 4096;
     constexpr int PERK = REG ? CAP / kSortThreads : 1;
     uint64_t kreg[PERK];
@@ -233,7 +290,8 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
 #pragma unroll
         for (int q = 0; q < PERK; ++q) {
             const uint32_t i = tid + q * kSortThreads;
-            kreg[q] = i < n ? src[i] : ~0ull;
+            const uint64_t k = src[min(i, n - 1)];   // unconditional (clamped) so that all loads are in flight together
+            kreg[q] = i < n ? k : ~0ull;
         }
     }
     // ---- key range ----
@@ -255,27 +313,30 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
     }
     if (lane == 0) { s_red[2 * wid] = kmin; s_red[2 * wid + 1] = kmax; }
     for (int b = tid; b < NB; b += kSortThreads) s_cnt[b] = 0;
-    if (tid == 0) s_flag = 0;
+    if (tid == 0) *s_flag = 0;
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < kSortThreads / LSR_WAVE; ++w) {
+    for (int w = 0; w < kWaves; ++w) {
         kmin = s_red[2 * w] < kmin ? s_red[2 * w] : kmin;
         kmax = s_red[2 * w + 1] > kmax ? s_red[2 * w + 1] : kmax;
     }
+    LSR_STAMP(1);
     const uint64_t range = kmax - kmin;
     const int bits = range ? 64 - __builtin_clzll(range) : 0;      // range < 2^bits
     constexpr int LOGNB = NB == 4096 ? 12 : (NB == 2048 ? 11 : 10);
     const int shift = bits > LOGNB ? bits - LOGNB : 0;
 
-    // ---- histogram, scan ----
+    // ---- histogram (REG: the returning atomic is the key's rank inside its bucket), scan ----
+    uint32_t rnk[PERK];
     if (REG) {
 #pragma unroll
-        for (int q = 0; q < PERK; ++q)
-            if (tid + q * kSortThreads < n) atomicAdd(&s_cnt[(uint32_t)((kreg[q] - kmin) >> shift)], 1u);
+        for (int q = 0; q < PERK; ++q)   // (under the validity test: padding lanes on one dummy word serialise — measured 0.048 -> 0.077 ms)
+            if (tid + q * kSortThreads < n) rnk[q] = atomicAdd(&s_cnt[(uint32_t)((kreg[q] - kmin) >> shift)], 1u);
     } else {
         for (uint32_t i = tid; i < n; i += kSortThreads) atomicAdd(&s_cnt[(uint32_t)((src[i] - kmin) >> shift)], 1u);
     }
     __syncthreads();
+    LSR_STAMP(2);
     constexpr int PER = NB / kSortThreads;
     uint32_t loc[PER], sum = 0, mx = 0;
 #pragma unroll
@@ -284,39 +345,71 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
 #pragma unroll
     for (int off = 1; off < LSR_WAVE; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
     if (lane == LSR_WAVE - 1) s_wsum[wid] = incl;
-    if (mx > kBucketOverflow) s_flag = 1;
+    if (mx > kBucketOverflow) *s_flag = 1;
     __syncthreads();
     uint32_t run = incl - sum;
 #pragma unroll
-    for (int w = 0; w < kSortThreads / LSR_WAVE; ++w) run += w < wid ? s_wsum[w] : 0u;
-    const bool overflow = s_flag != 0;
+    for (int w = 0; w < kWaves; ++w) run += w < wid ? s_wsum[w] : 0u;
+    const bool overflow = *s_flag != 0;
     if (!overflow) {
 #pragma unroll
         for (int q = 0; q < PER; ++q) { s_cnt[tid * PER + q] = run; run += loc[q]; }   // exclusive starts
-        __syncthreads();
-        // ---- scatter into buckets (s_cnt[b] ends up as the END of bucket b) ----
+        __syncthreads();   // also: every thread is done with the aliased scratch
+        LSR_STAMP(3);
         if (REG) {
+            // ---- place: start of the bucket + arrival rank ----
 #pragma unroll
             for (int q = 0; q < PERK; ++q)
-                if (tid + q * kSortThreads < n) s_keys[atomicAdd(&s_cnt[(uint32_t)((kreg[q] - kmin) >> shift)], 1u)] = kreg[q];
+                if (tid + q * kSortThreads < n) s_keys[s_cnt[(uint32_t)((kreg[q] - kmin) >> shift)] + rnk[q]] = kreg[q];
+            __syncthreads();
+            LSR_STAMP(4);
+            // ---- final position of every key: bucket start + number of smaller members ----
+            uint32_t dst[PERK];
+#pragma unroll
+            for (int q = 0; q < PERK; ++q) {
+                dst[q] = 0;
+                if (tid + q * kSortThreads < n) {
+                    const uint64_t key = kreg[q];
+                    const uint32_t b = (uint32_t)((key - kmin) >> shift);
+                    const uint32_t lo = s_cnt[b], hi = b + 1 < (uint32_t)NB ? s_cnt[b + 1] : n;
+                    uint32_t below = 0;
+                    for (uint32_t j = lo; j < hi; j += 4) {
+                        const uint32_t last = hi - 1;
+                        const uint64_t m0 = s_keys[j], m1 = s_keys[min(j + 1, last)], m2 = s_keys[min(j + 2, last)], m3 = s_keys[min(j + 3, last)];
+                        below += (m0 < key) + (j + 1 < hi && m1 < key) + (j + 2 < hi && m2 < key) + (j + 3 < hi && m3 < key);
+                    }
+                    dst[q] = lo + below;
+                }
+            }
+            __syncthreads();   // all reads of the key array done: its storage becomes the index list
+            uint32_t *s_out = (uint32_t *)s_keys;
+#pragma unroll
+            for (int q = 0; q < PERK; ++q)
+                if (tid + q * kSortThreads < n) s_out[dst[q]] = (uint32_t)kreg[q];
+            __syncthreads();
+            LSR_STAMP(5);
+            for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = s_out[i];
+            LSR_STAMP(6);
         } else {
+            // ---- lists beyond the register budget: scatter with a second atomic (s_cnt[b] ends up as the
+            // END of bucket b), then a short insertion sort per bucket ----
             for (uint32_t i = tid; i < n; i += kSortThreads) {
                 const uint64_t k = src[i];
                 s_keys[atomicAdd(&s_cnt[(uint32_t)((k - kmin) >> shift)], 1u)] = k;
             }
-        }
-        __syncthreads();
-        // ---- finish inside each bucket ----
-        for (int b = tid; b < NB; b += kSortThreads) {
-            const uint32_t lo = b ? s_cnt[b - 1] : 0u, hi = s_cnt[b];
-            for (uint32_t i = lo + 1; i < hi; ++i) {
-                const uint64_t k = s_keys[i];
-                uint32_t j = i;
-                while (j > lo && s_keys[j - 1] > k) { s_keys[j] = s_keys[j - 1]; --j; }
-                s_keys[j] = k;
+            __syncthreads();
+            for (int b = tid; b < NB; b += kSortThreads) {
+                const uint32_t lo = b ? s_cnt[b - 1] : 0u, hi = s_cnt[b];
+                for (uint32_t i = lo + 1; i < hi; ++i) {
+                    const uint64_t k = s_keys[i];
+                    uint32_t j = i;
+                    while (j > lo && s_keys[j - 1] > k) { s_keys[j] = s_keys[j - 1]; --j; }
+                    s_keys[j] = k;
+                }
             }
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = (uint32_t)(s_keys[i] & 0xffffffffull);
         }
-        __syncthreads();
     } else {
         // ---- bitonic network over the padded list ----
         uint32_t npad = 2;
@@ -343,9 +436,17 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
                 __syncthreads();
             }
         }
+        for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = (uint32_t)(s_keys[i] & 0xffffffffull);
     }
-    for (uint32_t i = tid; i < n; i += kSortThreads)
-        point_list[start + i] = (uint32_t)(s_keys[i] & 0xffffffffull);
+#ifdef LSR_ENABLE_TRACE
+    if (trace && tid == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trace[8 * (size_t)blockIdx.x + 7] = ((unsigned long long)n << 40) | ((unsigned long long)(xcc & 0xff) << 32) | hwid;
+    }
+#endif
+#undef LSR_STAMP
 }
 
 // Global-memory path for lists longer than the LDS capacity: bottom-up merge sort by one
@@ -359,7 +460,7 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t 
 __global__ void __launch_bounds__(kSortThreads)
 k_sort_tiles_global(int T, uint32_t cap, const uint32_t *__restrict__ tile_start,
                     uint64_t *keys, uint64_t *tmp, uint32_t *__restrict__ point_list) {
-    const size_t vt = (size_t)blockIdx.y * T + blockIdx.x;
+    const size_t vt = blockIdx.x;   // view-major (view, tile)
     const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
     if (n <= cap) return;
     uint64_t *src = keys + start, *dst = tmp + start;
@@ -394,22 +495,56 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     uint32_t *plist = (uint32_t *)(bin + B.point_list);
     const uint32_t *ts = (const uint32_t *)(geom + L.tile_start);
     {
-        dim3 grid((d.num_gaussians + kScatThreads * kScatItems - 1) / (kScatThreads * kScatItems), d.num_views);
         const bool lds = T <= 8192;
+        // Items per thread: the launch should be ONE round of resident workgroups (8 per CU, fewer when
+        // the per-tile counters of a large image take the LDS) — with a fixed 2048 Gaussians per block the
+        // 16-view headline needed 9.2 blocks per CU and ran a second, 15 %-full round (phase trace).
+        const int64_t resident = (int64_t)device_cus() * (lds ? std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / ((int64_t)T * 8 + 64))) : 8);
+        const int64_t work = (int64_t)d.num_views * d.num_gaussians;
+        const int64_t rounds = (work + resident * kScatThreads * kScatItems - 1) / (resident * kScatThreads * kScatItems);
+        int items = (int)((work + resident * kScatThreads * rounds - 1) / (resident * kScatThreads * rounds));
+        items = std::max(1, std::min(kScatItems, items));
+        const uint32_t chunks = (uint32_t)((d.num_gaussians + kScatThreads * items - 1) / (kScatThreads * items));
+        dim3 grid(chunks * (uint32_t)d.num_views);
+        unsigned long long *strace = nullptr;
+#ifdef LSR_ENABLE_TRACE
+        const char *strace_path = getenv("LSR_TRACE_SCATTER");
+        if (strace_path) {
+            (void)hipMalloc((void **)&strace, (size_t)grid.x * 64);
+            (void)hipMemsetAsync(strace, 0, (size_t)grid.x * 64, s);
+        }
+#endif
         prof_begin(kStScatter, s);
         const uint32_t capacity = (uint32_t)(num_pairs < 0xFFFFFFFFll ? num_pairs : 0xFFFFFFFFll);
 #define LSR_SCAT(LDSR, CHK, SHM)                                                                          \
     hipLaunchKernelGGL((k_scatter<LDSR, CHK>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T,  \
-                       (const BinRec *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity)
+                       (const BinRec *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, strace)
         if (lds) { if (device_counts) LSR_SCAT(true, true, (size_t)T * 8); else LSR_SCAT(true, false, (size_t)T * 8); }
         else { if (device_counts) LSR_SCAT(false, true, 0); else LSR_SCAT(false, false, 0); }
 #undef LSR_SCAT
         prof_end(kStScatter, s);
+#ifdef LSR_ENABLE_TRACE
+        if (strace_path) {
+            std::vector<unsigned long long> host((size_t)grid.x * 8);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(host.data(), strace, host.size() * 8, hipMemcpyDeviceToHost);
+            if (FILE *f = fopen(strace_path, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+            (void)hipFree(strace);
+        }
+#endif
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     {
-        dim3 grid(T, d.num_views);
+        dim3 grid((uint32_t)T * (uint32_t)d.num_views);
+        unsigned long long *trace = nullptr;
+#ifdef LSR_ENABLE_TRACE
+        const char *trace_path = getenv("LSR_TRACE_SORT");
+        if (trace_path) {
+            (void)hipMalloc((void **)&trace, (size_t)grid.x * 64);
+            (void)hipMemsetAsync(trace, 0, (size_t)grid.x * 64, s);
+        }
+#endif
         int cap;
         uint32_t longer_than = 0;
         prof_begin(kStSort, s);
@@ -422,7 +557,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
                                       CAPV * 8 + (CAPV < 2048 ? CAPV : 2048) * 4);               \
         hipLaunchKernelGGL((k_sort_tiles<CAPV>), grid, dim3(kSortThreads),                       \
                            (size_t)CAPV * 8 + (size_t)(CAPV < 2048 ? CAPV : 2048) * 4, s,        \
-                           T, ts, (const uint64_t *)keys, plist, longer_than);                   \
+                           T, ts, (const uint64_t *)keys, plist, longer_than, trace);            \
     } while (0)
         if (max_tile_pairs <= 1024) LSR_SORT(1024);
         else if (max_tile_pairs <= 2048) LSR_SORT(2048);
@@ -447,6 +582,15 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
             if (e != hipSuccess) return e;
         }
         prof_end(kStSort, s);
+#ifdef LSR_ENABLE_TRACE
+        if (trace_path) {
+            std::vector<unsigned long long> host((size_t)grid.x * 8);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(host.data(), trace, host.size() * 8, hipMemcpyDeviceToHost);
+            if (FILE *f = fopen(trace_path, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+            (void)hipFree(trace);
+        }
+#endif
     }
     return hipSuccess;
 }
