@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LSR_ABI_VERSION 4
+#define LSR_ABI_VERSION 5
 #define LSR_TILE 16            /* tile edge in pixels (16x16 = the published algorithm's tile) */
 #define LSR_MAX_FEAT_CHANNELS 32
 #define LSR_MAX_SH_DEGREE 4
@@ -152,10 +152,13 @@ typedef struct lsr_in_grads { /* shapes follow the inputs: (G,..) when the strid
 /* Debug / test view of the workspaces (byte offsets from the respective workspace base). */
 typedef struct lsr_layout {
     /* geom_rec: [V*G][geom_rec_floats] f32 = x_pix y_pix conicA conicB conicC opacity z clampbits payload...
-     * geom_bin: [V*G] {u16 rect[4]; f32 depth; i32 radius} */
+     * geom_bin: [V*G] records of geom_bin_stride bytes: 8 = {u8 rect[4] (minx miny maxx maxy, in tiles); f32 depth}
+     *           when the tile grid fits byte coordinates, else 16 = {u16 rect[4]; f32 depth; u32 unused};
+     *           depth 0 = culled */
     size_t geom_rec, geom_rec_floats, geom_bin, geom_tile_count, geom_tile_start, geom_header;
     size_t bin_keys, bin_point_list;
     size_t img_final_T, img_n_contrib;
+    size_t geom_bin_stride;
 } lsr_layout;
 
 int lsr_abi_version(void);

@@ -265,6 +265,7 @@ int lsr_get_layout(const lsr_dims *d, int64_t num_pairs, lsr_layout *out) {
     out->geom_tile_count = L.tile_count; out->geom_tile_start = L.tile_start; out->geom_header = L.header;
     out->bin_keys = B.keys; out->bin_point_list = B.point_list;
     out->img_final_T = I.final_T; out->img_n_contrib = I.n_contrib;
+    out->geom_bin_stride = bin_stride(*d);
     return LSR_OK;
 }
 

@@ -146,9 +146,9 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror
 constexpr int kScatThreads = 256;
 constexpr int kScatItems = 12;   // most (view, Gaussian) items of one thread; the launcher picks the count
 
-template <bool LDS_RESERVE, bool CHECK>
+template <bool LDS_RESERVE, bool CHECK, bool NARROW>
 __global__ void __launch_bounds__(kScatThreads, 8)
-k_scatter(int G, int gx, int T, const BinRec *__restrict__ binrec,
+k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
           const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ tile_cursor,
           uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, unsigned long long *trace) {
 #ifdef LSR_ENABLE_TRACE
@@ -165,29 +165,39 @@ k_scatter(int G, int gx, int T, const BinRec *__restrict__ binrec,
     const uint32_t *ts = tile_start + (size_t)v * T;
     uint32_t *cur = tile_cursor + (size_t)v * T;
     const int base = (int)(unit % chunks) * (kScatThreads * items);
-    // rectangles stay PACKED in registers (x0 | y0 << 16, x1 | y1 << 16) between the two passes; the
-    // empty asm makes each pass unpack its own copy instead of keeping four coordinates per item live
-    uint32_t lo16[kScatItems], hi16[kScatItems];
+    // rectangles stay PACKED in registers between the two passes (narrow records: one word, wide: x0 | y0 << 16,
+    // x1 | y1 << 16); the empty asm makes each pass unpack its own copy instead of keeping four coordinates
+    // per item live
+    uint32_t lo16[kScatItems], hi16[NARROW ? 1 : kScatItems];
     float dep[kScatItems];
     // unconditional loads at clamped addresses (all in flight together; a load under a per-lane condition
     // makes the compiler wait for each one), invalid items become empty rectangles afterwards
-    const BinRec *bv = binrec + vo;
 #pragma unroll
     for (int it = 0; it < kScatItems; ++it) {
         const int i = base + min(it, items - 1) * kScatThreads + (int)threadIdx.x;
-        const uint3 br = *(const uint3 *)(bv + min(i, G - 1));   // rectangle + depth bits (the radius word is not needed)
         const bool valid = it < items && i < G;
-        lo16[it] = br.x; hi16[it] = valid ? br.y : 0u; dep[it] = __uint_as_float(br.z);
+        if (NARROW) {
+            const uint2 br = *(const uint2 *)(binrec + (vo + min(i, G - 1)) * sizeof(BinRec));
+            lo16[it] = valid ? br.x : 0u; dep[it] = __uint_as_float(br.y);
+        } else {
+            const uint3 br = *(const uint3 *)(binrec + (vo + min(i, G - 1)) * sizeof(BinRecWide));   // rectangle + depth bits
+            lo16[it] = br.x; hi16[NARROW ? 0 : it] = valid ? br.y : 0u; dep[it] = __uint_as_float(br.z);
+        }
     }
+    auto unpack = [&](int it, int &x0, int &y0, int &x1, int &y1) {
+        uint32_t a = lo16[it], b = NARROW ? 0u : hi16[NARROW ? 0 : it];
+        asm volatile("" : "+v"(a), "+v"(b));
+        if (NARROW) { x0 = a & 0xff; y0 = (a >> 8) & 0xff; x1 = (a >> 16) & 0xff; y1 = a >> 24; }
+        else { x0 = a & 0xffff; y0 = a >> 16; x1 = b & 0xffff; y1 = b >> 16; }
+    };
     if (LDS_RESERVE) {
         for (int t = threadIdx.x; t < T; t += kScatThreads) s_cnt[t] = 0;
         __syncthreads();
         LSR_STAMP(1);
 #pragma unroll
         for (int it = 0; it < kScatItems; ++it) {
-            uint32_t a = lo16[it], b = hi16[it];
-            asm volatile("" : "+v"(a), "+v"(b));
-            const int x0 = a & 0xffff, y0 = a >> 16, x1 = b & 0xffff, y1 = b >> 16;
+            int x0, y0, x1, y1;
+            unpack(it, x0, y0, x1, y1);
             for (int y = y0; y < y1; ++y)
                 for (int x = x0; x < x1; ++x) atomicAdd(&s_cnt[y * gx + x], 1u);
         }
@@ -206,9 +216,8 @@ k_scatter(int G, int gx, int T, const BinRec *__restrict__ binrec,
 #pragma unroll
     for (int it = 0; it < kScatItems; ++it) {
         const uint32_t i = (uint32_t)(base + it * kScatThreads) + tid2;
-        uint32_t a = lo16[it], b = hi16[it];
-        asm volatile("" : "+v"(a), "+v"(b));
-        const int x0 = a & 0xffff, y0 = a >> 16, x1 = b & 0xffff, y1 = b >> 16;
+        int x0, y0, x1, y1;
+        unpack(it, x0, y0, x1, y1);
         if (x1 <= x0 || y1 <= y0) continue;
         const uint64_t key = ((uint64_t)__float_as_uint(dep[it]) << 32) | i;
         for (int y = y0; y < y1; ++y)
@@ -516,12 +525,14 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
 #endif
         prof_begin(kStScatter, s);
         const uint32_t capacity = (uint32_t)(num_pairs < 0xFFFFFFFFll ? num_pairs : 0xFFFFFFFFll);
-#define LSR_SCAT(LDSR, CHK, SHM)                                                                          \
-    hipLaunchKernelGGL((k_scatter<LDSR, CHK>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T,  \
-                       (const BinRec *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, strace)
+#define LSR_SCAT2(LDSR, CHK, NRW, SHM)                                                                         \
+    hipLaunchKernelGGL((k_scatter<LDSR, CHK, NRW>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T,  \
+                       (const char *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, strace)
+#define LSR_SCAT(LDSR, CHK, SHM) do { if (narrow_bins(d)) LSR_SCAT2(LDSR, CHK, true, SHM); else LSR_SCAT2(LDSR, CHK, false, SHM); } while (0)
         if (lds) { if (device_counts) LSR_SCAT(true, true, (size_t)T * 8); else LSR_SCAT(true, false, (size_t)T * 8); }
         else { if (device_counts) LSR_SCAT(false, true, 0); else LSR_SCAT(false, false, 0); }
 #undef LSR_SCAT
+#undef LSR_SCAT2
         prof_end(kStScatter, s);
 #ifdef LSR_ENABLE_TRACE
         if (strace_path) {

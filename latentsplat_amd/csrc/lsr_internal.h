@@ -52,12 +52,22 @@ inline int rec_floats(const lsr_dims &d) {
     const int nch = (d.color_mode != LSR_COLOR_NONE ? 3 : 0) + d.feat_channels;
     return nch <= 8 ? 16 : (nch <= 12 ? 32 : 64);   // always >= 8 + the compositing kernels' padded channel count
 }
-// What the binning stage needs of a Gaussian, kept dense (16 B) so k_scatter streams it.
-struct BinRec {
-    ushort4 rect;      // tile rectangle [minx, miny, maxx, maxy)
-    float depth;       // view z (sort key bits)
-    int32_t radius;    // screen radius in pixels, 0 = culled
+// What the binning stage needs of a (view, Gaussian), kept dense so k_scatter streams it: the tile
+// rectangle [minx, miny, maxx, maxy) and the view depth (sort key bits; 0 = culled).  Written for ALL
+// V*G slots by k_preprocess and read back once by k_scatter — both stages are bandwidth-bound, so the
+// record is 8 bytes whenever the tile grid fits byte coordinates (images up to 4080 px a side) and
+// 16 bytes otherwise.
+struct BinRec {            // narrow form
+    uint32_t rect;         // minx | miny << 8 | maxx << 16 | maxy << 24
+    float depth;
 };
+struct BinRecWide {
+    ushort4 rect;
+    float depth;
+    uint32_t unused;
+};
+inline bool narrow_bins(const lsr_dims &d) { return tiles_x(d) <= 255 && tiles_y(d) <= 255; }
+inline size_t bin_stride(const lsr_dims &d) { return narrow_bins(d) ? sizeof(BinRec) : sizeof(BinRecWide); }
 
 inline GeomLayout geom_layout(const lsr_dims &d) {
     GeomLayout L;
@@ -66,7 +76,7 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     size_t o = 0;
     L.rec_floats = rec_floats(d);
     L.rec = o; o = align_up(o + VG * (size_t)L.rec_floats * 4);
-    L.bin = o; o = align_up(o + VG * sizeof(BinRec));
+    L.bin = o; o = align_up(o + VG * bin_stride(d));
     L.header = o; o += 256;                        // header .. tile_cursor are cleared by ONE memset per forward
     L.tile_count = o; o = align_up(o + VT * 4);
     L.tile_cursor = o; o = align_up(o + VT * 4);   // adjacent to tile_count: one memset clears both

@@ -28,7 +28,7 @@ constexpr int kPreItems = 8;  // (Gaussian, view) items per thread: 2048 per blo
 // factor, so the grid keeps its size.
 template <int COLOR_MODE, bool LDS_HIST, int VB>
 __global__ void __launch_bounds__(kPreThreads)
-k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec *__restrict__ binrec,
+k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *__restrict__ binrec, int narrow,
              int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count) {
     extern __shared__ uint32_t s_hist[];   // [VB][T] pair counts
     // 64-byte records are staged here and stored by the whole block as one contiguous run
@@ -179,8 +179,15 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, BinRec 
             } while (0);
             if (in_range) {
                 radii[o] = out_radius;
-                BinRec br; br.rect = out_rect; br.depth = out_depth; br.radius = out_radius;
-                binrec[o] = br;
+                if (narrow) {
+                    BinRec br;
+                    br.rect = (uint32_t)out_rect.x | ((uint32_t)out_rect.y << 8) | ((uint32_t)out_rect.z << 16) | ((uint32_t)out_rect.w << 24);
+                    br.depth = out_depth;
+                    ((BinRec *)binrec)[o] = br;
+                } else {
+                    BinRecWide br; br.rect = out_rect; br.depth = out_depth; br.unused = 0u;
+                    ((BinRecWide *)binrec)[o] = br;
+                }
             }
             if (staged) {
 #pragma unroll
@@ -240,12 +247,13 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     const int items = kPreItems / vb;
     dim3 grid((d.num_gaussians + kPreThreads * items - 1) / (kPreThreads * items), (d.num_views + vb - 1) / vb);
     float *rec = (float *)(geom + L.rec);
-    BinRec *binrec = (BinRec *)(geom + L.bin);
+    char *binrec = geom + L.bin;
+    const int narrow = narrow_bins(d) ? 1 : 0;
     const int RF = L.rec_floats;
     uint32_t *tc = (uint32_t *)(geom + L.tile_count);
     const bool lds = (size_t)T * vb <= 4096;
     const size_t shm = lds ? (size_t)T * vb * 4 : 0;
-#define LSR_PRE2(CM, LH, VBV) hipLaunchKernelGGL((k_preprocess<CM, LH, VBV>), grid, dim3(kPreThreads), shm, s, d, in, rec, RF, binrec, radii, tc)
+#define LSR_PRE2(CM, LH, VBV) hipLaunchKernelGGL((k_preprocess<CM, LH, VBV>), grid, dim3(kPreThreads), shm, s, d, in, rec, RF, binrec, narrow, radii, tc)
 #define LSR_PRE(CM)                                                                              \
     do {                                                                                         \
         if (lds) { if (vb == 4) LSR_PRE2(CM, true, 4); else if (vb == 2) LSR_PRE2(CM, true, 2); else LSR_PRE2(CM, true, 1); } \

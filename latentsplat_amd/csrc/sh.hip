@@ -40,7 +40,8 @@ constexpr int kShBasisF = 11;   // 9 + zero slot, odd stride
 struct ShParams {
     lsr_dims d;
     lsr_inputs in;
-    const BinRec *binrec;     // radius > 0 <=> visible
+    const float *vis;         // depth word of the (view, Gaussian) bin records: > 0 <=> visible
+    int vis_stride;           // in floats (2 narrow, 4 wide records)
     float *rec;               // screen-space records (forward writes the payload slots)
     uint8_t *clamp;           // [V*G] bit c set: colour channel c clamped at 0
     const float *grec;        // backward: packed gradient records
@@ -145,7 +146,7 @@ k_sh_fwd(ShParams p) {
 
     auto compute = [&](int v) {
         const size_t o = (size_t)v * G + (active ? i : 0);
-        if (!(active && p.binrec[o].radius > 0)) return;
+        if (!(active && p.vis[o * p.vis_stride] > 0.0f)) return;
         const ShDir dir = sh_direction(p, v, i);
         float *R = p.rec + o * (size_t)p.RF + 8;
         float basF[9];
@@ -255,7 +256,7 @@ k_sh_bwd(ShParams p) {
         // ---- pass 1: thread = (view v0 + wave, Gaussian lane) ----
         const int v = v0 + wave;
         const size_t o = (size_t)v * G + (active ? i : 0);
-        const bool vis = wave < nv && active && p.binrec[o].radius > 0;
+        const bool vis = wave < nv && active && p.vis[o * p.vis_stride] > 0.0f;
         float *mg = s_gch + (wave * LSR_WAVE + lane) * cs;
         if (vis) {
             const ShDir dir = sh_direction(p, v, i);
@@ -409,7 +410,9 @@ static uint32_t mdiv_of(int x) { return x > 0 ? (uint32_t)(((1u << 22) + x - 1) 
 static ShParams make_params(const lsr_dims &d, const lsr_inputs &in, const GeomLayout &L, const char *geom, int view0) {
     ShParams p;
     const size_t off = (size_t)view0 * (size_t)d.num_gaussians;   // first (view, Gaussian) slot of this launch
-    p.d = d; p.in = in; p.binrec = (const BinRec *)(geom + L.bin) + off;
+    p.d = d; p.in = in;
+    p.vis_stride = (int)(bin_stride(d) / 4);
+    p.vis = (const float *)(geom + L.bin) + off * (size_t)p.vis_stride + (narrow_bins(d) ? 1 : 2);
     p.rec = (float *)const_cast<char *>(geom + L.rec) + off * L.rec_floats;
     p.clamp = (uint8_t *)const_cast<char *>(geom + L.sh_clamp) + off;
     p.grec = nullptr; p.RF = L.rec_floats; p.g = lsr_in_grads{};

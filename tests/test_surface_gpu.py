@@ -363,13 +363,17 @@ def test_device_camera_table_matches_host_math(hip_device):
 
 def test_large_image_uses_global_histogram_paths(hip_device):
     """More than 4096 / 8192 tiles: the LDS-privatised tile histograms of k_preprocess / k_scatter
-    fall back to global atomics; results must not change."""
-    for H, W in ((1040, 1024), (1552, 1408)):       # 65*64 = 4160 tiles, 97*88 = 8536 tiles
-        sc = util.make_scene(1500, image_size=max(H, W), views=1, color_sh_degree=1, feature_channels=4,
+    fall back to global atomics; results must not change.
+    The last shape has 257 tile columns: tile rectangles no longer fit the 8-byte bin records (byte
+    coordinates) and the 16-byte form is used."""
+    for H, W, G in ((1040, 1024, 1500), (1552, 1408, 1500), (48, 4112, 20000)):       # 65*64 = 4160 tiles, 97*88 = 8536 tiles, 3*257
+        sc = util.make_scene(G, image_size=max(H, W), views=1, color_sh_degree=1, feature_channels=4,
                              sigma_px=(2.0, 40.0), opacity_scale=1.0)
         bi = util.boundary_inputs(sc, H, W, bg=(0.1, 0.2, 0.3))
         run = util.HipRun(bi, hip_device)
         o = util.oracle_forward(bi, 0)
+        assert run.layout.geom_bin_stride == (16 if W > 4080 else 8)
+        np.testing.assert_array_equal(run.rect()[0], o["rect"])
         np.testing.assert_array_equal(run.radii[0].cpu().numpy(), o["radii"])
         ts = run.tile_start()
         np.testing.assert_array_equal(np.diff(ts), o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0])

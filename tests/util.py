@@ -129,6 +129,10 @@ class HipRun:
 
     def rect(self):
         n = self.d.num_views * self.d.num_gaussians
+        if self.layout.geom_bin_stride == 8:   # narrow records: u8 tile coordinates
+            b = self._view(self.geom, self.layout.geom_bin, n * 8, torch.uint8).cpu().numpy().astype(np.int32).reshape(
+                self.d.num_views, self.d.num_gaussians, 8)
+            return b[:, :, :4]
         b = self._view(self.geom, self.layout.geom_bin, n * 16, torch.int16).cpu().numpy().astype(np.int32).reshape(
             self.d.num_views, self.d.num_gaussians, 8)
         return b[:, :, :4] & 0xFFFF
