@@ -18,6 +18,8 @@ __device__ __forceinline__ float ndc2pix(float v, int S) {
     return (float)(((v + 1.0) * S - 1.0) * 0.5);
 }
 
+typedef const float __attribute__((address_space(4))) *kfloat_ptr;   // constant address space: uniform loads become s_load
+
 constexpr int kPreThreads = 256;
 constexpr int kPreItems = 8;  // (Gaussian, view) items per thread: 2048 per block, one histogram flush each
 
@@ -43,10 +45,15 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
     const int G = d.num_gaussians;
     const int gx = (d.width + LSR_TILE - 1) / LSR_TILE, gy = (d.height + LSR_TILE - 1) / LSR_TILE;
     const int T = gx * gy;
-    if (LDS_HIST) {
-        for (int t = threadIdx.x; t < VB * T; t += kPreThreads) s_hist[t] = 0;
-        __syncthreads();
+    // per-view constants that cost an IEEE division each: once per block, not once per (Gaussian, view)
+    __shared__ float2 s_focal[VB];
+    if (threadIdx.x < VB && v0 + (int)threadIdx.x < d.num_views) {
+        const float *vw = in.views + (size_t)(v0 + threadIdx.x) * LSR_VIEW_FLOATS;
+        s_focal[threadIdx.x] = make_float2(d.width / (2.0f * vw[35]), d.height / (2.0f * vw[36]));
     }
+    if (LDS_HIST)
+        for (int t = threadIdx.x; t < VB * T; t += kPreThreads) s_hist[t] = 0;
+    __syncthreads();
     const int ce = d.cov_elems;
     const size_t sl = (size_t)input_slice(d, v0);   // the input slice all views of this block read
     const float *means = in.means3D + sl * d.vs_means;
@@ -76,98 +83,97 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
             pay_in[0] = cp[0]; pay_in[1] = cp[1]; pay_in[2] = cp[2];
         }
         const float *fp = in.features + sl * d.vs_feat + ii * d.feat_channels;
+        // payload slots 8.. : rgb (if any; SH colour is filled in by sh.hip) then the feature channels,
+        // zero padded.  View independent, so the two words of a 64-byte record are built once per Gaussian.
+        auto payload = [&](int c4) {
+            float w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = 4 * c4 + k;
+                w[k] = c < coff ? pay_in[c < 3 ? c : 0]
+                                : ((direct_feat && c - coff < d.feat_channels) ? fp[c - coff] : 0.0f);
+            }
+            return make_float4(w[0], w[1], w[2], w[3]);
+        };
+        float4 pay0 = make_float4(0, 0, 0, 0), pay1 = make_float4(0, 0, 0, 0);
+        if (staged) { pay0 = payload(0); pay1 = payload(1); }
 
 #pragma unroll 1
         for (int vb = 0; vb < VB; ++vb) {
             const int v = v0 + vb;
             if (v >= d.num_views) break;   // block-uniform
-            const float *vw = in.views + (size_t)v * LSR_VIEW_FLOATS;
+            // the camera goes through the scalar cache into SGPRs (constant address space: the table was
+            // written by an earlier launch), not through 44 broadcast vector loads per lane
+            const kfloat_ptr vw = (kfloat_ptr)(in.views + (size_t)v * LSR_VIEW_FLOATS);
             float vm[16], pm[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) { vm[k] = vw[k]; pm[k] = vw[16 + k]; }
             const float tanfovx = vw[35], tanfovy = vw[36];
-            const float focal_x = d.width / (2.0f * tanfovx);
-            const float focal_y = d.height / (2.0f * tanfovy);
+            const float focal_x = s_focal[vb].x, focal_y = s_focal[vb].y;   // = width / (2 tan), height / (2 tan)
             const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
             const float scale = vw[40], scale2 = scale * scale;   // scene scale (1/near), applied like the reference does
             uint32_t *tc = tile_count + (size_t)v * T;
             uint32_t *hist = s_hist + vb * T;
             const size_t o = (size_t)v * G + ii;
             const float p0 = q0 * scale, p1 = q1 * scale, p2 = q2 * scale;
-            float4 rr[4] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-            int32_t out_radius = 0;
-            float out_depth = 0.0f;
-            ushort4 out_rect = make_ushort4(0, 0, 0, 0);
-            do {
-                if (!in_range) break;
-                const float t0 = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
-                const float t1 = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
-                const float t2 = vm[2] * p0 + vm[6] * p1 + vm[10] * p2 + vm[14];
-                if (t2 <= LSR_NEAR_CULL) break;
-                const float h0 = pm[0] * p0 + pm[4] * p1 + pm[8] * p2 + pm[12];
-                const float h1 = pm[1] * p0 + pm[5] * p1 + pm[9] * p2 + pm[13];
-                const float h3 = pm[3] * p0 + pm[7] * p1 + pm[11] * p2 + pm[15];
-                const float p_w = 1.0f / (h3 + 0.0000001f);
-                const float ndc_x = h0 * p_w, ndc_y = h1 * p_w;
+            // ONE visibility predicate instead of nested early exits (each exit level made the compiler
+            // re-materialise the zeroed outputs): culled lanes run the arithmetic on whatever they hold
+            // (IEEE special values are harmless here) and are masked where results leave the thread.
+            const float t0 = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
+            const float t1 = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
+            const float t2 = vm[2] * p0 + vm[6] * p1 + vm[10] * p2 + vm[14];
+            bool ok = in_range && !(t2 <= LSR_NEAR_CULL);
+            const float h0 = pm[0] * p0 + pm[4] * p1 + pm[8] * p2 + pm[12];
+            const float h1 = pm[1] * p0 + pm[5] * p1 + pm[9] * p2 + pm[13];
+            const float h3 = pm[3] * p0 + pm[7] * p1 + pm[11] * p2 + pm[15];
+            const float p_w = 1.0f / (h3 + 0.0000001f);
+            const float ndc_x = h0 * p_w, ndc_y = h1 * p_w;
 
-                const float txtz = t0 / t2, tytz = t1 / t2;
-                const float tx = fmin_sel(limx, fmax_sel(-limx, txtz)) * t2;
-                const float ty = fmin_sel(limy, fmax_sel(-limy, tytz)) * t2;
-                const float tz = t2;
-                const float j00 = focal_x / tz, j02 = -(focal_x * tx) / (tz * tz);
-                const float j11 = focal_y / tz, j12 = -(focal_y * ty) / (tz * tz);
-                const float m00 = j00 * vm[0] + j02 * vm[2];
-                const float m01 = j00 * vm[4] + j02 * vm[6];
-                const float m02 = j00 * vm[8] + j02 * vm[10];
-                const float m10 = j11 * vm[1] + j12 * vm[2];
-                const float m11 = j11 * vm[5] + j12 * vm[6];
-                const float m12 = j11 * vm[9] + j12 * vm[10];
-                const float s0 = r0 * scale2, s1 = r1 * scale2, s2 = r2 * scale2;
-                const float s3 = r3 * scale2, s4 = r4 * scale2, s5 = r5 * scale2;
-                const float v00 = s0 * m00 + s1 * m01 + s2 * m02;
-                const float v01 = s1 * m00 + s3 * m01 + s4 * m02;
-                const float v02 = s2 * m00 + s4 * m01 + s5 * m02;
-                const float v10 = s0 * m10 + s1 * m11 + s2 * m12;
-                const float v11 = s1 * m10 + s3 * m11 + s4 * m12;
-                const float v12 = s2 * m10 + s4 * m11 + s5 * m12;
-                const float ca = (m00 * v00 + m01 * v01 + m02 * v02) + LSR_LOWPASS;
-                const float cb = m00 * v10 + m01 * v11 + m02 * v12;
-                const float cc = (m10 * v10 + m11 * v11 + m12 * v12) + LSR_LOWPASS;
-                const float det = ca * cc - cb * cb;
-                if (det == 0.0f) break;
-                const float det_inv = 1.0f / det;
-                const float conic_a = cc * det_inv, conic_b = -cb * det_inv, conic_c = ca * det_inv;
-                const float mid = 0.5f * (ca + cc);
-                const float disc = sqrtf(fmax_sel(0.1f, mid * mid - det));
-                const float lambda1 = mid + disc, lambda2 = mid - disc;
-                const float my_radius = ceilf(3.0f * sqrtf(fmax_sel(lambda1, lambda2)));
-                const float px = ndc2pix(ndc_x, d.width), py = ndc2pix(ndc_y, d.height);
-                const int rminx = imin_sel(gx, imax_sel(0, (int)((px - my_radius) / LSR_TILE)));
-                const int rminy = imin_sel(gy, imax_sel(0, (int)((py - my_radius) / LSR_TILE)));
-                const int rmaxx = imin_sel(gx, imax_sel(0, (int)((px + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
-                const int rmaxy = imin_sel(gy, imax_sel(0, (int)((py + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
-                if ((rmaxx - rminx) * (rmaxy - rminy) == 0) break;
+            const float txtz = t0 / t2, tytz = t1 / t2;
+            const float tx = fmin_sel(limx, fmax_sel(-limx, txtz)) * t2;
+            const float ty = fmin_sel(limy, fmax_sel(-limy, tytz)) * t2;
+            const float tz = t2;
+            const float j00 = focal_x / tz, j02 = -(focal_x * tx) / (tz * tz);
+            const float j11 = focal_y / tz, j12 = -(focal_y * ty) / (tz * tz);
+            const float m00 = j00 * vm[0] + j02 * vm[2];
+            const float m01 = j00 * vm[4] + j02 * vm[6];
+            const float m02 = j00 * vm[8] + j02 * vm[10];
+            const float m10 = j11 * vm[1] + j12 * vm[2];
+            const float m11 = j11 * vm[5] + j12 * vm[6];
+            const float m12 = j11 * vm[9] + j12 * vm[10];
+            const float s0 = r0 * scale2, s1 = r1 * scale2, s2 = r2 * scale2;
+            const float s3 = r3 * scale2, s4 = r4 * scale2, s5 = r5 * scale2;
+            const float v00 = s0 * m00 + s1 * m01 + s2 * m02;
+            const float v01 = s1 * m00 + s3 * m01 + s4 * m02;
+            const float v02 = s2 * m00 + s4 * m01 + s5 * m02;
+            const float v10 = s0 * m10 + s1 * m11 + s2 * m12;
+            const float v11 = s1 * m10 + s3 * m11 + s4 * m12;
+            const float v12 = s2 * m10 + s4 * m11 + s5 * m12;
+            const float ca = (m00 * v00 + m01 * v01 + m02 * v02) + LSR_LOWPASS;
+            const float cb = m00 * v10 + m01 * v11 + m02 * v12;
+            const float cc = (m10 * v10 + m11 * v11 + m12 * v12) + LSR_LOWPASS;
+            const float det = ca * cc - cb * cb;
+            ok = ok && !(det == 0.0f);
+            const float det_inv = 1.0f / det;
+            const float conic_a = cc * det_inv, conic_b = -cb * det_inv, conic_c = ca * det_inv;
+            const float mid = 0.5f * (ca + cc);
+            const float disc = sqrtf(fmax_sel(0.1f, mid * mid - det));
+            const float lambda1 = mid + disc, lambda2 = mid - disc;
+            const float my_radius = ceilf(3.0f * sqrtf(fmax_sel(lambda1, lambda2)));
+            const float px = ndc2pix(ndc_x, d.width), py = ndc2pix(ndc_y, d.height);
+            const int rminx = imin_sel(gx, imax_sel(0, (int)((px - my_radius) / LSR_TILE)));
+            const int rminy = imin_sel(gy, imax_sel(0, (int)((py - my_radius) / LSR_TILE)));
+            const int rmaxx = imin_sel(gx, imax_sel(0, (int)((px + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
+            const int rmaxy = imin_sel(gy, imax_sel(0, (int)((py + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
+            ok = ok && (rmaxx - rminx) * (rmaxy - rminy) != 0;
 
-                float4 *R = (float4 *)(rec + o * (size_t)RF);
-                out_radius = (int32_t)my_radius;
-                out_rect = make_ushort4((unsigned short)rminx, (unsigned short)rminy,
-                                        (unsigned short)rmaxx, (unsigned short)rmaxy);
-                out_depth = tz;
-                rr[0] = make_float4(px, py, conic_a, conic_b);
-                rr[1] = make_float4(conic_c, opacity, tz, 0.0f);
-                if (!staged) { R[0] = rr[0]; R[1] = rr[1]; }
-                {   // payload slots 8.. : rgb (if any; SH colour is filled in by sh.hip) then the feature channels, zero padded
-                    for (int c4 = 0; c4 < (RF - 8) / 4; ++c4) {
-                        float w[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int c = 4 * c4 + k;
-                            w[k] = c < coff ? pay_in[c < 3 ? c : 0]
-                                            : ((direct_feat && c - coff < d.feat_channels) ? fp[c - coff] : 0.0f);
-                        }
-                        if (staged) rr[c4 < 2 ? 2 + c4 : 2] = make_float4(w[0], w[1], w[2], w[3]);
-                        else R[2 + c4] = make_float4(w[0], w[1], w[2], w[3]);
-                    }
+            const float4 rr0 = make_float4(px, py, conic_a, conic_b);
+            const float4 rr1 = make_float4(conic_c, opacity, ok ? tz : 0.0f, 0.0f);   // view z 0 marks a culled record
+            if (ok) {
+                if (!staged) {
+                    float4 *R = (float4 *)(rec + o * (size_t)RF);
+                    R[0] = rr0; R[1] = rr1;
+                    for (int c4 = 0; c4 < (RF - 8) / 4; ++c4) R[2 + c4] = payload(c4);
                 }
                 // per-tile pair counts (also the compositing kernels' scheduling key: a finer work
                 // estimate — quadrants reached per entry — was measured to schedule no better)
@@ -176,22 +182,28 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
                         if (LDS_HIST) atomicAdd(&hist[y * gx + x], 1u);
                         else atomicAdd(&tc[y * gx + x], 1u);
                     }
-            } while (0);
+            }
             if (in_range) {
-                radii[o] = out_radius;
+                radii[o] = ok ? (int32_t)my_radius : 0;
+                const float out_depth = ok ? tz : 0.0f;
                 if (narrow) {
                     BinRec br;
-                    br.rect = (uint32_t)out_rect.x | ((uint32_t)out_rect.y << 8) | ((uint32_t)out_rect.z << 16) | ((uint32_t)out_rect.w << 24);
+                    br.rect = ok ? ((uint32_t)rminx | ((uint32_t)rminy << 8) | ((uint32_t)rmaxx << 16) | ((uint32_t)rmaxy << 24)) : 0u;
                     br.depth = out_depth;
                     ((BinRec *)binrec)[o] = br;
                 } else {
-                    BinRecWide br; br.rect = out_rect; br.depth = out_depth; br.unused = 0u;
+                    BinRecWide br;
+                    br.rect = ok ? make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy)
+                                 : make_ushort4(0, 0, 0, 0);
+                    br.depth = out_depth; br.unused = 0u;
                     ((BinRecWide *)binrec)[o] = br;
                 }
             }
             if (staged) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) s_rec[k * kRecRow + threadIdx.x] = rr[k];
+                s_rec[0 * kRecRow + threadIdx.x] = rr0;
+                s_rec[1 * kRecRow + threadIdx.x] = rr1;
+                s_rec[2 * kRecRow + threadIdx.x] = pay0;
+                s_rec[3 * kRecRow + threadIdx.x] = pay1;
                 __syncthreads();
                 float4 *dst = (float4 *)(rec + ((size_t)v * G + chunk0) * 16);
                 const int nrec = G - chunk0 < kPreThreads ? G - chunk0 : kPreThreads;
