@@ -99,8 +99,10 @@ def _payload(means: Tensor, campos: Tensor, color_sh: Optional[Tensor], feature_
 
 
 def _squeeze_shared(t: Optional[Tensor]) -> Optional[Tensor]:
-    """(1,G,...) -> (G,...) so the rasterizer treats it as shared by all views."""
-    return t[0] if (t is not None and t.shape[0] == 1) else t
+    """(1,G,...) -> (G,...) so the rasterizer treats it as shared by all views.  ``squeeze`` rather than
+    ``t[0]``: the backward of a select allocates a zero tensor of the full shape and copies the gradient
+    into it (a 174 MB fill + copy for the colour harmonics at configs[3]); squeeze's is a view."""
+    return t.squeeze(0) if (t is not None and t.shape[0] == 1) else t
 
 
 def _view_table(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, background: Tensor,
