@@ -615,9 +615,11 @@ def main():
                                 algorithmic_bytes_per_launch=bwd_bytes, launch_ms=bwd_ms)
         # every stage against the HBM roofline with its own algorithmic bytes
         stage_bytes = dict(
-            preprocess=V * G * (12 + 36 + 4 + 4 * C) + g_vis * (64 + 16) + V * G * 4,
+            # the shared scene is read once per block of 4 views; written: one 64-byte record per visible
+            # (view, Gaussian), an 8-byte bin record and the 4-byte radius for every one
+            preprocess=-(-V // 4) * G * (12 + 36 + 4 + 4 * C) + g_vis * 64 + V * G * (8 + 4),
             tile_scan=V * (S // 16) * (S // 16) * 12,
-            scatter=V * G * 16 + P * 8,
+            scatter=V * G * 8 + P * 8,
             sort_tiles=P * (8 + 4),
             render_forward=render_bytes)
         stage_roofline = {}
