@@ -193,12 +193,18 @@ int lsr_pack_view(const float *viewmatrix, const float *projmatrix, const float 
 
 /* ---- forward, phase 1: per-Gaussian preprocess + per-tile counting + tile offset scan.
  * Writes radii.  Synchronises `stream` once to return the pair count and the longest tile list
- * through the two host pointers (both required). */
+ * through the two host pointers (both required).
+ * Also starts the view-dependent payload pass (colour / latent features from SH), which only depends on
+ * the preprocess: it runs on a library-owned side stream (one per device, forked from `stream` with an
+ * event) while the host fetches the pair count and the binning of phase 2 runs; phase 2 joins it
+ * before compositing.  lsr_forward_nosync does the same inside one call (event fork / join are
+ * captured by a stream capture).  LSR_SH_SIDE_STREAM=0 keeps every launch on `stream`. */
 int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii,
                         int64_t *num_pairs_host, int32_t *max_tile_pairs_host,
                         lsr_stream_t stream);
 
-/* ---- forward, phase 2: binning, per-tile depth sort, front-to-back compositing. Async. */
+/* ---- forward, phase 2: binning, per-tile depth sort, front-to-back compositing. Async.  Must follow
+ * the lsr_forward_prepare of the same geom_ws on the same device (it waits for that call's SH pass). */
 int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, void *bin_ws,
                        void *img_ws, int64_t num_pairs, int32_t max_tile_pairs,
                        const lsr_outputs *out, lsr_stream_t stream);

@@ -186,6 +186,64 @@ static int for_each_view_group(const lsr_dims &d, const lsr_inputs &in, const ls
     }
     return LSR_OK;
 }
+// The SH payload pass (sh.hip) depends on k_preprocess only and touches nothing that tile_scan / scatter /
+// sort read or write, so the forward runs it on a library-owned side stream: forked after the preprocess
+// launch, joined before the compositing launch.  In the synchronous forward this also fills the host's
+// round trip for the pair count (the device used to idle ~45 us there).  One side stream and one pair of
+// events per device, shared by all host threads: stream order on the side stream makes a wait on the
+// LATEST join record cover every earlier fork.  LSR_SH_SIDE_STREAM=0 keeps everything on the caller's stream.
+struct SideCtx {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool tried = false;
+};
+static SideCtx *side_ctx() {
+    if (!env_int("LSR_SH_SIDE_STREAM", 1)) return nullptr;
+    static SideCtx ctx[64];
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    SideCtx &c = ctx[dev];
+    if (!c.tried) {
+        c.tried = true;
+        if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            c.side = nullptr;
+        }
+    }
+    return c.side ? &c : nullptr;
+}
+static bool has_sh_payload(const lsr_dims &d) {
+    return d.num_gaussians > 0 && (d.color_mode == LSR_COLOR_SH || (d.feat_channels > 0 && d.feat_mode == LSR_FEAT_SH));
+}
+// SH forward of all view groups: on the side stream (forked from what is queued on `s` so far; the caller
+// joins with sh_forward_join before the compositing launch), or in line on `s`.
+static int sh_forward_fork(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s) {
+    if (!has_sh_payload(d)) return LSR_OK;
+    SideCtx *c = side_ctx();
+    hipStream_t q = s;
+    if (c) {
+        LSR_HIP(hipEventRecord(c->fork, s));
+        LSR_HIP(hipStreamWaitEvent(c->side, c->fork, 0));
+        q = c->side;
+    }
+    const int rc = for_each_view_group(d, in, nullptr, [&](const lsr_dims &dg, const lsr_inputs &ig, const lsr_in_grads &, const lsr_dims *layout, int view0) -> int {
+        LSR_STAGE("sh_forward", q, launch_sh_forward(dg, ig, geom, q, layout, view0));
+        return LSR_OK;
+    });
+    if (rc) return rc;
+    if (c) LSR_HIP(hipEventRecord(c->join, c->side));
+    return LSR_OK;
+}
+static int sh_forward_join(const lsr_dims &d, hipStream_t s) {
+    if (!has_sh_payload(d)) return LSR_OK;
+    if (SideCtx *c = side_ctx()) LSR_HIP(hipStreamWaitEvent(s, c->join, 0));
+    return LSR_OK;
+}
+
 static int check_inputs(const lsr_dims *d, const lsr_inputs *in) {
     if (!in || !in->views) return LSR_ENULL;
     if (d->num_gaussians > 0) {
@@ -302,6 +360,8 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
     hipStream_t s = (hipStream_t)stream;
     char *geom = (char *)geom_ws;
     LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, s));
+    rc = sh_forward_fork(*d, *in, geom, s);   // view-dependent payload: next to tile_scan, the host round trip and the binning
+    if (rc) return rc;
     // Pair count and longest list come back through a 64-byte pinned, device-mapped host buffer that
     // k_tile_scan writes directly (one per host thread, allocated on first use; the library's only
     // allocation and it is host memory).  Without it: a device-to-host copy command.
@@ -345,12 +405,9 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
     if (num_pairs < 0 || max_tile_pairs < 0) return LSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    rc = for_each_view_group(*d, *in, nullptr, [&](const lsr_dims &dg, const lsr_inputs &ig, const lsr_in_grads &, const lsr_dims *layout, int view0) -> int {
-        LSR_STAGE("sh_forward", s, launch_sh_forward(dg, ig, (char *)geom_ws, s, layout, view0));
-        return LSR_OK;
-    });
-    if (rc) return rc;
     LSR_STAGE("binning", s, launch_binning(*d, (char *)geom_ws, (char *)bin_ws, num_pairs, max_tile_pairs, out->radii, s));
+    rc = sh_forward_join(*d, s);   // the SH payload pass was launched by lsr_forward_prepare
+    if (rc) return rc;
     LSR_STAGE("render_forward", s, launch_render_forward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs, (char *)img_ws, *out, s));
     return LSR_OK;
 }
@@ -371,13 +428,12 @@ int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     char *geom = (char *)geom_ws;
     // the same stage sequence as prepare + render; nothing between the launches waits for the device
     LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, s));
-    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, (uint32_t)pair_capacity, s));
-    rc = for_each_view_group(*d, *in, nullptr, [&](const lsr_dims &dg, const lsr_inputs &ig, const lsr_in_grads &, const lsr_dims *layout, int view0) -> int {
-        LSR_STAGE("sh_forward", s, launch_sh_forward(dg, ig, geom, s, layout, view0));
-        return LSR_OK;
-    });
+    rc = sh_forward_fork(*d, *in, geom, s);
     if (rc) return rc;
+    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, (uint32_t)pair_capacity, s));
     LSR_STAGE("binning", s, launch_binning(*d, geom, (char *)bin_ws, pair_capacity, max_tile_hint, out->radii, s, true));
+    rc = sh_forward_join(*d, s);
+    if (rc) return rc;
     LSR_STAGE("render_forward", s, launch_render_forward(*d, *in, geom, (const char *)bin_ws, pair_capacity, (char *)img_ws, *out, s));
     return LSR_OK;
 }
