@@ -140,3 +140,34 @@ torch.save(a.cpu(), sys.argv[1])
     assert outs["1"][0].startswith("EQUAL True"), outs["1"][0]          # bitwise reproducible
     a, b = outs["1"][1], outs["0"][1]
     assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_sh_side_stream_does_not_change_results(hip_device):
+    """The SH payload pass runs on a library-owned side stream (forked after the preprocess, joined before
+    compositing).  With LSR_SH_SIDE_STREAM=0 (read once per process, hence a subprocess) every launch stays
+    on the caller's stream: both modes must give bitwise identical images, synchronous and no-sync."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch, hashlib
+sys.path.insert(0, %r)
+from tests.test_latency_gpu import _inputs, _render
+dev = torch.device("cuda:0")
+bi, views, t, size = _inputs(dev, G=30000, V=3, size=96, sh=3)
+h = hashlib.sha1()
+for kw in ({}, dict(pair_capacity=400000, max_tile_hint=2048)):
+    for _ in range(3):          # back-to-back calls: forks and joins of successive forwards interleave on the side stream
+        out = _render(views, t, size, 3, **kw)
+    for o in out[:4]:
+        h.update(o.cpu().numpy().tobytes())
+print("HASH", h.hexdigest())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for side in ("1", "0"):
+        env = dict(os.environ, LSR_SH_SIDE_STREAM=side)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[side] = r.stdout.strip().splitlines()[-1]
+    assert digests["1"].startswith("HASH ") and digests["1"] == digests["0"], digests
