@@ -306,38 +306,50 @@ k_render_bwd(RenderBwdParams p) {
             const int px = tx0 + 8 * (k & 1) + 4 * gcol + lx, py = ty0 + 8 * (k >> 1) + 4 * grow + ly;
             pxy[k] = float2_b{(float)px, (float)py};
             const bool inside = px < p.W && py < p.H && ((own >> k) & 1u);
-            const size_t pix = (size_t)py * p.W + px, vp = (size_t)v * HW + pix;
-            const float Tfin = inside ? p.final_T[vp] : 1.0f;
+            // every per-pixel load is issued UNCONDITIONALLY at a clamped pixel (all of a row's loads in
+            // flight together) and masked afterwards: loads under the per-lane `inside` test were waited
+            // for one by one — ~30 serial round trips at the head of every item
+            const int pxc = min(px, p.W - 1), pyc = min(py, p.H - 1);
+            const size_t pix = (size_t)pyc * p.W + pxc, vp = (size_t)v * HW + pix;
+            const float Tfin_l = p.final_T[vp];
+            const uint32_t nc_l = p.n_contrib[vp];
+            float gl[NCHP], fl[NCHP];
+#pragma unroll
+            for (int c = 0; c < NCHP; ++c) gl[c] = fl[c] = 0.0f;
+            if (p.has_color && p.g_color) {          // kernel-argument uniform
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    gl[c] = p.g_color[((size_t)v * 3 + c) * HW + pix];
+                    fl[c] = p.f_color[((size_t)v * 3 + c) * HW + pix];
+                }
+            }
+            if (p.g_feat) {
+#pragma unroll
+                for (int c = 0; c < NCHP; ++c)
+                    if (c >= coff && c - coff < p.C) {   // uniform
+                        gl[c] = p.g_feat[((size_t)v * p.C + (c - coff)) * HW + pix];
+                        fl[c] = p.f_feat[((size_t)v * p.C + (c - coff)) * HW + pix];
+                    }
+            }
+            const float gmask_l = p.g_mask ? p.g_mask[vp] : 0.0f;
+            const float gdep_l = DEPTH_GRAD ? p.g_depth[vp] : 0.0f, fdep_l = DEPTH_GRAD ? p.f_depth[vp] : 0.0f;
+            const float Tfin = inside ? Tfin_l : 1.0f;
             Tr[k] = 1.0f;
-            last[k] = inside ? p.n_contrib[vp] : 0u;
+            last[k] = inside ? nc_l : 0u;
             maxlast = max(maxlast, last[k]);
             // R_0 = g . (rendered - T_final * bg)  +  T_final * (g . bg - g_mask)  =  g . rendered - T_final * g_mask
             float r0 = 0.0f;
             float dp[NCHP];
 #pragma unroll
-            for (int c = 0; c < NCHP; ++c) dp[c] = 0.0f;
-            if (inside) {
-                if (p.has_color && p.g_color) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        dp[c] = p.g_color[((size_t)v * 3 + c) * HW + pix];
-                        r0 = __builtin_fmaf(p.f_color[((size_t)v * 3 + c) * HW + pix], dp[c], r0);
-                    }
-                }
-                if (p.g_feat) {
-#pragma unroll
-                    for (int c = 0; c < NCHP; ++c)
-                        if (c >= coff && c - coff < p.C) {
-                            dp[c] = p.g_feat[((size_t)v * p.C + (c - coff)) * HW + pix];
-                            r0 = __builtin_fmaf(p.f_feat[((size_t)v * p.C + (c - coff)) * HW + pix], dp[c], r0);
-                        }
-                }
-                if (p.g_mask) r0 = __builtin_fmaf(-Tfin, p.g_mask[vp], r0);  // mask = 1 - T_final
+            for (int c = 0; c < NCHP; ++c) {
+                dp[c] = inside ? gl[c] : 0.0f;
+                r0 = __builtin_fmaf(fl[c], dp[c], r0);     // channels that are not rendered hold zeros
             }
+            r0 = __builtin_fmaf(-Tfin, inside ? gmask_l : 0.0f, r0);  // mask = 1 - T_final
 #pragma unroll
             for (int c = 0; c < NCHP / 2; ++c) dpix[k][c] = float2_b{dp[2 * c], dp[2 * c + 1]};
-            ddep[k] = (DEPTH_GRAD && inside) ? p.g_depth[vp] : 0.0f;
-            if (DEPTH_GRAD && inside) r0 = __builtin_fmaf(p.f_depth[vp], ddep[k], r0);
+            ddep[k] = (DEPTH_GRAD && inside) ? gdep_l : 0.0f;
+            if (DEPTH_GRAD) r0 = __builtin_fmaf(fdep_l, ddep[k], r0);
             Rr[k] = r0;
         }
         // wave-uniform upper bound of the entries any owned pixel has to consider
@@ -347,29 +359,35 @@ k_render_bwd(RenderBwdParams p) {
 
         // software-pipelined staging as in the forward: records of batch b+1 and list indices of
         // batch b+2 are in flight while batch b is processed
+        // (unconditional loads at clamped positions, see the forward: a load under a per-lane condition is
+        // waited for at the join)
         struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t g; };
-        auto load_idx = [&](uint32_t rel) -> uint32_t { return rel < maxlast ? p.point_list[start + rel] : 0u; };
-        auto load_rec = [&](uint32_t rel, uint32_t g) {
+        const uint32_t lastrel = maxlast - 1u;   // only used when maxlast > 0
+        auto load_idx = [&](uint32_t rel) -> uint32_t { return p.point_list[start + min(rel, lastrel)]; };
+        auto load_rec = [&](uint32_t g) {
             StageRec r;
             r.g = g;
-            r.a = r.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float4 *R = p.geo + (vG + g) * (size_t)p.rec_f4;
+            r.a = R[0]; r.b = R[1];
 #pragma unroll
-            for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (rel < maxlast) {
-                const float4 *R = p.geo + (vG + g) * (size_t)p.rec_f4;
-                r.a = R[0]; r.b = R[1];
-#pragma unroll
-                for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];
-            }
+            for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];
             return r;
         };
-        uint32_t g_ahead = load_idx(lane);
-        StageRec nxt = load_rec(lane, g_ahead);
-        g_ahead = load_idx(LSR_WAVE + lane);
+        uint32_t g_ahead = 0;
+        StageRec nxt;
+        nxt.g = 0;
+        nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int c4 = 0; c4 < NCHP / 4; ++c4) nxt.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (maxlast > 0) {   // wave-uniform
+            g_ahead = load_idx(lane);
+            nxt = load_rec(g_ahead);
+            g_ahead = load_idx(LSR_WAVE + lane);
+        }
 
         for (uint32_t cbase = 0; cbase < maxlast; cbase += LSR_WAVE) {
             const StageRec cur = nxt;
-            nxt = load_rec(cbase + LSR_WAVE + lane, g_ahead);
+            nxt = load_rec(g_ahead);
             g_ahead = load_idx(cbase + 2 * LSR_WAVE + lane);
             // ---- stage up to 64 list entries (one per lane) ----
             {   // every list slot starts as the null record's slot

@@ -158,24 +158,30 @@ k_render_fwd(RenderFwdParams p) {
         // Software-pipelined staging: while batch b is composited, the records of batch b+1 and the
         // list indices of batch b+2 are already in flight (two dependent global latencies per batch
         // otherwise sit on the serial path of the wave that walks the longest list).
+        // The loads are UNCONDITIONAL at clamped positions (slots past the end re-read the last entry, which
+        // the `e < end` tests below ignore): a load under a per-lane condition is followed by a wait for it at
+        // the join, which put both latencies back on the serial path of every batch.
         struct StageRec { float4 a, b, pay[NCHP / 4]; };
-        auto load_idx = [&](uint32_t e) -> uint32_t { return e < end ? p.point_list[e] : 0u; };
-        auto load_rec = [&](uint32_t e, uint32_t g) {
+        const uint32_t last = end - 1u;   // only used when the list is not empty
+        auto load_idx = [&](uint32_t e) -> uint32_t { return p.point_list[min(e, last)]; };
+        auto load_rec = [&](uint32_t g) {
             StageRec r;
-            r.a = r.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float4 *R = p.rec + (vG + g) * (size_t)p.rec_f4;
+            r.a = R[0]; r.b = R[1];  // (x,y,A,B) (C,o,z,-)
 #pragma unroll
-            for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (e < end) {
-                const float4 *R = p.rec + (vG + g) * (size_t)p.rec_f4;
-                r.a = R[0]; r.b = R[1];  // (x,y,A,B) (C,o,z,-)
-#pragma unroll
-                for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];  // payload, zero padded
-            }
+            for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];  // payload, zero padded
             return r;
         };
-        uint32_t g_ahead = load_idx(start + lane);
-        StageRec nxt = load_rec(start + lane, g_ahead);
-        g_ahead = load_idx(start + LSR_WAVE + lane);
+        uint32_t g_ahead = 0;
+        StageRec nxt;
+        nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int c4 = 0; c4 < NCHP / 4; ++c4) nxt.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (start < end) {   // wave-uniform
+            g_ahead = load_idx(start + lane);
+            nxt = load_rec(g_ahead);
+            g_ahead = load_idx(start + LSR_WAVE + lane);
+        }
 
         for (uint32_t base = start; base < end; base += LSR_WAVE) {
             uint64_t all_done = ~0ull;
@@ -184,7 +190,7 @@ k_render_fwd(RenderFwdParams p) {
             if (all_done == ~0ull) break;
 
             const StageRec cur = nxt;
-            nxt = load_rec(base + LSR_WAVE + lane, g_ahead);
+            nxt = load_rec(g_ahead);
             g_ahead = load_idx(base + 2 * LSR_WAVE + lane);
             // ---- stage up to 64 list entries (one per lane) ----
             {   // every list slot starts as the null record; the compaction below overwrites a prefix
@@ -287,7 +293,10 @@ k_render_fwd(RenderFwdParams p) {
             wave_lds_fence();  // WAR on the LDS slice before the next batch is staged
         }
 
-        const float *vw = p.views + (size_t)v * LSR_VIEW_FLOATS;
+        // background colour through the scalar cache (constant address space; the table was written by an
+        // earlier launch) — as plain loads these were three waited-for vector loads per pixel row
+        typedef const float __attribute__((address_space(4))) *kfloat_ptr;
+        const kfloat_ptr vw = (kfloat_ptr)(p.views + (size_t)v * LSR_VIEW_FLOATS);
 #pragma unroll
         for (int k = 0; k < PXL; ++k) {
             if (!inside[k]) continue;
