@@ -110,16 +110,23 @@ __device__ __forceinline__ float sh_dot(const float *bas, const float *co, int d
 struct ShDir {
     float dx, dy, dz, len, sc;
 };
-__device__ __forceinline__ ShDir sh_direction(const ShParams &p, int v, int i) {
-    const float *vw = p.in.views + (size_t)v * LSR_VIEW_FLOATS;
+struct ShPos { float x, y, z; };
+typedef const float __attribute__((address_space(4))) *kfloat_ptr;   // constant address space: uniform loads become s_load
+__device__ __forceinline__ ShPos sh_position(const ShParams &p, int v, int i) {
+    const float *mp = p.in.means3D + (size_t)v * p.d.vs_means + 3 * (size_t)i;
+    return ShPos{mp[0], mp[1], mp[2]};
+}
+// v is wave-uniform in both kernels: scene scale and camera position come through the scalar cache
+__device__ __forceinline__ ShDir sh_direction(const ShParams &p, int v, const ShPos &m) {
+    const kfloat_ptr vw = (kfloat_ptr)(p.in.views + (size_t)v * LSR_VIEW_FLOATS);
     ShDir r;
     r.sc = vw[40];
-    const float *mp = p.in.means3D + (size_t)v * p.d.vs_means + 3 * (size_t)i;
-    float dx = mp[0] * r.sc - vw[32], dy = mp[1] * r.sc - vw[33], dz = mp[2] * r.sc - vw[34];
+    float dx = m.x * r.sc - vw[32], dy = m.y * r.sc - vw[33], dz = m.z * r.sc - vw[34];
     r.len = sqrtf(dx * dx + dy * dy + dz * dz);
     r.dx = dx / r.len; r.dy = dy / r.len; r.dz = dz / r.len;
     return r;
 }
+__device__ __forceinline__ ShDir sh_direction(const ShParams &p, int v, int i) { return sh_direction(p, v, sh_position(p, v, i)); }
 
 __device__ __forceinline__ bool sh_shared_scene(const ShParams &p) {
     return (!p.has[0] || p.d.vs_color == 0) && (!p.has[1] || p.d.vs_feat == 0);
@@ -132,7 +139,7 @@ __global__ void __launch_bounds__(kShThreads)
 k_sh_fwd(ShParams p) {
     extern __shared__ float s_lds[];
     const lsr_dims &d = p.d;
-    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wave = tid / LSR_WAVE;
+    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / LSR_WAVE);
     const int G = d.num_gaussians, V = d.num_views;
     const int g0 = blockIdx.x * LSR_WAVE, i = g0 + lane;
     const int rows = G - g0 < LSR_WAVE ? G - g0 : LSR_WAVE;
@@ -144,10 +151,18 @@ k_sh_fwd(ShParams p) {
     const float *my = s_lds + lane * p.ks[0];
     const float *myF = s_lds + p.offF + lane * p.ks[1];
 
-    auto compute = [&](int v) {
+    // visibility and position are requested by `fetch` (unconditionally, before the wait for the staged
+    // coefficients where possible), `compute` consumes them
+    struct Fetched { float visf; ShPos pos; };
+    auto fetch = [&](int v) {
+        const int vl = v < V ? v : V - 1;
+        const size_t o = (size_t)vl * G + (active ? i : 0);
+        return Fetched{p.vis[o * p.vis_stride], sh_position(p, vl, active ? i : 0)};
+    };
+    auto compute = [&](int v, const Fetched &f) {
         const size_t o = (size_t)v * G + (active ? i : 0);
-        if (!(active && p.vis[o * p.vis_stride] > 0.0f)) return;
-        const ShDir dir = sh_direction(p, v, i);
+        if (!(active && f.visf > 0.0f)) return;
+        const ShDir dir = sh_direction(p, v, f.pos);
         float *R = p.rec + o * (size_t)p.RF + 8;
         float basF[9];
         // features use the reference's axis naming: B^ref(x,y,z) = B(z,x,y) up to degree 2
@@ -205,27 +220,32 @@ k_sh_fwd(ShParams p) {
     if (sh_shared_scene(p)) {
         stage_group(s_lds, p, 0, 0, g0, rows, tid);
         stage_group(s_lds, p, 1, 0, g0, rows, tid);
+        Fetched f = fetch(wave);
         staged_barrier();
-        for (int v = wave; v < V; v += kShWaves) compute(v);
+        for (int v = wave; v < V; v += kShWaves) {
+            const Fetched nxt = fetch(v + kShWaves);   // next view's reads in flight during this one's arithmetic
+            compute(v, f);
+            f = nxt;
+        }
     } else {
         for (int v = 0; v < V; ++v) {
             __syncthreads();
             stage_group(s_lds, p, 0, v, g0, rows, tid);
             stage_group(s_lds, p, 1, v, g0, rows, tid);
+            const Fetched f = fetch(v);
             staged_barrier();
-            if (wave == (v & (kShWaves - 1))) compute(v);
+            if (wave == (v & (kShWaves - 1))) compute(v, f);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 template <int DEGC, int COFF>
-__global__ void __launch_bounds__(kShThreads)
+__global__ void __launch_bounds__(kShThreads, 4)
 k_sh_bwd(ShParams p) {
     extern __shared__ float s_lds[];
-    __shared__ float s_part[kShWaves][LSR_WAVE][3];
     const lsr_dims &d = p.d;
-    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wave = tid / LSR_WAVE;
+    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / LSR_WAVE);
     const int G = d.num_gaussians, V = d.num_views;
     const int g0 = blockIdx.x * LSR_WAVE, i = g0 + lane;
     const int rows = G - g0 < LSR_WAVE ? G - g0 : LSR_WAVE;
@@ -239,9 +259,11 @@ k_sh_bwd(ShParams p) {
     const bool shared = sh_shared_scene(p);
     const int chunk = shared ? kShWaves : 1;            // per-view coefficient outputs: one view at a time
     const int ntot = COFF + C, cs = ntot | 1;
-    // LDS: [ coefficient rows | (re-used after the direction pass) basC, basF ] [ gch ]
-    const int area = max(p.offF + LSR_WAVE * p.ks[1], kShWaves * LSR_WAVE * (kShBasisC + kShBasisF));
-    float *s_basC = s_lds, *s_basF = s_lds + kShWaves * LSR_WAVE * kShBasisC;
+    // LDS: [ coefficient rows | re-used after the direction pass: basC, then (after the colour element pass)
+    // basF in the same place ] [ gch ].  One basis array at a time keeps the block at ~36 KB for the
+    // configs[3] payload (colour degree 4 + 4 x degree-2 features): four blocks per CU instead of three.
+    const int area = max(p.offF + LSR_WAVE * p.ks[1], kShWaves * LSR_WAVE * kShBasisC);
+    float *s_basC = s_lds, *s_basF = s_lds;
     float *s_gch = s_lds + area;
     const float *my = s_lds + lane * p.ks[0];
     const float *myF = s_lds + p.offF + lane * p.ks[1];
@@ -252,25 +274,43 @@ k_sh_bwd(ShParams p) {
         __syncthreads();   // previous chunk's element pass is done with the LDS arrays
         stage_group(s_lds, p, 0, shared ? 0 : v0, g0, rows, tid);
         stage_group(s_lds, p, 1, shared ? 0 : v0, g0, rows, tid);
-        staged_barrier();
         // ---- pass 1: thread = (view v0 + wave, Gaussian lane) ----
+        // Everything this thread reads from global memory is requested HERE, unconditionally (clamped view /
+        // Gaussian), next to the coefficient staging: visibility, clamp bits, position and the channel
+        // gradients of its record.  (Loaded inside the `vis` branch and the per-channel loops they were ~10
+        // serial round trips per block — the kernel ran at 2.4 TB/s with the VALU 43 % busy.)
         const int v = v0 + wave;
-        const size_t o = (size_t)v * G + (active ? i : 0);
-        const bool vis = wave < nv && active && p.vis[o * p.vis_stride] > 0.0f;
+        const int vl = v < V ? v : V - 1;
+        const size_t o = (size_t)vl * G + (active ? i : 0);
+        const float visf = p.vis[o * p.vis_stride];
+        const uint32_t bits = DEGC >= 0 ? (uint32_t)p.clamp[o] : 0u;
+        const ShPos pos = sh_position(p, vl, active ? i : 0);
+        const float *gr = p.grec + o * (size_t)p.RF + 8;
+        const bool pay8 = ntot <= 8;          // the whole payload half of a 64-byte record as two 16-byte loads
+        float4 gq0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), gq1 = gq0;
+        if (pay8) { gq0 = *(const float4 *)gr; gq1 = *(const float4 *)(gr + 4); }
         float *mg = s_gch + (wave * LSR_WAVE + lane) * cs;
+        staged_barrier();
+        const bool vis = wave < nv && active && visf > 0.0f;
+        if (pay8) {   // channel gradients (clamped colour channels zeroed) go to this thread's LDS row first;
+                      // the rolled channel loops below read them back by index
+            const float gv[8] = {gq0.x, gq0.y, gq0.z, gq0.w, gq1.x, gq1.y, gq1.z, gq1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < ntot) mg[j] = (vis && !(DEGC >= 0 && j < 3 && (bits >> j & 1u))) ? gv[j] : 0.0f;
+        }
         if (vis) {
-            const ShDir dir = sh_direction(p, v, i);
-            const float *gr = p.grec + o * (size_t)p.RF + 8;
+            const ShDir dir = sh_direction(p, v, pos);
             float ddx = 0.0f, ddy = 0.0f, ddz = 0.0f;   // dL / d(unit direction)
             if (DEGC >= 0) {
-                const uint32_t bits = p.clamp[o];
                 float sg[nbC > 0 ? nbC : 1];
 #pragma unroll
                 for (int k = 0; k < nbC; ++k) sg[k] = 0.0f;
 #pragma unroll 1
                 for (int c = 0; c < 3; ++c) {   // not unrolled: 25 coefficient reads in flight, not 75
-                    const float gc = (bits >> c & 1u) ? 0.0f : gr[c];
-                    mg[c] = gc;
+                    float gc;
+                    if (pay8) gc = mg[c];
+                    else { gc = (bits >> c & 1u) ? 0.0f : gr[c]; mg[c] = gc; }
                     if (cmaj) {
                         const float *co = my + c * K;
 #pragma unroll
@@ -297,12 +337,13 @@ k_sh_bwd(ShParams p) {
                 for (int k = 0; k < 9; ++k) sg[k] = 0.0f;
 #pragma unroll 1
                 for (int c = 0; c < C; ++c) {
-                    const float gc = gr[COFF + c];
-                    mg[COFF + c] = gc;
+                    float gc;
+                    if (pay8) gc = mg[COFF + c];
+                    else { gc = gr[COFF + c]; mg[COFF + c] = gc; }
                     const float *co = myF + c * Kf;
 #pragma unroll
                     for (int k = 0; k < 9; ++k)
-                        if (k < nbF) sg[k] = __builtin_fmaf(co[k], gc, sg[k]);
+                        if (k < nbF) sg[k] = __builtin_fmaf(co[k], gc, sg[k]);   // (unconditional clamped reads: 11 more spilled registers, 0.157 -> 0.164 ms)
                 }
                 float dbas[9][3];
                 sh_basis_grad<2>(degF, dir.dz, dir.dx, dir.dy, dbas);
@@ -331,21 +372,13 @@ k_sh_bwd(ShParams p) {
         {   // the SH bases go where the coefficients were (recomputed here rather than kept live
             // through the direction pass: registers, not VALU, limit this kernel's occupancy)
             ShDir dir = {0.0f, 0.0f, 1.0f, 1.0f, 1.0f};
-            if (vis) dir = sh_direction(p, v, i);
+            if (vis) dir = sh_direction(p, v, pos);
             if (DEGC >= 0) {
                 float basC[nbC > 0 ? nbC : 1];
                 sh_basis<DEGC>(DEGC, cax ? dir.dz : dir.dx, cax ? dir.dx : dir.dy, cax ? dir.dy : dir.dz, basC);   // LSR_SH_AXES_REFERENCE: B(z,x,y)
                 float *mb = s_basC + (wave * LSR_WAVE + lane) * kShBasisC;
 #pragma unroll
                 for (int k = 0; k < 26; ++k) mb[k] = (vis && k < nbC) ? basC[k < nbC ? k : 0] : 0.0f;
-            }
-            if (hasF) {
-                float basF[9];
-                sh_basis<2>(degF, dir.dz, dir.dx, dir.dy, basF);
-                float *mb = s_basF + (wave * LSR_WAVE + lane) * kShBasisF;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) mb[k] = (vis && k < nbF) ? basF[k] : 0.0f;
-                mb[9] = 0.0f;
             }
         }
         __syncthreads();
@@ -369,6 +402,18 @@ k_sh_bwd(ShParams p) {
             }
         }
         if (hasF) {
+            if (DEGC >= 0) __syncthreads();   // the colour element pass is done with the basis area
+            {
+                ShDir dir = {0.0f, 0.0f, 1.0f, 1.0f, 1.0f};
+                if (vis) dir = sh_direction(p, v, pos);
+                float basF[9];
+                sh_basis<2>(degF, dir.dz, dir.dx, dir.dy, basF);
+                float *mb = s_basF + (wave * LSR_WAVE + lane) * kShBasisF;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) mb[k] = (vis && k < nbF) ? basF[k] : 0.0f;
+                mb[9] = 0.0f;
+            }
+            __syncthreads();
             const int ks = p.ks[1];
             float *dst = p.g.features + (d.vs_feat != 0 ? (size_t)v0 * d.vs_feat : 0) + (size_t)g0 * ks;
             for (int t = tid; t < rows * ks; t += kShThreads) {
@@ -385,6 +430,8 @@ k_sh_bwd(ShParams p) {
         }
     }
     if (d.vs_means == 0) {
+        __syncthreads();   // the last element pass is done with the LDS arrays: the partial sums go to their start
+        float (*s_part)[LSR_WAVE][3] = (float (*)[LSR_WAVE][3])s_lds;
 #pragma unroll
         for (int a = 0; a < 3; ++a) s_part[wave][lane][a] = acc[a];
         __syncthreads();
@@ -470,7 +517,7 @@ hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const cha
     const int degc = p.has[0] ? d.sh_degree : -1, coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
     const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), block(kShThreads);
     const int cs = (coff + d.feat_channels) | 1;
-    const int area = std::max(p.offF + LSR_WAVE * p.ks[1], kShWaves * LSR_WAVE * (kShBasisC + kShBasisF));
+    const int area = std::max(p.offF + LSR_WAVE * p.ks[1], kShWaves * LSR_WAVE * kShBasisC);
     const size_t shm = ((size_t)area + (size_t)kShWaves * LSR_WAVE * cs) * 4;
     if (shm > 65536) {   // many direct channels next to an SH group
         if (degc == 4) allow_big_lds<4, 3>(shm); else if (degc == 3) allow_big_lds<3, 3>(shm);
