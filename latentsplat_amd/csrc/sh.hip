@@ -26,6 +26,7 @@
 //    more views than one chunk).
 // The colour degree is a template parameter (straight-line band code, no dead registers).
 #include <algorithm>
+#include <type_traits>
 
 #include "lsr_internal.h"
 #include "lsr_sh.h"
@@ -387,19 +388,25 @@ k_sh_bwd(ShParams p) {
         if (DEGC >= 0) {
             const int ks = p.ks[0];
             float *dst = p.g.color + (d.vs_color != 0 ? (size_t)v0 * d.vs_color : 0) + (size_t)g0 * ks;
-            for (int t = tid; t < rows * ks; t += kShThreads) {
-                const int g = udiv_small(t, p.mdiv[0]), rem = t - g * ks;
-                int k, c;
-                if (cmaj) { c = udiv_small(rem, p.mdivK); k = rem - c * K; }
-                else { k = (rem * 0xAAABu) >> 17; c = rem - 3 * k; }
-                const int kb = k < nbC ? k : 25;   // coefficients beyond the evaluated bands: zero slot
-                float a = rmw ? dst[t] : 0.0f;
-                const float *pb = s_basC + g * kShBasisC + kb, *pg = s_gch + g * cs + c;
+            // Two instances of the loop: with the read-modify-write load in it the compiler puts
+            // `s_waitcnt vmcnt(0)` in front of every store, and on gfx9 that also waits for the PREVIOUS
+            // store — 28 serial store round trips per thread.  Views beyond nv and culled Gaussians have
+            // zero rows in both LDS arrays, so all four view terms are added unconditionally.
+            auto colour_pass = [&](auto RMW) {
+                for (int t = tid; t < rows * ks; t += kShThreads) {
+                    const int g = udiv_small(t, p.mdiv[0]), rem = t - g * ks;
+                    int k, c;
+                    if (cmaj) { c = udiv_small(rem, p.mdivK); k = rem - c * K; }
+                    else { k = (rem * 0xAAABu) >> 17; c = rem - 3 * k; }
+                    const int kb = k < nbC ? k : 25;   // coefficients beyond the evaluated bands: zero slot
+                    float a = decltype(RMW)::value ? dst[t] : 0.0f;
+                    const float *pb = s_basC + g * kShBasisC + kb, *pg = s_gch + g * cs + c;
 #pragma unroll
-                for (int vi = 0; vi < kShWaves; ++vi)
-                    if (vi < nv) a = __builtin_fmaf(pb[vi * LSR_WAVE * kShBasisC], pg[vi * LSR_WAVE * cs], a);
-                dst[t] = a;
-            }
+                    for (int vi = 0; vi < kShWaves; ++vi) a = __builtin_fmaf(pb[vi * LSR_WAVE * kShBasisC], pg[vi * LSR_WAVE * cs], a);
+                    dst[t] = a;
+                }
+            };
+            if (rmw) colour_pass(std::true_type{}); else colour_pass(std::false_type{});
         }
         if (hasF) {
             if (DEGC >= 0) __syncthreads();   // the colour element pass is done with the basis area
@@ -416,17 +423,19 @@ k_sh_bwd(ShParams p) {
             __syncthreads();
             const int ks = p.ks[1];
             float *dst = p.g.features + (d.vs_feat != 0 ? (size_t)v0 * d.vs_feat : 0) + (size_t)g0 * ks;
-            for (int t = tid; t < rows * ks; t += kShThreads) {
-                const int g = udiv_small(t, p.mdiv[1]), rem = t - g * ks;
-                const int c = udiv_small(rem, p.mdivKf), k = rem - c * Kf;
-                const int kb = k < nbF ? k : 9;
-                float a = rmw ? dst[t] : 0.0f;
-                const float *pb = s_basF + g * kShBasisF + kb, *pg = s_gch + g * cs + COFF + c;
+            auto feature_pass = [&](auto RMW) {
+                for (int t = tid; t < rows * ks; t += kShThreads) {
+                    const int g = udiv_small(t, p.mdiv[1]), rem = t - g * ks;
+                    const int c = udiv_small(rem, p.mdivKf), k = rem - c * Kf;
+                    const int kb = k < nbF ? k : 9;
+                    float a = decltype(RMW)::value ? dst[t] : 0.0f;
+                    const float *pb = s_basF + g * kShBasisF + kb, *pg = s_gch + g * cs + COFF + c;
 #pragma unroll
-                for (int vi = 0; vi < kShWaves; ++vi)
-                    if (vi < nv) a = __builtin_fmaf(pb[vi * LSR_WAVE * kShBasisF], pg[vi * LSR_WAVE * cs], a);
-                dst[t] = a;
-            }
+                    for (int vi = 0; vi < kShWaves; ++vi) a = __builtin_fmaf(pb[vi * LSR_WAVE * kShBasisF], pg[vi * LSR_WAVE * cs], a);
+                    dst[t] = a;
+                }
+            };
+            if (rmw) feature_pass(std::true_type{}); else feature_pass(std::false_type{});
         }
     }
     if (d.vs_means == 0) {
