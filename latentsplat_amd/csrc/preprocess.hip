@@ -97,6 +97,10 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
         };
         float4 pay0 = make_float4(0, 0, 0, 0), pay1 = make_float4(0, 0, 0, 0);
         if (staged) { pay0 = payload(0); pay1 = payload(1); }
+        // The wait for these loads belongs HERE, once per Gaussian: left to the compiler it lands inside the
+        // view loop as `s_waitcnt vmcnt(0)`, which on gfx9 also waits for the previous view's record stores.
+        asm volatile("" :: "v"(q0), "v"(q1), "v"(q2), "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5), "v"(opacity),
+                     "v"(pay0.x), "v"(pay0.y), "v"(pay0.z), "v"(pay0.w), "v"(pay1.x), "v"(pay1.y), "v"(pay1.z), "v"(pay1.w));
 
 #pragma unroll 1
         for (int vb = 0; vb < VB; ++vb) {
