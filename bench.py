@@ -488,13 +488,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # LSR_BENCH_SHARE_GPU=1: smoke test of the multi-process path on a ONE-GPU box (every rank on cuda:0,
+    # rendezvous and the scalar reductions over gloo).  Never set by the driver; numbers of such a run mean nothing.
+    share_gpu = os.environ.get("LSR_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from latentsplat_amd import _lib
     from latentsplat_amd.rasterizer import rasterize_views
@@ -510,7 +518,7 @@ def main():
         return out, (m, c, o, f)
 
     def timed(fn, steps, warmup):
-        return timed_region(fn, steps, warmup, dist, lambda: torch.cuda.synchronize(dev), dev)
+        return timed_region(fn, steps, warmup, dist, lambda: torch.cuda.synchronize(dev), "cpu" if share_gpu else dev)
 
     # ---- headline: forward only (configs[1]).  In the timed region only the dominant kernel (the
     # roofline's) is bracketed by hipEvents; bracketing all five stages costs ~3 % of a step, so the

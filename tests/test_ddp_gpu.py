@@ -120,3 +120,31 @@ def test_ddp_allreduced_grads_equal_single_process_mean():
     for n in want:
         scale = max(1e-6, float(want[n].abs().max()))
         assert float((got[n] - want[n]).abs().max()) <= 1e-4 * scale, n
+
+
+def test_bench_multi_process_path_on_one_gpu():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank:
+    RANK / LOCAL_RANK / WORLD_SIZE from the environment, barrier + sync on both sides of the timed region,
+    MAX over ranks, one JSON line from rank 0) — on a one-GPU box both ranks share cuda:0 and rendezvous
+    over gloo (LSR_BENCH_SHARE_GPU=1), so the numbers mean nothing but every line of the N > 1 path runs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--gaussians", "20000", "--views", "4",
+           "--no-cpu-baseline", "--no-latency"]
+    env = dict(os.environ, LSR_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 prints, rank 1 stays silent
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert len(out["per_rank_ms_per_step"]) == 2 and max(out["per_rank_ms_per_step"]) == pytest.approx(out["ms_per_step"], rel=1e-6)
+    assert out["value"] == pytest.approx(2 * 4 * 1e3 / out["ms_per_step"], rel=1e-6)   # whole-job rate: both ranks' views over the slowest rank's time
+    assert out["cpu_baseline"] is None                  # rank 0 at N = 1 only
