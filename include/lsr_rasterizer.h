@@ -192,8 +192,9 @@ int lsr_pack_view(const float *viewmatrix, const float *projmatrix, const float 
                   float *view_out, lsr_stream_t stream);
 
 /* ---- forward, phase 1: per-Gaussian preprocess + per-tile counting + tile offset scan.
- * Writes radii.  Synchronises `stream` once to return the pair count and the longest tile list
- * through the two host pointers (both required).
+ * Writes radii.  Waits once for the device to return the pair count and the longest tile list through
+ * the two host pointers (both required): on an event recorded right behind the preprocess kernel, whose
+ * last workgroup totals the tile counts — the offset scan is still running when the call returns.
  * Also starts the view-dependent payload pass (colour / latent features from SH), which only depends on
  * the preprocess: it runs on a library-owned side stream (one per device, forked from `stream` with an
  * event) while the host fetches the pair count and the binning of phase 2 runs; phase 2 joins it

@@ -359,13 +359,14 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
     if (d->num_gaussians > 0 && !radii) return LSR_ENULL;
     hipStream_t s = (hipStream_t)stream;
     char *geom = (char *)geom_ws;
-    LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, s));
-    rc = sh_forward_fork(*d, *in, geom, s);   // view-dependent payload: next to tile_scan, the host round trip and the binning
-    if (rc) return rc;
-    // Pair count and longest list come back through a 64-byte pinned, device-mapped host buffer that
-    // k_tile_scan writes directly (one per host thread, allocated on first use; the library's only
-    // allocation and it is host memory).  Without it: a device-to-host copy command.
+    // Pair count and longest list come back through a 64-byte pinned, device-mapped host buffer (one per host
+    // thread, allocated on first use; the library's only allocation and it is host memory).  The LAST
+    // workgroup of k_preprocess writes them, and the host waits on an event recorded right behind that
+    // kernel: k_tile_scan and the SH pass run while the host wakes up, sizes the binning workspace and
+    // launches phase 2 (the device used to idle through that round trip).  Without mapped memory: a
+    // device-to-host copy of the header after k_tile_scan.
     static thread_local uint32_t *h_hdr = nullptr, *h_hdr_dev = nullptr;
+    static thread_local hipEvent_t h_events[64] = {};     // one per device this thread has used (events belong to a device)
     static thread_local bool h_tried = false;
     if (!h_tried) {
         h_tried = true;
@@ -377,10 +378,26 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
             (void)hipGetLastError();
         }
     }
-    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, h_hdr_dev, 0xFFFFFFFFu, s));
+    hipEvent_t h_event = nullptr;
+    {
+        int dev = -1;
+        if (h_hdr && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (!h_events[dev] && hipEventCreateWithFlags(&h_events[dev], hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                h_events[dev] = nullptr;
+            }
+            h_event = h_events[dev];
+        }
+    }
+    const bool early = h_event != nullptr && d->num_gaussians > 0;
+    LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, early ? h_hdr_dev : nullptr, s));
+    if (early) LSR_HIP(hipEventRecord(h_event, s));
+    rc = sh_forward_fork(*d, *in, geom, s);   // view-dependent payload: next to tile_scan, the host round trip and the binning
+    if (rc) return rc;
+    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, 0xFFFFFFFFu, s));
     uint32_t hdr[2] = {0, 0};
-    if (h_hdr) {
-        LSR_HIP(hipStreamSynchronize(s));
+    if (early) {
+        LSR_HIP(hipEventSynchronize(h_event));
         hdr[0] = h_hdr[0]; hdr[1] = h_hdr[1];
     } else {
         LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));
@@ -427,7 +444,7 @@ int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     hipStream_t s = (hipStream_t)stream;
     char *geom = (char *)geom_ws;
     // the same stage sequence as prepare + render; nothing between the launches waits for the device
-    LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, s));
+    LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, nullptr, s));
     rc = sh_forward_fork(*d, *in, geom, s);
     if (rc) return rc;
     LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, (uint32_t)pair_capacity, s));

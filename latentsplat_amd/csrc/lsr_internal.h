@@ -142,7 +142,7 @@ inline int wave_slots(int cus) { return cus * 4 * 4; }
 // Environment knobs are development aids; each is read ONCE per process (never on the launch path).
 int env_int(const char *name, int fallback);        // api.hip: latched on first use
 // header words of the geometry workspace
-enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrQueueFwd = 2, kHdrNumItems = 3, kHdrOverflow = 4 };
+enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrQueueFwd = 2, kHdrNumItems = 3, kHdrOverflow = 4, kHdrPreDone = 5 };
 
 // ---- optional per-stage hipEvent timing (api.hip); no-ops unless lsr_profile_enable(1) ----
 enum Stage { kStPreprocess = 0, kStTileScan, kStScatter, kStSort, kStRenderFwd, kStRenderBwd, kStPreprocessBwd, kStShFwd, kStShBwd, kStAdapterFwd, kStAdapterBwd, kStLatentFwd, kStLatentBwd, kNumStages };
@@ -155,7 +155,10 @@ void note_hip_error(int hip_error);   // what lsr_last_hip_error() returns for t
 hipError_t launch_clear(void *ptr, size_t bytes, hipStream_t s);
 
 // ---- stage launchers (defined one per .hip file) ----
-hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii,
+// host_mirror (optional, device pointer to two mapped host words): the LAST workgroup of k_preprocess to
+// finish sums the tile counts and writes (pair count, longest list) there, so the synchronous forward can
+// hand them to the host while k_tile_scan is still running.
+hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, uint32_t *host_mirror,
                              hipStream_t s);
 // pair_capacity: pairs the binning workspace can hold (UINT32_MAX = exact sizing after a host read-back)
 hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror, uint32_t pair_capacity, hipStream_t s);

@@ -171,3 +171,26 @@ print("HASH", h.hexdigest())
         assert r.returncode == 0, r.stderr[-2000:]
         digests[side] = r.stdout.strip().splitlines()[-1]
     assert digests["1"].startswith("HASH ") and digests["1"] == digests["0"], digests
+
+
+def test_early_pair_count_equals_the_device_header(hip_device):
+    """The synchronous forward hands the pair count to the host from the LAST workgroup of k_preprocess
+    (while k_tile_scan is still running); the authoritative numbers are the ones k_tile_scan leaves in the
+    workspace header.  They must agree on every call — a smaller host count would under-size the binning
+    workspace.  Repeated over shapes that use the LDS-privatised and the global tile histograms."""
+    import ctypes as C
+    from latentsplat_amd import _lib
+    lib = _lib.load()
+    for G, V, size, reps in ((120_000, 8, 256, 40), (3_000, 1, 1040, 10), (40_000, 3, 64, 40)):
+        sc = util.make_scene(G, image_size=size, views=V, color_sh_degree=None, feature_channels=4, seed=3)
+        bi = util.boundary_inputs(sc, size, size, use_sh=False)
+        run = util.HipRun(bi, hip_device, shared_means=True)
+        p = lambda x: C.c_void_p(x.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(hip_device).cuda_stream)
+        for _ in range(reps):
+            npairs, maxtile = C.c_int64(0), C.c_int32(0)
+            _lib.check(lib.lsr_forward_prepare(C.byref(run.d), C.byref(run.inp), p(run.geom), p(run.radii),
+                                               C.byref(npairs), C.byref(maxtile), stream), "prepare")
+            dp, dm, ov = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+            _lib.check(lib.lsr_forward_status(C.byref(run.d), p(run.geom), C.byref(dp), C.byref(dm), C.byref(ov), stream), "status")
+            assert (npairs.value, maxtile.value) == (dp.value, dm.value) == (run.P, run.maxtile)
