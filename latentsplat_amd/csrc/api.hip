@@ -226,6 +226,9 @@ static int sh_forward_fork(const lsr_dims &d, const lsr_inputs &in, char *geom, 
     SideCtx *c = side_ctx();
     hipStream_t q = s;
     if (c) {
+        // record + wait as one step: another host thread forking on the same device re-records the same event
+        static std::mutex fork_mu;
+        std::lock_guard<std::mutex> lock(fork_mu);
         LSR_HIP(hipEventRecord(c->fork, s));
         LSR_HIP(hipStreamWaitEvent(c->side, c->fork, 0));
         q = c->side;
