@@ -498,11 +498,31 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
     if (num_pairs > 0)
         LSR_STAGE("render_backward", s, launch_render_backward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs,
                                        (const char *)img_ws, *fwd, *gout, (char *)grad_ws, *gin, s));
-    return for_each_view_group(*d, *in, gin, [&](const lsr_dims &dg, const lsr_inputs &ig, const lsr_in_grads &gg, const lsr_dims *layout, int view0) -> int {
-        LSR_STAGE("preprocess_backward", s, launch_preprocess_backward(dg, ig, (const char *)geom_ws, radii, (const char *)grad_ws, gg, s, layout, view0));
-        LSR_STAGE("sh_backward", s, launch_sh_backward(dg, ig, (const char *)geom_ws, (const char *)grad_ws, gg, s, layout, view0));
+    // Geometry / SH backward per scene (view group).  Inside a scene the two kernels are ordered (both add into
+    // the scene's mean gradients); different scenes touch disjoint gradient slices, so with several scenes in
+    // the call the odd ones go to the side stream and two chains of these memory-bound kernels run
+    // concurrently (forked behind the compositing backward, joined at the end).
+    const int groups = d->views_per_group > 1 ? (d->num_views + d->views_per_group - 1) / d->views_per_group : 1;
+    SideCtx *c = groups >= 2 ? side_ctx() : nullptr;
+    if (c) {
+        static std::mutex fork_mu;
+        std::lock_guard<std::mutex> lock(fork_mu);
+        LSR_HIP(hipEventRecord(c->fork, s));
+        LSR_HIP(hipStreamWaitEvent(c->side, c->fork, 0));
+    }
+    int g = 0;
+    rc = for_each_view_group(*d, *in, gin, [&](const lsr_dims &dg, const lsr_inputs &ig, const lsr_in_grads &gg, const lsr_dims *layout, int view0) -> int {
+        hipStream_t q = (c && (g++ & 1)) ? c->side : s;
+        LSR_STAGE("preprocess_backward", q, launch_preprocess_backward(dg, ig, (const char *)geom_ws, radii, (const char *)grad_ws, gg, q, layout, view0));
+        LSR_STAGE("sh_backward", q, launch_sh_backward(dg, ig, (const char *)geom_ws, (const char *)grad_ws, gg, q, layout, view0));
         return LSR_OK;
     });
+    if (rc) return rc;
+    if (c) {
+        LSR_HIP(hipEventRecord(c->join, c->side));
+        LSR_HIP(hipStreamWaitEvent(s, c->join, 0));
+    }
+    return LSR_OK;
 }
 
 }  // extern "C"

@@ -183,7 +183,7 @@ def test_early_pair_count_equals_the_device_header(hip_device):
     lib = _lib.load()
     for G, V, size, reps in ((120_000, 8, 256, 40), (3_000, 1, 1040, 10), (40_000, 3, 64, 40)):
         sc = util.make_scene(G, image_size=size, views=V, color_sh_degree=None, feature_channels=4, seed=3)
-        bi = util.boundary_inputs(sc, size, size, use_sh=False)
+        bi = util.boundary_inputs(sc, size, size)          # per-view feature tensors (V,G,C), as HipRun's strides expect
         run = util.HipRun(bi, hip_device, shared_means=True)
         p = lambda x: C.c_void_p(x.data_ptr())
         stream = C.c_void_p(torch.cuda.current_stream(hip_device).cuda_stream)

@@ -90,6 +90,9 @@ class HipRun:
         Cf = 0 if self.features is None else self.features.shape[-1]
         mode = 1 if bi["shs"] is not None else (2 if bi["colors_precomp"] is not None else 0)
         K = bi["shs"].shape[1] if bi["shs"] is not None else 0
+        # the feature stride declared below assumes a (V,G,C) tensor; a (1,G,C) one would be read out of bounds
+        assert self.features is None or self.features.shape[0] == V, \
+            f"HipRun: features have leading dim {self.features.shape[0]}, expected {V} views"
         self.d = d = Dims(V, G, H, W, Cf, mode, bi["sh_degree"], K, 0 if shared_means else 3 * G,
                           0 if shared_means else 6 * G, 0, 0, Cf * G if Cf else 0, 6, 0, 0, 0, 0, 0)
         p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
