@@ -418,12 +418,24 @@ def _pack_view(rs: GaussianRasterizationSettings, dev) -> Tensor:
     return out
 
 
+_NEAR_CULL = 0.2   # view-space z at or below which a Gaussian is culled (LSR_NEAR_CULL in csrc/lsr_internal.h)
+
+
 class GaussianRasterizer(nn.Module):
     """Drop-in for ``diff_gaussian_rasterization.GaussianRasterizer`` (one view per call)."""
 
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()
         self.raster_settings = raster_settings
+
+    def markVisible(self, positions: Tensor) -> Tensor:
+        """Published API of the upstream class (its frustum test keeps everything with view-space z > 0.2;
+        the screen-bounds half of that test is commented out upstream).  ``viewmatrix`` is the transposed
+        world-to-view matrix the settings tuple carries.  The reference never calls it; plain tensor ops."""
+        with torch.no_grad():
+            vm = torch.as_tensor(self.raster_settings.viewmatrix, dtype=positions.dtype, device=positions.device)
+            z = positions @ vm[:3, 2] + vm[3, 2]
+            return z > _NEAR_CULL
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, features=None,
                 scales=None, rotations=None, cov3D_precomp=None):

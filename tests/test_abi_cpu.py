@@ -97,3 +97,28 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_SO", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.LsrError, match="no CPU"):
         _lib.load()
+
+
+def test_mark_visible_matches_the_oracle_near_plane_cull():
+    """GaussianRasterizer.markVisible (upstream API, unused by the reference): view-space z > 0.2, with the
+    transposed view matrix of the settings tuple — the same Gaussians the oracle's preprocess keeps past its
+    near-plane test."""
+    import numpy as np
+    import torch
+    import diff_gaussian_rasterization as dgr
+    from tests import util
+    sc = util.make_scene(4000, image_size=64, views=1, color_sh_degree=0, feature_channels=None)
+    sc.means[:500, 2] -= 2.0          # push some behind / next to the camera
+    bi = util.boundary_inputs(sc, 64, 64)
+    c = bi["cams"]
+    rs = dgr.GaussianRasterizationSettings(
+        image_height=64, image_width=64, tanfovx=float(c.tan_fov_x[0]), tanfovy=float(c.tan_fov_y[0]),
+        bg=bi["bg"][0], scale_modifier=1.0, viewmatrix=c.view_matrix[0], projmatrix=c.full_projection[0],
+        sh_degree=0, campos=c.campos[0], prefiltered=False, debug=False)
+    vis = dgr.GaussianRasterizer(rs).markVisible(bi["means"][0])
+    vm = c.view_matrix[0].numpy().astype(np.float32).reshape(16)
+    m = bi["means"][0].numpy().astype(np.float32)
+    z = vm[2] * m[:, 0] + vm[6] * m[:, 1] + vm[10] * m[:, 2] + vm[14]
+    want = z > 0.2
+    assert vis.dtype == torch.bool and vis.shape == (4000,)
+    assert (vis.numpy() != want).sum() <= 2 and 0 < want.sum() < 4000     # (float summation order at the threshold)
