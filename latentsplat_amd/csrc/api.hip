@@ -392,15 +392,19 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
             h_event = h_events[dev];
         }
     }
-    const bool early = h_event != nullptr && d->num_gaussians > 0;
+    // (one workgroup adds the counts up: beyond 64 k tiles the scan kernel's own totals are the faster way)
+    const bool early = h_event != nullptr && d->num_gaussians > 0 && (int64_t)d->num_views * num_tiles(*d) <= 65536;
     LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, early ? h_hdr_dev : nullptr, s));
     if (early) LSR_HIP(hipEventRecord(h_event, s));
     rc = sh_forward_fork(*d, *in, geom, s);   // view-dependent payload: next to tile_scan, the host round trip and the binning
     if (rc) return rc;
-    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, 0xFFFFFFFFu, s));
+    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, early ? nullptr : h_hdr_dev, 0xFFFFFFFFu, s));
     uint32_t hdr[2] = {0, 0};
     if (early) {
         LSR_HIP(hipEventSynchronize(h_event));
+        hdr[0] = h_hdr[0]; hdr[1] = h_hdr[1];
+    } else if (h_hdr) {      // k_tile_scan wrote the mapped words itself
+        LSR_HIP(hipStreamSynchronize(s));
         hdr[0] = h_hdr[0]; hdr[1] = h_hdr[1];
     } else {
         LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));

@@ -248,9 +248,16 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
         if (s_last) {
             const int N = d.num_views * T;
             uint32_t sum = 0, mx = 0;
-            for (int t = threadIdx.x; t < N; t += kPreThreads) {
-                const uint32_t c = __hip_atomic_load(&tile_count[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sum += c; mx = max(mx, c);
+            for (int t0 = threadIdx.x; t0 < N; t0 += 8 * kPreThreads) {   // eight loads in flight per thread
+                uint32_t c[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    c[j] = __hip_atomic_load(&tile_count[min(t0 + j * kPreThreads, N - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t cj = t0 + j * kPreThreads < N ? c[j] : 0u;
+                    sum += cj; mx = max(mx, cj);
+                }
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
