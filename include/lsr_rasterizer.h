@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LSR_ABI_VERSION 5
+#define LSR_ABI_VERSION 6
 #define LSR_TILE 16            /* tile edge in pixels (16x16 = the published algorithm's tile) */
 #define LSR_MAX_FEAT_CHANNELS 32
 #define LSR_MAX_SH_DEGREE 4
@@ -152,13 +152,22 @@ typedef struct lsr_in_grads { /* shapes follow the inputs: (G,..) when the strid
 /* Debug / test view of the workspaces (byte offsets from the respective workspace base). */
 typedef struct lsr_layout {
     /* geom_rec: [V*G][geom_rec_floats] f32 = x_pix y_pix conicA conicB conicC opacity z clampbits payload...
-     * geom_bin: [V*G] records of geom_bin_stride bytes: 8 = {u8 rect[4] (minx miny maxx maxy, in tiles); f32 depth}
-     *           when the tile grid fits byte coordinates, else 16 = {u16 rect[4]; f32 depth; u32 unused};
-     *           depth 0 = culled */
+     * geom_bin: [V*G] records of geom_bin_stride bytes: 12 = {u8 rect[4] (minx miny maxx maxy, in tiles); f32 depth;
+     *           u8 span[4]} when the tile grid fits byte coordinates, else 16 = {u16 rect[4]; f32 depth; u8 span[4]};
+     *           depth 0 = culled; span = footprint of alpha >= 1/255 in 4-pixel cells relative to the rectangle
+     * bin_point_list: [P] canonical per-tile lists (depth order, ties by index): tile t of view v owns
+     *           [tile_start[v*T+t], tile_start[v*T+t+1])
+     * bin_quad_list: [4P] render lists (ABI v6): the tile with canonical list [s, s+n) owns [4s, 4s+4n); the list of
+     *           its 8x8 quadrant q (q = 2*(y>=8) + (x>=8)) starts at 4s + q*n and has geom_quad_count[4*(v*T+t)+q]
+     *           entries `index | sub-block bits << 28`: the canonical list restricted to the entries whose
+     *           alpha >= 1/255 footprint box reaches the quadrant, in canonical order; bit (2*r + c) = the entry can
+     *           reach the quadrant's 4x4-pixel sub-block (c, r).  img_n_contrib counts positions of THESE lists.
+     * key_index_shift: 8 when the sort keys are `depth << 32 | index << 8 | sub-block code`, 0 for plain indices */
     size_t geom_rec, geom_rec_floats, geom_bin, geom_tile_count, geom_tile_start, geom_header;
     size_t bin_keys, bin_point_list;
     size_t img_final_T, img_n_contrib;
     size_t geom_bin_stride;
+    size_t bin_quad_list, geom_quad_count, key_index_shift;
 } lsr_layout;
 
 int lsr_abi_version(void);

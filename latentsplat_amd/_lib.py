@@ -60,7 +60,8 @@ class InGrads(C.Structure):
 class Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
                 ("geom_rec", "geom_rec_floats", "geom_bin", "geom_tile_count", "geom_tile_start",
-                 "geom_header", "bin_keys", "bin_point_list", "img_final_T", "img_n_contrib", "geom_bin_stride")]
+                 "geom_header", "bin_keys", "bin_point_list", "img_final_T", "img_n_contrib", "geom_bin_stride",
+                 "bin_quad_list", "geom_quad_count", "key_index_shift")]
 
 
 class AdapterDims(C.Structure):      # lsr_adapter_dims (include/lsr_adapter.h, include/lsr_latent.h, include/lsr_ply.h)
@@ -202,7 +203,7 @@ def load():
     lib.lsr_ply_pack.argtypes = [I64, I32, C.POINTER(PlyInputs), P, P]
     lib.lsr_ply_write_host.restype = C.c_int
     lib.lsr_ply_write_host.argtypes = [C.c_char_p, P, I64]
-    if lib.lsr_abi_version() != 5:
+    if lib.lsr_abi_version() != 6:
         raise LsrError("liblsr_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

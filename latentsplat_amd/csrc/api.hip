@@ -72,7 +72,7 @@ int lsr::device_cus() {
 
 bool lsr::deterministic_backward() { return env_int("LSR_DETERMINISTIC", 0) != 0; }
 
-// Development knobs (LSR_SPLIT, LSR_LIMIT, LSR_PXL_BWD, ...): read from the environment once per
+// Development knobs (LSR_FWD_VARIANT, LSR_SH_SIDE_STREAM, ...): read from the environment once per
 // process and knob, then served from a table — no getenv on the launch path.
 int lsr::env_int(const char *name, int fallback) {
     struct Knob { const char *name; int value; };
@@ -124,8 +124,9 @@ static int check_dims(const lsr_dims *d) {
     if (tiles_x(*d) > 65535 || tiles_y(*d) > 65535) return LSR_EUNSUPPORTED;
     // work items pack (view*T + tile) into 28 bits (kItemTileMask)
     if ((int64_t)d->num_views * num_tiles(*d) >= (int64_t)1 << 28) return LSR_EUNSUPPORTED;
-    // pair counts and tile offsets are 32-bit: every Gaussian can touch every tile
+    // (view, Gaussian) slots are indexed with 31 bits; a quadrant-list entry keeps the Gaussian index in 28
     if ((int64_t)d->num_views * d->num_gaussians >= (int64_t)1 << 31) return LSR_EUNSUPPORTED;
+    if ((int64_t)d->num_gaussians > (int64_t)1 << 28) return LSR_EUNSUPPORTED;
     // per-view strides: 0 (shared scene) or exactly one dense (G, ...) array per view
     const int64_t G = d->num_gaussians;
     const int64_t color_elems = d->color_mode == LSR_COLOR_SH ? (int64_t)d->sh_coeffs * 3 : 3;
@@ -325,6 +326,7 @@ int lsr_get_layout(const lsr_dims *d, int64_t num_pairs, lsr_layout *out) {
     out->geom_rec = L.rec; out->geom_rec_floats = (size_t)L.rec_floats; out->geom_bin = L.bin;
     out->geom_tile_count = L.tile_count; out->geom_tile_start = L.tile_start; out->geom_header = L.header;
     out->bin_keys = B.keys; out->bin_point_list = B.point_list;
+    out->bin_quad_list = B.quad_list; out->geom_quad_count = L.quad_count; out->key_index_shift = (size_t)key_index_shift(d->num_gaussians);
     out->img_final_T = I.final_T; out->img_n_contrib = I.n_contrib;
     out->geom_bin_stride = bin_stride(*d);
     return LSR_OK;

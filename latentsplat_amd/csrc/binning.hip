@@ -4,8 +4,9 @@
 //
 //   k_tile_scan : exclusive scan of the per-tile pair counts (V*T entries) -> tile_start,
 //                 total pair count and the longest list (header[0], header[1]); also emits the
-//                 compositing work items ordered longest-list-first (counting sort) — the work
-//                 queue order of both compositing kernels (longest-processing-time-first balancing).
+//                 compositing work items — four (view, tile, quadrant) items per tile — ordered
+//                 longest-list-first (counting sort): the work queue order of both compositing
+//                 kernels (longest-processing-time-first balancing).
 //   k_scatter   : every visible Gaussian writes (depth_bits<<32 | index) into each tile segment
 //                 it overlaps.  Slots come from a two-level reservation: LDS counters per block,
 //                 then ONE global atomic per (block, tile).
@@ -13,7 +14,7 @@
 //                 fallback).  Ascending (depth bits, index)
 //                 == the published stable sort by depth with ties in emission (= index) order,
 //                 so lists are bit-exact whatever order the scatter produced.
-#include "lsr_internal.h"
+#include "lsr_blend.h"
 #include <algorithm>
 #ifdef LSR_ENABLE_TRACE
 #include <cstdio>
@@ -66,8 +67,7 @@ __device__ __forceinline__ uint32_t block_max(uint32_t v, uint32_t *s_wave) {
 
 __global__ void __launch_bounds__(kScanThreads)
 k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *header,
-            uint32_t *host_mirror, uint32_t *__restrict__ order, int N, int force_base, int limit_pct, uint32_t slots,
-            uint32_t capacity) {
+            uint32_t *host_mirror, uint32_t *__restrict__ order, int N, uint32_t capacity) {
     __shared__ uint32_t s_wave[kScanWaves];
     __shared__ uint32_t s_cls[kScanThreads];      // counting-sort classes: histogram -> running offsets
     const int tid = threadIdx.x;
@@ -91,29 +91,14 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
         if (host_mirror) { host_mirror[0] = total; host_mirror[1] = maxc; }
     }
     // ---- work items, costliest first: counting sort on kScanThreads classes of the per-tile cost
-    // (= list length.  A finer estimate — quadrants reached per entry, accumulated by k_preprocess —
-    // was measured to schedule no better and was removed).  Tiles are split into 2 or 4 quadrant-set
-    // items when there are fewer tiles than wave slots, and when their list is much longer than the
-    // mean (lsr_internal.h kItem*). ----
+    // (= canonical list length; the four quadrant items of a tile stay together).  The exact quadrant list
+    // lengths only exist after k_sort_tiles; the order is a scheduling hint (longest-processing-time
+    // first for the compositing kernels' work queue), never a correctness matter. ----
     const uint64_t scale = (uint64_t)maxc + 1u;
-    uint32_t base = (uint32_t)N >= slots ? 1u : (2u * (uint32_t)N >= slots ? 2u : 4u);
-    if (force_base) base = (uint32_t)force_base;
-    const uint32_t mean = total / (uint32_t)N + 1u;
-    const uint32_t limit = (uint32_t)((uint64_t)mean * (uint32_t)limit_pct / 100u) / base + 1u;   // longest list one item may walk
-    auto nsplit = [&](uint32_t c) -> uint32_t {
-        uint32_t sp = base;
-        while (sp < 4u && c / sp > limit) sp <<= 1;
-        return sp;
-    };
-    auto cls = [&](uint32_t w, uint32_t sp) -> uint32_t {
-        return kScanThreads - 1 - (uint32_t)(((uint64_t)(w / sp) * kScanThreads) / scale);
-    };
+    auto cls = [&](uint32_t w) -> uint32_t { return kScanThreads - 1 - (uint32_t)(((uint64_t)w * kScanThreads) / scale); };
     s_cls[tid] = 0;
     __syncthreads();
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t sp = nsplit(count[i]);
-        atomicAdd(&s_cls[cls(count[i], sp)], sp);
-    }
+    for (int i = lo; i < hi; ++i) atomicAdd(&s_cls[cls(count[i])], 4u);
     __syncthreads();
     const uint32_t mine = s_cls[tid];
     uint32_t num_items;
@@ -122,11 +107,8 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
     if (tid == 0) header[kHdrNumItems] = num_items;
     __syncthreads();
     for (int i = lo; i < hi; ++i) {
-        const uint32_t sp = nsplit(count[i]);
-        const uint32_t at = atomicAdd(&s_cls[cls(count[i], sp)], sp);
-        if (sp == 1) order[at] = (uint32_t)i | (0xFu << kItemOwnShift);
-        else if (sp == 2) { order[at] = (uint32_t)i | (0x3u << kItemOwnShift); order[at + 1] = (uint32_t)i | (0xCu << kItemOwnShift); }
-        else for (uint32_t q = 0; q < 4; ++q) order[at + q] = (uint32_t)i | ((1u << q) << kItemOwnShift);
+        const uint32_t at = atomicAdd(&s_cls[cls(count[i])], 4u);
+        for (uint32_t q = 0; q < 4; ++q) order[at + q] = (uint32_t)i | (q << kItemQuadShift);
     }
 }
 
@@ -136,8 +118,7 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror
     prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
                        (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
-                       (uint32_t *)(geom + L.header), host_mirror, (uint32_t *)(geom + L.tile_order), N,
-                       env_int("LSR_SPLIT", 0), env_int("LSR_LIMIT", 150), (uint32_t)wave_slots(device_cus()), pair_capacity);
+                       (uint32_t *)(geom + L.header), host_mirror, (uint32_t *)(geom + L.tile_order), N, pair_capacity);
     prof_end(kStTileScan, s);
     return hipGetLastError();
 }
@@ -150,7 +131,7 @@ template <bool LDS_RESERVE, bool CHECK, bool NARROW>
 __global__ void __launch_bounds__(kScatThreads, 8)
 k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
           const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ tile_cursor,
-          uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, unsigned long long *trace) {
+          uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, int idx_shift, unsigned long long *trace) {
 #ifdef LSR_ENABLE_TRACE
 #define LSR_STAMP(k) do { if (trace && threadIdx.x == 0) trace[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
 #else
@@ -168,7 +149,7 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
     // rectangles stay PACKED in registers between the two passes (narrow records: one word, wide: x0 | y0 << 16,
     // x1 | y1 << 16); the empty asm makes each pass unpack its own copy instead of keeping four coordinates
     // per item live
-    uint32_t lo16[kScatItems], hi16[NARROW ? 1 : kScatItems];
+    uint32_t lo16[kScatItems], hi16[NARROW ? 1 : kScatItems], span[kScatItems];
     float dep[kScatItems];
     // unconditional loads at clamped addresses (all in flight together; a load under a per-lane condition
     // makes the compiler wait for each one), invalid items become empty rectangles afterwards
@@ -177,11 +158,11 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
         const int i = base + min(it, items - 1) * kScatThreads + (int)threadIdx.x;
         const bool valid = it < items && i < G;
         if (NARROW) {
-            const uint2 br = *(const uint2 *)(binrec + (vo + min(i, G - 1)) * sizeof(BinRec));
-            lo16[it] = valid ? br.x : 0u; dep[it] = __uint_as_float(br.y);
+            const uint3 br = *(const uint3 *)(binrec + (vo + min(i, G - 1)) * sizeof(BinRec));      // rectangle, depth bits, footprint span
+            lo16[it] = valid ? br.x : 0u; dep[it] = __uint_as_float(br.y); span[it] = br.z;
         } else {
-            const uint3 br = *(const uint3 *)(binrec + (vo + min(i, G - 1)) * sizeof(BinRecWide));   // rectangle + depth bits
-            lo16[it] = br.x; hi16[NARROW ? 0 : it] = valid ? br.y : 0u; dep[it] = __uint_as_float(br.z);
+            const uint4 br = *(const uint4 *)(binrec + (vo + min(i, G - 1)) * sizeof(BinRecWide));
+            lo16[it] = br.x; hi16[NARROW ? 0 : it] = valid ? br.y : 0u; dep[it] = __uint_as_float(br.z); span[it] = br.w;
         }
     }
     auto unpack = [&](int it, int &x0, int &y0, int &x1, int &y1) {
@@ -219,14 +200,18 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
         int x0, y0, x1, y1;
         unpack(it, x0, y0, x1, y1);
         if (x1 <= x0 || y1 <= y0) continue;
-        const uint64_t key = ((uint64_t)__float_as_uint(dep[it]) << 32) | i;
+        // key = depth bits << 32 | index << 8 | sub-block code of THIS tile (lsr_internal.h); plain index when the
+        // scene is too large for the 24-bit field (idx_shift == 0)
+        const uint64_t key = ((uint64_t)__float_as_uint(dep[it]) << 32) | (i << idx_shift);
+        const uint32_t sp = span[it];
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) {
                 const int t = y * gx + x;
                 uint32_t pos;
                 if (LDS_RESERVE) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
                 else pos = ts[t] + atomicAdd(&cur[t], 1u);
-                if (!CHECK || pos < capacity) keys[pos] = key;   // CHECK (no-sync forward): tile_scan clamped the offsets to the workspace capacity
+                const uint32_t code = idx_shift ? span_code(sp, x - x0, y - y0) : 0u;
+                if (!CHECK || pos < capacity) keys[pos] = key | code;   // CHECK (no-sync forward): tile_scan clamped the offsets to the workspace capacity
             }
     }
     LSR_STAMP(4);
@@ -246,6 +231,94 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
 
 // ------------------------------------------------------------------------------------------
 constexpr int kSortThreads = 512;
+
+// What k_sort_tiles needs to turn a tile's sorted list into its four quadrant render lists.
+struct QuadOut {
+    const char *binrec;       // [V*G] bin records (only read when the keys carry no sub-block code: idx_shift == 0)
+    uint32_t *quad_list;      // BinLayout::quad_list
+    uint32_t *quad_count;     // GeomLayout::quad_count
+    int G, gx, narrow;
+    int idx_shift;            // key_index_shift(G): 8 = low key byte is the pair's sub-block code, 0 = plain index
+};
+// low key word -> Gaussian index, and the pair's 16-bit sub-block mask (from the code in the key, or from the
+// Gaussian's bin record for oversized scenes)
+struct TileCtx {
+    QuadOut qo;
+    const char *vbin;         // bin records of this tile's view
+    int tx, ty;               // tile coordinates
+    __device__ __forceinline__ uint32_t index_of(uint32_t w) const { return w >> qo.idx_shift; }
+    __device__ __forceinline__ uint32_t mask_of(uint32_t w) const {
+        if (qo.idx_shift) return code_mask(w & 0xFFu);
+        const uint32_t i = min(w, (uint32_t)qo.G - 1u);
+        int rx, ry;
+        uint32_t span;
+        if (qo.narrow) { const BinRec br = ((const BinRec *)vbin)[i]; rx = (int)(br.rect & 0xFFu); ry = (int)((br.rect >> 8) & 0xFFu); span = br.span; }
+        else { const BinRecWide br = ((const BinRecWide *)vbin)[i]; rx = br.rect.x; ry = br.rect.y; span = br.span; }
+        return code_mask(span_code(span, tx - rx, ty - ry));
+    }
+};
+constexpr int kEmitTab = 130;   // uint64 words of LDS scratch emit_quadrant_lists needs
+
+// Block-wide (kSortThreads threads): walks the tile's depth-sorted list in order and appends every entry to
+// the list of each 8x8 quadrant its footprint can reach (order preserved), as `index | 4 sub-block
+// bits << 28`.  low_word(p) = low key word of sorted position p.  A pass covers 64 wave-chunks of 64
+// positions: per chunk and quadrant a ballot count (four 16-bit fields of one u64), one wave scans the 64
+// chunk totals, then every entry's place is chunk offset + lanes below it in the ballot.
+// qdst = quad_list + 4 * tile_start: the list of quadrant q starts at qdst + q * n.
+template <class LowWord>
+__device__ __forceinline__ void emit_quadrant_lists(const TileCtx &tc, uint32_t n, uint32_t *qdst, uint32_t *qcnt, uint64_t *s_tab, LowWord low_word) {
+    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
+    constexpr int kWaves = kSortThreads / LSR_WAVE, kSteps = LSR_WAVE / kWaves;
+    constexpr uint32_t qsb[4] = {0x0033u, 0x00CCu, 0x3300u, 0xCC00u};
+    uint32_t run[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t base = 0; base < n; base += LSR_WAVE * LSR_WAVE) {
+        // (nothing but `run` lives across the barriers: the second phase reads the words again — the kernel's
+        // register budget decides how many of its workgroups share a CU)
+#pragma unroll
+        for (int st = 0; st < kSteps; ++st) {
+            const uint32_t p = base + (uint32_t)((st * kWaves + wid) * LSR_WAVE + lane);
+            const uint32_t w = low_word(min(p, n - 1));            // unconditional at a clamped position
+            const uint32_t m16 = p < n ? tc.mask_of(w) : 0u;
+            uint64_t packed = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) packed |= (uint64_t)__builtin_popcountll(__ballot((m16 & qsb[q]) != 0u)) << (16 * q);
+            if (lane == 0) s_tab[st * kWaves + wid] = packed;
+        }
+        __syncthreads();
+        if (wid == 0) {
+            const uint64_t v = s_tab[lane];
+            uint64_t incl = v;
+#pragma unroll
+            for (int off = 1; off < LSR_WAVE; off <<= 1) { const uint64_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+            s_tab[LSR_WAVE + lane] = incl - v;
+            if (lane == LSR_WAVE - 1) s_tab[2 * LSR_WAVE] = incl;
+        }
+        __syncthreads();
+        const uint64_t tot = s_tab[2 * LSR_WAVE];
+#pragma unroll
+        for (int st = 0; st < kSteps; ++st) {
+            const uint32_t p = base + (uint32_t)((st * kWaves + wid) * LSR_WAVE + lane);
+            if (base + (uint32_t)((st * kWaves + wid) * LSR_WAVE) >= n) break;   // wave-uniform
+            const uint32_t w = low_word(min(p, n - 1));
+            const uint32_t idx = tc.index_of(w), m16 = p < n ? tc.mask_of(w) : 0u;
+            const uint64_t off = s_tab[LSR_WAVE + st * kWaves + wid];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = (m16 & qsb[q]) != 0u;
+                const uint64_t bal = __ballot(in);
+                if (in) {
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    qdst[(size_t)q * n + run[q] + (uint32_t)((off >> (16 * q)) & 0xFFFFu) + below] =
+                        idx | (quadrant_bits(m16, q) << kQuadBitsShift);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) run[q] += (uint32_t)((tot >> (16 * q)) & 0xFFFFu);
+        __syncthreads();   // s_tab is reused by the next pass
+    }
+    if (tid < 4) qcnt[tid] = tid == 0 ? run[0] : (tid == 1 ? run[1] : (tid == 2 ? run[2] : run[3]));
+}
 
 // One workgroup per (tile, view); list length n <= CAP, keys sorted inside LDS.
 //
@@ -270,7 +343,7 @@ constexpr uint32_t kBucketOverflow = 48;   // longest bucket the in-bucket pass 
 template <int CAP>
 __global__ void __launch_bounds__(kSortThreads)
 k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
-             uint32_t *__restrict__ point_list, uint32_t longer_than, unsigned long long *trace) {
+             uint32_t *__restrict__ point_list, QuadOut qo, uint32_t longer_than, unsigned long long *trace) {
 #ifdef LSR_ENABLE_TRACE
 #define LSR_STAMP(k) do { if (trace && threadIdx.x == 0) trace[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
 #else
@@ -287,10 +360,28 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
     const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
     const size_t vt = blockIdx.x;   // view-major (view, tile)
     const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
-    if (n == 0 || n <= longer_than) return;   // shorter lists belong to another launch (no-sync forward: two variants)
+    uint32_t *qcnt = qo.quad_count + 4 * vt, *qdst = qo.quad_list + 4 * (size_t)start;
+    if (n == 0) { if (longer_than == 0 && tid < 4) qcnt[tid] = 0; return; }
+    if (n <= longer_than) return;   // shorter lists belong to another launch (no-sync forward: two variants)
     if (n > (uint32_t)CAP) return;  // handled by a larger variant / the global-memory path
     const uint64_t *src = keys + start;
-    if (n == 1) { if (tid == 0) point_list[start] = (uint32_t)src[0]; return; }
+    const int tile = (int)(vt % (size_t)T);
+    TileCtx tc;
+    tc.qo = qo; tc.tx = tile % qo.gx; tc.ty = tile / qo.gx;
+    tc.vbin = qo.binrec + (vt / (size_t)T) * (size_t)qo.G * (qo.narrow ? sizeof(BinRec) : sizeof(BinRecWide));
+    if (n == 1) {
+        if (tid == 0) {
+            const uint32_t w = (uint32_t)src[0], idx = tc.index_of(w);
+            point_list[start] = idx;
+            const uint32_t m = tc.mask_of(w);
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t bits = quadrant_bits(m, q);
+                if (bits) qdst[q] = idx | (bits << kQuadBitsShift);
+                qcnt[q] = bits ? 1u : 0u;
+            }
+        }
+        return;
+    }
 
     constexpr bool REG = CAP <= 4096;
     constexpr int PERK = REG ? CAP / kSortThreads : 1;
@@ -390,14 +481,16 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
                     dst[q] = lo + below;
                 }
             }
-            __syncthreads();   // all reads of the key array done: its storage becomes the index list
+            __syncthreads();   // all reads of the key array done: its storage becomes the sorted list of low key words
             uint32_t *s_out = (uint32_t *)s_keys;
 #pragma unroll
             for (int q = 0; q < PERK; ++q)
                 if (tid + q * kSortThreads < n) s_out[dst[q]] = (uint32_t)kreg[q];
             __syncthreads();
             LSR_STAMP(5);
-            for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = s_out[i];
+            for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = tc.index_of(s_out[i]);
+            // quadrant render lists (the bucket offsets in s_cnt are dead: scratch of the emitter)
+            emit_quadrant_lists(tc, n, qdst, qcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return s_out[p]; });
             LSR_STAMP(6);
         } else {
             // ---- lists beyond the register budget: scatter with a second atomic (s_cnt[b] ends up as the
@@ -417,7 +510,8 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
                 }
             }
             __syncthreads();
-            for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = (uint32_t)(s_keys[i] & 0xffffffffull);
+            for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = tc.index_of((uint32_t)s_keys[i]);
+            emit_quadrant_lists(tc, n, qdst, qcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return (uint32_t)s_keys[p]; });
         }
     } else {
         // ---- bitonic network over the padded list ----
@@ -445,7 +539,8 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
                 __syncthreads();
             }
         }
-        for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = (uint32_t)(s_keys[i] & 0xffffffffull);
+        for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = tc.index_of((uint32_t)s_keys[i]);
+        emit_quadrant_lists(tc, n, qdst, qcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return (uint32_t)s_keys[p]; });
     }
 #ifdef LSR_ENABLE_TRACE
     if (trace && tid == 0) {
@@ -468,7 +563,8 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t 
 }
 __global__ void __launch_bounds__(kSortThreads)
 k_sort_tiles_global(int T, uint32_t cap, const uint32_t *__restrict__ tile_start,
-                    uint64_t *keys, uint64_t *tmp, uint32_t *__restrict__ point_list) {
+                    uint64_t *keys, uint64_t *tmp, uint32_t *point_list, QuadOut qo) {
+    __shared__ uint64_t s_tab[kEmitTab];
     const size_t vt = blockIdx.x;   // view-major (view, tile)
     const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
     if (n <= cap) return;
@@ -488,20 +584,31 @@ k_sort_tiles_global(int T, uint32_t cap, const uint32_t *__restrict__ tile_start
         __syncthreads();
         uint64_t *t = src; src = dst; dst = t;
     }
+    const int tile = (int)(vt % (size_t)T);
+    TileCtx tc;
+    tc.qo = qo; tc.tx = tile % qo.gx; tc.ty = tile / qo.gx;
+    tc.vbin = qo.binrec + (vt / (size_t)T) * (size_t)qo.G * (qo.narrow ? sizeof(BinRec) : sizeof(BinRecWide));
     for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
-        point_list[start + i] = (uint32_t)(src[i] & 0xffffffffull);
+        point_list[start + i] = tc.index_of((uint32_t)src[i]);
+    const uint64_t *sorted = src;
+    emit_quadrant_lists(tc, n, qo.quad_list + 4 * (size_t)start, qo.quad_count + 4 * vt, s_tab, [&](uint32_t p) { return (uint32_t)sorted[p]; });
 }
 
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
                           int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts) {
     (void)radii;
-    if (num_pairs <= 0 || d.num_gaussians == 0) return hipSuccess;
     const GeomLayout L = geom_layout(d);
+    if (num_pairs <= 0 || d.num_gaussians == 0)   // nothing to sort: every quadrant render list is empty
+        return launch_clear(geom + L.quad_count, align_up((size_t)d.num_views * (size_t)num_tiles(d) * 16), s);
     // no-sync forward: the merge scratch is always part of the layout (the longest list is unknown)
     const BinLayout B = bin_layout(d, num_pairs, device_counts ? kSortLdsMax + 1 : max_tile_pairs);
     const int T = (int)num_tiles(d), gx = tiles_x(d);
     uint64_t *keys = (uint64_t *)(bin + B.keys);
     uint32_t *plist = (uint32_t *)(bin + B.point_list);
+    QuadOut qo;
+    qo.binrec = geom + L.bin; qo.quad_list = (uint32_t *)(bin + B.quad_list);
+    qo.quad_count = (uint32_t *)(geom + L.quad_count);
+    qo.G = d.num_gaussians; qo.gx = gx; qo.narrow = narrow_bins(d) ? 1 : 0; qo.idx_shift = key_index_shift(d.num_gaussians);
     const uint32_t *ts = (const uint32_t *)(geom + L.tile_start);
     {
         const bool lds = T <= 8192;
@@ -527,7 +634,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         const uint32_t capacity = (uint32_t)(num_pairs < 0xFFFFFFFFll ? num_pairs : 0xFFFFFFFFll);
 #define LSR_SCAT2(LDSR, CHK, NRW, SHM)                                                                         \
     hipLaunchKernelGGL((k_scatter<LDSR, CHK, NRW>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T,  \
-                       (const char *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, strace)
+                       (const char *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, key_index_shift(d.num_gaussians), strace)
 #define LSR_SCAT(LDSR, CHK, SHM) do { if (narrow_bins(d)) LSR_SCAT2(LDSR, CHK, true, SHM); else LSR_SCAT2(LDSR, CHK, false, SHM); } while (0)
         if (lds) { if (device_counts) LSR_SCAT(true, true, (size_t)T * 8); else LSR_SCAT(true, false, (size_t)T * 8); }
         else { if (device_counts) LSR_SCAT(false, true, 0); else LSR_SCAT(false, false, 0); }
@@ -568,7 +675,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
                                       CAPV * 8 + (CAPV < 2048 ? CAPV : 2048) * 4);               \
         hipLaunchKernelGGL((k_sort_tiles<CAPV>), grid, dim3(kSortThreads),                       \
                            (size_t)CAPV * 8 + (size_t)(CAPV < 2048 ? CAPV : 2048) * 4, s,        \
-                           T, ts, (const uint64_t *)keys, plist, longer_than, trace);            \
+                           T, ts, (const uint64_t *)keys, plist, qo, longer_than, trace);        \
     } while (0)
         if (max_tile_pairs <= 1024) LSR_SORT(1024);
         else if (max_tile_pairs <= 2048) LSR_SORT(2048);
@@ -588,7 +695,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
 #undef LSR_SORT
         if (device_counts || max_tile_pairs > cap) {
             hipLaunchKernelGGL(k_sort_tiles_global, grid, dim3(kSortThreads), 0, s, T, (uint32_t)cap,
-                               ts, keys, (uint64_t *)(bin + B.tmp), plist);
+                               ts, keys, (uint64_t *)(bin + B.tmp), plist, qo);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }

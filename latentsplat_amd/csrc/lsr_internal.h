@@ -17,14 +17,14 @@ namespace lsr {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t header, rec, bin, tile_count, tile_start, tile_cursor, tile_order, sh_clamp, total;
+    size_t header, rec, bin, tile_count, tile_start, tile_cursor, tile_order, quad_count, sh_clamp, total;
     int rec_floats;
 };
 struct ImgLayout {
     size_t final_T, n_contrib, total;
 };
 struct BinLayout {
-    size_t keys, point_list, tmp, total;
+    size_t keys, point_list, quad_list, tmp, total;
 };
 // One packed gradient record per (view, Gaussian), accumulated by the compositing backward.  With
 // u = opacity * G * dL/dalpha per (pixel, Gaussian) and d = mean_pix - pixel:
@@ -55,19 +55,38 @@ inline int rec_floats(const lsr_dims &d) {
 // What the binning stage needs of a (view, Gaussian), kept dense so k_scatter streams it: the tile
 // rectangle [minx, miny, maxx, maxy) and the view depth (sort key bits; 0 = culled).  Written for ALL
 // V*G slots by k_preprocess and read back once by k_scatter — both stages are bandwidth-bound, so the
-// record is 8 bytes whenever the tile grid fits byte coordinates (images up to 4080 px a side) and
+// record is 12 bytes whenever the tile grid fits byte coordinates (images up to 4080 px a side) and
 // 16 bytes otherwise.
-struct BinRec {            // narrow form
+struct BinRec {            // narrow form (12 bytes)
     uint32_t rect;         // minx | miny << 8 | maxx << 16 | maxy << 24
     float depth;
+    uint32_t span;         // footprint span in 4-pixel cells (below)
 };
 struct BinRecWide {
     ushort4 rect;
     float depth;
-    uint32_t unused;
+    uint32_t span;
 };
 inline bool narrow_bins(const lsr_dims &d) { return tiles_x(d) <= 255 && tiles_y(d) <= 255; }
 inline size_t bin_stride(const lsr_dims &d) { return narrow_bins(d) ? sizeof(BinRec) : sizeof(BinRecWide); }
+
+// Footprint span of a (view, Gaussian), 4 bytes of its bin record: the axis-aligned bounding box of
+// { alpha >= 1/255 } (lsr_blend.h footprint_cells: conservative, 0.1 % + 0.05 px of slack) in units of
+// 4-pixel CELLS (cell c = pixel centres 4c .. 4c+3 — the grid of the compositing kernels' 4x4 sub-blocks),
+// relative to the first cell of the tile rectangle and saturated to a byte:
+//   x0 | x1 << 8 | y0 << 16 | y1 << 24;   first / last reached cell; a last cell of 255 means "255 or
+//   beyond"; x0 > x1 (kSpanNone) = reaches no pixel at all.
+// k_scatter turns it into the 8-bit sub-block code of every (Gaussian, tile) pair, carried in the low byte of
+// the sort key (below), from which k_sort_tiles builds the per-QUADRANT render lists.
+constexpr uint32_t kSpanNone = 0x00010001u;   // x0 = 1 > x1 = 0
+constexpr uint32_t kSpanAll = 0xFF00FF00u;    // conic not trustworthy: every cell
+// Sort key of a (Gaussian, tile) pair: depth bits << 32 | index << 8 | code, code = c0 | c1 << 2 | r0 << 4 | r1 << 6:
+// the columns c0..c1 and rows r0..r1 (0..3) of the tile's 4x4-pixel sub-blocks the pair can reach
+// (c0 > c1: none).  Indices are distinct inside a tile, so the order is still the published
+// (depth, index) order.  Needs index < 2^24; larger scenes keep `depth << 32 | index` keys
+// (key_index_shift = 0) and k_sort_tiles derives the code from a gather of the bin record instead.
+__host__ __device__ inline int key_index_shift(int num_gaussians) { return num_gaussians <= (1 << 24) ? 8 : 0; }
+constexpr uint32_t kCodeNone = 0x11u;   // c0 = 1 > c1 = 0, r0 = 1 > r1 = 0
 
 inline GeomLayout geom_layout(const lsr_dims &d) {
     GeomLayout L;
@@ -82,6 +101,7 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     L.tile_cursor = o; o = align_up(o + VT * 4);   // adjacent to tile_count: one memset clears both
     L.tile_start = o; o = align_up(o + (VT + 1) * 4);
     L.tile_order = o; o = align_up(o + 4 * VT * 4);   // work items (see kItem*), costliest first
+    L.quad_count = o; o = align_up(o + 4 * VT * 4);   // entries of the four quadrant render lists of every (view, tile)
     L.sh_clamp = o; o = align_up(o + VG);             // per (view, Gaussian): colour channels clamped at 0 (sh.hip)
     L.total = o;
     return L;
@@ -101,7 +121,11 @@ inline BinLayout bin_layout(const lsr_dims &d, int64_t num_pairs, int32_t max_ti
     const size_t P = (size_t)(num_pairs > 0 ? num_pairs : 1);
     L.keys = 0;
     L.point_list = align_up(P * 8);
-    L.tmp = L.point_list + align_up(P * 4);
+    // Quadrant render lists (k_sort_tiles -> compositing kernels): the tile whose canonical list is
+    // point_list[s, s + n) owns quad_list[4 s, 4 s + 4 n); the list of its quadrant q starts at 4 s + q n
+    // and holds quad_count[4 (view T + tile) + q] entries `index | sub-block bits << 28`.
+    L.quad_list = L.point_list + align_up(P * 4);
+    L.tmp = L.quad_list + align_up(P * 16);
     L.total = L.tmp + (max_tile_pairs > kSortLdsMax ? align_up(P * 8) : 0);
     return L;
 }
@@ -121,19 +145,23 @@ inline GradLayout grad_layout(const lsr_dims &d) {
     return L;
 }
 
-// Compositing work items: one wave renders the quadrants in `own` of one (view, tile).
-//   item = (view*T + tile) | own << 28.  k_tile_scan emits them costliest-first.  When there are
-//   fewer tiles than wave slots every tile is split into 2 or 4 items (disjoint quadrant sets) to
-//   fill the machine.  Tiles whose list is longer than 1.5x the mean are split as well (LSR_LIMIT =
-//   percent of the mean, default 150): per-item traces on MI355X show that the launch ends with the
-//   ONE wave that walks the longest list (its serial chain, 1.8x the mean list, outlasts every
-//   balanced SIMD total by ~20 %); halving those few items costs a second staging of their entries
-//   and took the 16-view launch from 0.55 to 0.51 ms.  Splitting more (<= 130 %) loses again.
+// Compositing work items: one wave renders ONE 8x8 quadrant of one (view, tile), walking that quadrant's
+// render list (BinLayout::quad_list: only the entries whose alpha >= 1/255 footprint box reaches the
+// quadrant, each with the 4-bit mask of the quadrant's 4x4 sub-blocks it can reach).
+//   item = (view*T + tile) | quadrant << 28.  k_tile_scan emits the four items of every tile, longest
+//   canonical list first (the work-queue order of both compositing kernels).
+// Rounds 1-2 walked the canonical tile list per item and re-derived the masks per staged entry; splitting a
+// tile into quadrant items then cost a full re-staging of its list, so a 16-view launch ran one
+// whole tile per wave slot and ended 25 % after its average wave.  With per-quadrant lists an item stages
+// only what it evaluates, so items are a quarter of the size and the queue levels the SIMDs.
+
 // Input slice a view reads: its own (per-view strides), its group's, or the shared one (stride 0).
 __host__ __device__ inline int input_slice(const lsr_dims &d, int v) { return d.views_per_group > 1 ? v / d.views_per_group : v; }
 
 constexpr uint32_t kItemTileMask = 0x0FFFFFFFu;
-constexpr int kItemOwnShift = 28;
+constexpr int kItemQuadShift = 28;
+constexpr uint32_t kQuadIndexMask = 0x0FFFFFFFu;   // quad_list entry = Gaussian index | sub-block bits << 28
+constexpr int kQuadBitsShift = 28;
 // The compositing kernels run one 16-wave workgroup (4 waves per SIMD) per compute unit; the number
 // of CUs is queried per device (api.hip), so a partitioned (CPX) or binned part gets its own static
 // assignment.  wave slots = CUs x SIMDs x resident compositing waves per SIMD.

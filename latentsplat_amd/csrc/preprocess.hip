@@ -6,7 +6,7 @@
 // Build this file with -ffp-contract=off: radius / rectangle / depth bits feed the bit-exact
 // tile lists, so every float operation must be the single IEEE operation written here (the CPU
 // oracle performs the identical sequence).  Spec: SURVEY.md Appendix A.1-A.3.
-#include "lsr_internal.h"
+#include "lsr_blend.h"
 
 namespace lsr {
 
@@ -188,18 +188,20 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
                     }
             }
             if (in_range) {
+                // footprint span for the per-quadrant render lists (k_scatter / k_sort_tiles); not part of the bit-exact contract
+                const uint32_t span = ok ? footprint_cells(px, py, conic_a, conic_b, conic_c, opacity, rminx, rminy) : kSpanNone;
                 radii[o] = ok ? (int32_t)my_radius : 0;
                 const float out_depth = ok ? tz : 0.0f;
                 if (narrow) {
                     BinRec br;
                     br.rect = ok ? ((uint32_t)rminx | ((uint32_t)rminy << 8) | ((uint32_t)rmaxx << 16) | ((uint32_t)rmaxy << 24)) : 0u;
-                    br.depth = out_depth;
+                    br.depth = out_depth; br.span = span;
                     ((BinRec *)binrec)[o] = br;
                 } else {
                     BinRecWide br;
                     br.rect = ok ? make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy)
                                  : make_ushort4(0, 0, 0, 0);
-                    br.depth = out_depth; br.unused = 0u;
+                    br.depth = out_depth; br.span = span;
                     ((BinRecWide *)binrec)[o] = br;
                 }
             }

@@ -18,14 +18,15 @@
 // into dL/d(x, y), dL/d(A, B, C), dL/d opacity are applied ONCE per (view, Gaussian) by
 // k_preprocess_bwd (they are constant over the pixels), not per evaluation.
 //
-// Execution shape: one lane = one pixel, one 16-lane group = one 4x4 sub-block walking its own
+// Execution shape: the forward's work items (one 8x8 quadrant of a tile per wave, walking that quadrant's
+// render list); one lane = one pixel, one 16-lane group = one 4x4 sub-block walking its own
 // compacted list (as in the forward), so a wave instruction serves up to four different entries.
 // The contributions of a group's 16 pixels are summed by a transposed butterfly INSIDE the DPP row
 // (row_ror / row_half_mirror / quad_perm — full-rate, no permlane, no LDS): afterwards lane s of
 // the group holds gradient slot s, and ONE ds_add_f32 instruction adds the four groups' records
-// into a per-batch LDS table (row = staged entry).  When the batch's four rounds are done the
-// touched rows are flushed with coalesced global atomics, one 64-byte record per 16 lanes: one
-// global record-add per (Gaussian, tile) pair instead of one per (entry, wave) reduction of 64
+// into a per-batch LDS table (row = staged entry).  When the batch is done the rows are flushed with
+// coalesced global atomics, one 64-byte record per 16 lanes: one global record-add per entry of a
+// quadrant list (1.2 per (Gaussian, tile) pair) instead of one per (entry, wave) reduction of 64
 // lanes + atomic in round 1 of this kernel (that reduction was ~40 % of its time).
 // Spec: SURVEY.md Appendix A.6.
 #include "lsr_blend.h"
@@ -45,13 +46,13 @@ typedef float float4_b __attribute__((ext_vector_type(4)));
 struct RenderBwdParams {
     int H, W, gx, T, G, C, has_color;
     int num_cus;                  // workgroups of 4*WPS waves (one per compute unit)
-    const uint32_t *items;        // work items of the forward (view*T + tile | quadrant set << 28), costliest first
+    const uint32_t *items;        // work items of the forward (view*T + tile | quadrant << 28), costliest first
     const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t *queue;              // work-queue head (zeroed with the gradient workspace)
     const float *views;
     const float4 *geo;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
     int rec_f4;
-    const uint32_t *tile_start, *point_list;
+    const uint32_t *tile_start, *quad_list;
     const float *final_T;
     const uint32_t *n_contrib;
     const float *g_color, *g_feat, *g_mask, *g_depth;  // dL/d outputs (any may be NULL)
@@ -220,11 +221,10 @@ __device__ __forceinline__ float row_reduce_8ch(float a0, float a1, float a2, fl
 __device__ __forceinline__ void atomic_add_f32(float *addr, float v) { unsafeAtomicAdd(addr, v); }
 
 // WPS = resident waves per SIMD (workgroup = 4*WPS waves = one compute unit's worth): 4 where the
-// per-wave LDS slice allows it, 3 for the 8-channel payload, 1 for the widest.
+// per-wave LDS slice allows it, fewer for the wide payloads.
 template <int NCHP, bool DEPTH_GRAD, int WPS>
 __global__ void __launch_bounds__(LSR_WAVE * 4 * WPS)
 k_render_bwd(RenderBwdParams p) {
-    constexpr int PXL = 4;
     constexpr int WPB = 4 * WPS;
     // float4 per staged entry: odd (conflict-free staging stores) except for the 8-channel payload, whose
     // 16 floats are stored at a 64-byte stride (2-way conflicts in the staging stores only) so that the
@@ -237,11 +237,12 @@ k_render_bwd(RenderBwdParams p) {
     // depth gradient is on, 7) for the 8-channel payload (same LDS budget), the full record otherwise
     constexpr bool kPackRow = NCHP == 8 && !DEPTH_GRAD;
     constexpr int RT = kPackRow ? 14 : RF;
+    constexpr int kListRow = LSR_WAVE + 2;    // u16 per list row: 33 words, so the four lane groups' reads of list[b][i] hit four banks
     struct Lds {
         float4 ent[WPB][LSR_WAVE + 1][kEnt];   // (x, y, a2, c2) (b2, log2 o, z, list position) payload...; slot 64 = null record
         float acc[WPB][LSR_WAVE + 1][RT];      // this batch's gradient records, row = staged entry (row 64: dump row of the null record)
         uint32_t gid[WPB][LSR_WAVE];           // Gaussian index of the staged entry
-        uint16_t list[WPB][16][LSR_WAVE];      // per sub-block: staging slots of the entries that can reach it, in list order
+        uint16_t list[WPB][4][kListRow];       // per sub-block: staging slots of the entries that can reach it, in list order
     };
     __shared__ Lds s_lds;
 
@@ -250,7 +251,7 @@ k_render_bwd(RenderBwdParams p) {
     float4 (*s_ent)[kEnt] = s_lds.ent[wid];
     float (*s_acc)[RT] = s_lds.acc[wid];
     uint32_t *s_gid = s_lds.gid[wid];
-    uint16_t (*s_list)[LSR_WAVE] = s_lds.list[wid];
+    uint16_t (*s_list)[kListRow] = s_lds.list[wid];
     {   // null record + cleared gradient table (rows are re-zeroed by the flush)
         if (lane == 0) {
             s_ent[LSR_WAVE][0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -258,6 +259,7 @@ k_render_bwd(RenderBwdParams p) {
 #pragma unroll
             for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
+        if (lane < 8) s_list[lane >> 1][LSR_WAVE + (lane & 1)] = (uint16_t)LSR_WAVE;   // the rows' pad words
         float *A = &s_acc[0][0];
         for (int i = lane; i < (LSR_WAVE + 1) * RT; i += LSR_WAVE) A[i] = 0.0f;
     }
@@ -266,7 +268,6 @@ k_render_bwd(RenderBwdParams p) {
     const size_t HW = (size_t)p.H * p.W;
     const int grp = lane >> 4, gcol = grp & 1, grow = grp >> 1, l16 = lane & 15;
     const int tcol = kPackRow ? (l16 < 8 ? l16 : l16 - 2) : l16;   // this lane's record slot -> column of the table row (slots 6, 7 unused when packed)
-    const int gsb = 4 * grow + gcol;
     const int lx = lane & 3, ly = (lane >> 2) & 3;
 
     const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = simd_bins * (uint32_t)WPS;
@@ -289,23 +290,22 @@ k_render_bwd(RenderBwdParams p) {
         }
         qi = __builtin_amdgcn_readfirstlane(qi);
         const uint32_t item = p.items[qi];
-        const uint32_t vt = item & kItemTileMask, own = item >> kItemOwnShift;
-        const uint32_t own16 = own_subblocks(own);
+        const uint32_t vt = item & kItemTileMask, quad = item >> kItemQuadShift;
         const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
-        const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE;
+        const int tx0 = (tile % p.gx) * LSR_TILE + 8 * (int)(quad & 1u), ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)(quad >> 1);
         const size_t vG = (size_t)v * p.G;
-        const uint32_t start = p.tile_start[vt];
+        const uint32_t tstart = p.tile_start[vt], tn = p.tile_start[vt + 1] - tstart;
+        const uint32_t *qlist = p.quad_list + 4 * (size_t)tstart + (size_t)quad * tn;
 
-        float2_b pxy[PXL];
-        float Tr[PXL], Rr[PXL], ddep[PXL];
-        float2_b dpix[PXL][NCHP / 2];
-        uint32_t last[PXL];
-        uint32_t maxlast = 0;
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) {
-            const int px = tx0 + 8 * (k & 1) + 4 * gcol + lx, py = ty0 + 8 * (k >> 1) + 4 * grow + ly;
-            pxy[k] = float2_b{(float)px, (float)py};
-            const bool inside = px < p.W && py < p.H && ((own >> k) & 1u);
+        float2_b pxy;
+        float Tr, Rr, ddep;
+        float2_b dpix[NCHP / 2];
+        uint32_t last;
+        uint32_t maxlast;
+        {
+            const int px = tx0 + 4 * gcol + lx, py = ty0 + 4 * grow + ly;
+            pxy = float2_b{(float)px, (float)py};
+            const bool inside = px < p.W && py < p.H;
             // every per-pixel load is issued UNCONDITIONALLY at a clamped pixel (all of a row's loads in
             // flight together) and masked afterwards: loads under the per-lane `inside` test were waited
             // for one by one — ~30 serial round trips at the head of every item
@@ -334,9 +334,9 @@ k_render_bwd(RenderBwdParams p) {
             const float gmask_l = p.g_mask ? p.g_mask[vp] : 0.0f;
             const float gdep_l = DEPTH_GRAD ? p.g_depth[vp] : 0.0f, fdep_l = DEPTH_GRAD ? p.f_depth[vp] : 0.0f;
             const float Tfin = inside ? Tfin_l : 1.0f;
-            Tr[k] = 1.0f;
-            last[k] = inside ? nc_l : 0u;
-            maxlast = max(maxlast, last[k]);
+            Tr = 1.0f;
+            last = inside ? nc_l : 0u;
+            maxlast = last;
             // R_0 = g . (rendered - T_final * bg)  +  T_final * (g . bg - g_mask)  =  g . rendered - T_final * g_mask
             float r0 = 0.0f;
             float dp[NCHP];
@@ -347,208 +347,187 @@ k_render_bwd(RenderBwdParams p) {
             }
             r0 = __builtin_fmaf(-Tfin, inside ? gmask_l : 0.0f, r0);  // mask = 1 - T_final
 #pragma unroll
-            for (int c = 0; c < NCHP / 2; ++c) dpix[k][c] = float2_b{dp[2 * c], dp[2 * c + 1]};
-            ddep[k] = (DEPTH_GRAD && inside) ? gdep_l : 0.0f;
-            if (DEPTH_GRAD) r0 = __builtin_fmaf(fdep_l, ddep[k], r0);
-            Rr[k] = r0;
+            for (int c = 0; c < NCHP / 2; ++c) dpix[c] = float2_b{dp[2 * c], dp[2 * c + 1]};
+            ddep = (DEPTH_GRAD && inside) ? gdep_l : 0.0f;
+            if (DEPTH_GRAD) r0 = __builtin_fmaf(fdep_l, ddep, r0);
+            Rr = r0;
         }
-        // wave-uniform upper bound of the entries any owned pixel has to consider
+        // wave-uniform upper bound of the list entries any pixel has to consider
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) maxlast = max(maxlast, (uint32_t)__shfl_xor((int)maxlast, off));
         maxlast = __builtin_amdgcn_readfirstlane(maxlast);
 
-        // software-pipelined staging as in the forward: records of batch b+1 and list indices of
+        // software-pipelined staging as in the forward: records of batch b+1 and list entries of
         // batch b+2 are in flight while batch b is processed
         // (unconditional loads at clamped positions, see the forward: a load under a per-lane condition is
         // waited for at the join)
-        struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t g; };
+        struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t w; };
         const uint32_t lastrel = maxlast - 1u;   // only used when maxlast > 0
-        auto load_idx = [&](uint32_t rel) -> uint32_t { return p.point_list[start + min(rel, lastrel)]; };
-        auto load_rec = [&](uint32_t g) {
+        auto load_ent = [&](uint32_t rel) -> uint32_t { return qlist[min(rel, lastrel)]; };
+        auto load_rec = [&](uint32_t w) {
             StageRec r;
-            r.g = g;
-            const float4 *R = p.geo + (vG + g) * (size_t)p.rec_f4;
+            r.w = w;
+            const float4 *R = p.geo + (vG + (w & kQuadIndexMask)) * (size_t)p.rec_f4;
             r.a = R[0]; r.b = R[1];
 #pragma unroll
             for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];
             return r;
         };
-        uint32_t g_ahead = 0;
+        uint32_t w_ahead = 0;
         StageRec nxt;
-        nxt.g = 0;
+        nxt.w = 0;
         nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
         for (int c4 = 0; c4 < NCHP / 4; ++c4) nxt.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (maxlast > 0) {   // wave-uniform
-            g_ahead = load_idx(lane);
-            nxt = load_rec(g_ahead);
-            g_ahead = load_idx(LSR_WAVE + lane);
+            w_ahead = load_ent(lane);
+            nxt = load_rec(w_ahead);
+            w_ahead = load_ent(LSR_WAVE + lane);
         }
 
         for (uint32_t cbase = 0; cbase < maxlast; cbase += LSR_WAVE) {
             const StageRec cur = nxt;
-            nxt = load_rec(g_ahead);
-            g_ahead = load_idx(cbase + 2 * LSR_WAVE + lane);
+            nxt = load_rec(w_ahead);
+            w_ahead = load_ent(cbase + 2 * LSR_WAVE + lane);
             // ---- stage up to 64 list entries (one per lane) ----
-            {   // every list slot starts as the null record's slot
-                const uint32_t n2 = (uint32_t)LSR_WAVE | ((uint32_t)LSR_WAVE << 16);
-                const uint4 nul = make_uint4(n2, n2, n2, n2);
-                uint4 *L4 = (uint4 *)&s_list[0][0];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) L4[q * LSR_WAVE + lane] = nul;
-            }
-            const uint32_t rel = cbase + lane;  // 0-based position in the list
-            uint32_t m = 0;
-            if (rel < maxlast) {
+            for (int b = 0; b < 4; ++b) s_list[b][lane] = (uint16_t)LSR_WAVE;   // every list slot starts as the null record's slot
+            const uint32_t rel = cbase + lane;  // 0-based position in the quadrant's list
+            const uint32_t m = rel < maxlast ? (cur.w >> kQuadBitsShift) : 0u;
+            if (m) {
                 const float4 a = cur.a, b = cur.b;
-                m = subblock_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own16;
-                if (m) {
-                    const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);   // same folding as the forward
-                    s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
-                    s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z, __uint_as_float(rel + 1u));
+                const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);   // same folding as the forward
+                s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
+                s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z, __uint_as_float(rel + 1u));
 #pragma unroll
-                    for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[lane][2 + c4] = cur.pay[c4];
-                    s_gid[lane] = cur.g;
-                }
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[lane][2 + c4] = cur.pay[c4];
+                s_gid[lane] = cur.w & kQuadIndexMask;
             }
             const uint64_t staged = __ballot(m != 0);
             // compaction: per sub-block, the staged entries that can reach it, in list order.  An entry
-            // that sits at the SAME position in the lists of two sub-blocks of one quadrant will be
-            // processed by two lane groups in the same iteration; their updates of the entry's table row
-            // are ordered by a rank (number of lower sub-blocks of the quadrant holding the entry at that
-            // position), computed here once per staged entry and stored with the list element:
-            //   list element = staging slot | rank << 8.
-            uint32_t cnt[16], at[16];
+            // that sits at the SAME position in the lists of two sub-blocks will be processed by two lane
+            // groups in the same iteration; their updates of the entry's table row are ordered by a rank
+            // (number of lower sub-blocks holding the entry at that position), computed here once per
+            // staged entry and stored with the list element:   list element = staging slot | rank << 8.
+            uint32_t nk = 0, at[4];
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                cnt[b] = 0; at[b] = 0xFFFFu;           // 0xFFFF: not in this list
-                if (!((own16 >> b) & 1u)) continue;   // wave-uniform
+            for (int b = 0; b < 4; ++b) {
+                at[b] = 0xFFFFu;           // 0xFFFF: not in this list
                 const uint64_t bal = __ballot((m >> b) & 1u);
-                cnt[b] = (uint32_t)__builtin_popcountll(bal);
+                nk = max(nk, (uint32_t)__builtin_popcountll(bal));
                 if (__builtin_amdgcn_inverse_ballot_w64(bal))
                     at[b] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
             }
+            nk = __builtin_amdgcn_readfirstlane(nk);
 #pragma unroll
-            for (int k = 0; k < PXL; ++k) {
-                if (!((own >> k) & 1u)) continue;     // wave-uniform
-                const int q0 = 8 * (k >> 1) + 2 * (k & 1);
-                const int sb[4] = {q0, q0 + 1, q0 + 4, q0 + 5};   // lane groups 0..3 of the round
+            for (int j = 0; j < 4; ++j) {
+                if (at[j] == 0xFFFFu) continue;
+                uint32_t rank = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (at[sb[j]] == 0xFFFFu) continue;
-                    uint32_t rank = 0;
-#pragma unroll
-                    for (int jj = 0; jj < j; ++jj) rank += (uint32_t)(at[sb[jj]] == at[sb[j]]);
-                    s_list[sb[j]][at[sb[j]]] = (uint16_t)((uint32_t)lane | (rank << 8));
-                }
+                for (int jj = 0; jj < j; ++jj) rank += (uint32_t)(at[jj] == at[j]);
+                s_list[j][at[j]] = (uint16_t)((uint32_t)lane | (rank << 8));
             }
             wave_lds_fence_bwd();
 
+            const uint16_t *lp = &s_list[grp][0];
+            for (uint32_t i = 0; i < nk; ++i) {
+                const uint32_t lel = lp[i];
+                const uint32_t slot = lel & 0xFFu, rank = lel >> 8;
+                const float4_b *E = (const float4_b *)&s_ent[slot][0];
+                float *row = &s_acc[slot][tcol];
+                float acc_old[NGRP];                             // this lane's word(s) of the entry's table row, read early
 #pragma unroll
-            for (int k = 0; k < PXL; ++k) {
-                const int b0 = 8 * (k >> 1) + 2 * (k & 1);
-                const uint32_t nk = __builtin_amdgcn_readfirstlane(max(max(cnt[b0], cnt[b0 + 1]), max(cnt[b0 + 4], cnt[b0 + 5])));
-                if (nk == 0) continue;   // wave-uniform
-                const uint16_t *lp = &s_list[b0 + gsb][0];
-                for (uint32_t i = 0; i < nk; ++i) {
-                    const uint32_t lel = lp[i];
-                    const uint32_t slot = lel & 0xFFu, rank = lel >> 8;
-                    const float4_b *E = (const float4_b *)&s_ent[slot][0];
-                    float *row = &s_acc[slot][tcol];
-                    float acc_old[NGRP];                             // this lane's word(s) of the entry's table row, read early
+                for (int gi = 0; gi < NGRP; ++gi) acc_old[gi] = row[16 * gi];
+                float4_b a = E[0], b = E[1], t4[NCHP / 4];
 #pragma unroll
-                    for (int gi = 0; gi < NGRP; ++gi) acc_old[gi] = row[16 * gi];
-                    float4_b a = E[0], b = E[1], t4[NCHP / 4];
-#pragma unroll
-                    for (int c4 = 0; c4 < NCHP / 4; ++c4) t4[c4] = E[2 + c4];
-                    // Two or more lane groups can be at the SAME staged entry in this iteration (44 % of the
-                    // iterations on the bench scene): their read-modify-writes of the entry's table row are
-                    // ordered by the rank stored with the list element.  Rank 0 updates with the early-read
-                    // row; rank r > 0 re-reads the row after rank r-1 has written (a wave's LDS operations
-                    // execute in order).
-                    auto accumulate = [&](float *dst, float old, float tot, bool live) {
-                        if (live && rank == 0u) *dst = old + tot;
-                        uint64_t later = __ballot(rank != 0u);
-                        for (uint32_t r = 1; later; ++r) {      // wave-uniform, usually no or one round
-                            wave_lds_fence_bwd();
-                            if (live && rank == r) *dst = *dst + tot;
-                            later &= ~__ballot(rank == r);
-                        }
-                    };
-                    // keep the record reads whole 16-byte LDS loads into aligned register tuples (left alone
-                    // the compiler splits them by use and re-pairs the packed operands with moves)
-                    asm volatile("" : "+v"(a), "+v"(b));
-                    float2_b pay[NCHP / 2];
-#pragma unroll
-                    for (int c4 = 0; c4 < NCHP / 4; ++c4) {
-                        asm volatile("" : "+v"(t4[c4]));
-                        pay[2 * c4] = float2_b{t4[c4].x, t4[c4].y}; pay[2 * c4 + 1] = float2_b{t4[c4].z, t4[c4].w};
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) t4[c4] = E[2 + c4];
+                // Two or more lane groups can be at the SAME staged entry in this iteration (44 % of the
+                // iterations on the bench scene): their read-modify-writes of the entry's table row are
+                // ordered by the rank stored with the list element.  Rank 0 updates with the early-read
+                // row; rank r > 0 re-reads the row after rank r-1 has written (a wave's LDS operations
+                // execute in order).
+                auto accumulate = [&](float *dst, float old, float tot, bool live) {
+                    if (live && rank == 0u) *dst = old + tot;
+                    uint64_t later = __ballot(rank != 0u);
+                    for (uint32_t r = 1; later; ++r) {      // wave-uniform, usually no or one round
+                        wave_lds_fence_bwd();
+                        if (live && rank == r) *dst = *dst + tot;
+                        later &= ~__ballot(rank == r);
                     }
-                    // same operations as the forward's exponent (two of them packed)
-                    const float2_b d = float2_b{a.x, a.y} - pxy[k];
-                    const float2_b q = float2_b{a.z, a.w} * d;              // (a2 dx, c2 dy)
-                    const float p1 = __builtin_fmaf(b.x, d.y, q.x);
-                    const float p2 = __builtin_fmaf(q.y, d.y, b.y);
-                    const float ex = __builtin_fmaf(p1, d.x, p2);
-                    const float araw = fast_exp2(ex);
-                    const float aclamp = fminf(LSR_ALPHA_MAX, araw);
-                    const bool valid = (__float_as_uint(b.w) <= last[k]) & (ex <= b.y) & (aclamp >= LSR_ALPHA_MIN);
-                    const float alpha = valid ? aclamp : 0.0f;
-                    const float av = valid ? araw : 0.0f;           // opacity * exp(power)
-                    const float om = 1.0f - alpha;
-                    const float rcp1m = __builtin_amdgcn_rcpf(om);
-                    const float Tk = Tr[k];                          // transmittance in front of this entry
-                    const float w = alpha * Tk;
-                    const float2_b ww = float2_b{w, w};
-                    float2_b ds2 = pay[0] * dpix[k][0];              // g . c_i, two channels at a time
+                };
+                // keep the record reads whole 16-byte LDS loads into aligned register tuples (left alone
+                // the compiler splits them by use and re-pairs the packed operands with moves)
+                asm volatile("" : "+v"(a), "+v"(b));
+                float2_b pay[NCHP / 2];
 #pragma unroll
-                    for (int c = 1; c < NCHP / 2; ++c) ds2 = __builtin_elementwise_fma(pay[c], dpix[k][c], ds2);
-                    float dsum = ds2.x + ds2.y;
-                    float2_b gp[NCHP / 2];                           // dL/d payload channel pairs
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) {
+                    asm volatile("" : "+v"(t4[c4]));
+                    pay[2 * c4] = float2_b{t4[c4].x, t4[c4].y}; pay[2 * c4 + 1] = float2_b{t4[c4].z, t4[c4].w};
+                }
+                // same operations as the forward's exponent (two of them packed)
+                const float2_b d = float2_b{a.x, a.y} - pxy;
+                const float2_b q = float2_b{a.z, a.w} * d;              // (a2 dx, c2 dy)
+                const float p1 = __builtin_fmaf(b.x, d.y, q.x);
+                const float p2 = __builtin_fmaf(q.y, d.y, b.y);
+                const float ex = __builtin_fmaf(p1, d.x, p2);
+                const float araw = fast_exp2(ex);
+                const float aclamp = fminf(LSR_ALPHA_MAX, araw);
+                const bool valid = (__float_as_uint(b.w) <= last) & (ex <= b.y) & (aclamp >= LSR_ALPHA_MIN);
+                const float alpha = valid ? aclamp : 0.0f;
+                const float av = valid ? araw : 0.0f;           // opacity * exp(power)
+                const float om = 1.0f - alpha;
+                const float rcp1m = __builtin_amdgcn_rcpf(om);
+                const float Tk = Tr;                             // transmittance in front of this entry
+                const float w = alpha * Tk;
+                const float2_b ww = float2_b{w, w};
+                float2_b ds2 = pay[0] * dpix[0];                 // g . c_i, two channels at a time
 #pragma unroll
-                    for (int c = 0; c < NCHP / 2; ++c) gp[c] = dpix[k][c] * ww;
-                    float gz = 0.0f;
-                    if (DEPTH_GRAD) {
-                        dsum = __builtin_fmaf(b.z, ddep[k], dsum);
-                        gz = w * ddep[k];
-                    }
-                    Rr[k] = __builtin_fmaf(-w, dsum, Rr[k]);         // what is left behind this entry
-                    Tr[k] = Tk * om;
-                    const float dL_dalpha = __builtin_fmaf(Tk, dsum, -Rr[k] * rcp1m);
-                    const float u = av * dL_dalpha;                  // straight through the 0.99 clamp (A.6)
-                    const float2_b t1 = float2_b{u, u} * d;          // u (dx, dy)
-                    const float2_b t2 = t1 * d;                      // u (dx^2, dy^2)
-                    const float mxy = t1.x * d.y;
-                    // ---- sum over the sub-block's 16 pixels; lane s of the group ends up with slot s ----
-                    {
-                        constexpr uint32_t LIVE = 0x3Fu | (DEPTH_GRAD ? 0x40u : 0u) | (((1u << (NCHP < 8 ? NCHP : 8)) - 1u) << 8);
-                        float tot;
-                        if (!DEPTH_GRAD && NCHP == 4) tot = row_reduce_4ch(t1.x, t1.y, t2.x, mxy, t2.y, u, gp[0].x, gp[0].y, gp[1].x, gp[1].y);
-                        else if (!DEPTH_GRAD && NCHP == 8)
-                            tot = row_reduce_8ch(t1.x, t1.y, t2.x, mxy, t2.y, u, gp[0].x, gp[0].y, gp[1].x, gp[1].y,
-                                                 gp[2 % (NCHP / 2)].x, gp[2 % (NCHP / 2)].y, gp[3 % (NCHP / 2)].x, gp[3 % (NCHP / 2)].y);
-                        else tot = row_reduce16_transposed<LIVE>(
-                            t1.x, t1.y, t2.x, mxy, t2.y, u, gz, 0.0f,
-                            gp[0].x, gp[0].y, gp[1].x, gp[1].y,
-                            NCHP > 4 ? gp[2 % (NCHP / 2)].x : 0.0f, NCHP > 4 ? gp[2 % (NCHP / 2)].y : 0.0f,
-                            NCHP > 4 ? gp[3 % (NCHP / 2)].x : 0.0f, NCHP > 4 ? gp[3 % (NCHP / 2)].y : 0.0f, l16);
-                        // plain read-modify-write: only this wave touches its table and a wave's LDS operations
-                        // execute in order (measured: ds_add_f32 costs ~120 LDS cycles per wave instruction; with
-                        // it on every iteration the kernel was LDS bound at 1.44 ms)
-                        accumulate(row, acc_old[0], tot, LIVE >> l16 & 1u);
-                    }
+                for (int c = 1; c < NCHP / 2; ++c) ds2 = __builtin_elementwise_fma(pay[c], dpix[c], ds2);
+                float dsum = ds2.x + ds2.y;
+                float2_b gp[NCHP / 2];                           // dL/d payload channel pairs
 #pragma unroll
-                    for (int gi = 1; gi < NGRP; ++gi) {   // payload channels 16 gi - 8 .. 16 gi + 7
+                for (int c = 0; c < NCHP / 2; ++c) gp[c] = dpix[c] * ww;
+                float gz = 0.0f;
+                if (DEPTH_GRAD) {
+                    dsum = __builtin_fmaf(b.z, ddep, dsum);
+                    gz = w * ddep;
+                }
+                Rr = __builtin_fmaf(-w, dsum, Rr);               // what is left behind this entry
+                Tr = Tk * om;
+                const float dL_dalpha = __builtin_fmaf(Tk, dsum, -Rr * rcp1m);
+                const float u = av * dL_dalpha;                  // straight through the 0.99 clamp (A.6)
+                const float2_b t1 = float2_b{u, u} * d;          // u (dx, dy)
+                const float2_b t2 = t1 * d;                      // u (dx^2, dy^2)
+                const float mxy = t1.x * d.y;
+                // ---- sum over the sub-block's 16 pixels; lane s of the group ends up with slot s ----
+                {
+                    constexpr uint32_t LIVE = 0x3Fu | (DEPTH_GRAD ? 0x40u : 0u) | (((1u << (NCHP < 8 ? NCHP : 8)) - 1u) << 8);
+                    float tot;
+                    if (!DEPTH_GRAD && NCHP == 4) tot = row_reduce_4ch(t1.x, t1.y, t2.x, mxy, t2.y, u, gp[0].x, gp[0].y, gp[1].x, gp[1].y);
+                    else if (!DEPTH_GRAD && NCHP == 8)
+                        tot = row_reduce_8ch(t1.x, t1.y, t2.x, mxy, t2.y, u, gp[0].x, gp[0].y, gp[1].x, gp[1].y,
+                                             gp[2 % (NCHP / 2)].x, gp[2 % (NCHP / 2)].y, gp[3 % (NCHP / 2)].x, gp[3 % (NCHP / 2)].y);
+                    else tot = row_reduce16_transposed<LIVE>(
+                        t1.x, t1.y, t2.x, mxy, t2.y, u, gz, 0.0f,
+                        gp[0].x, gp[0].y, gp[1].x, gp[1].y,
+                        NCHP > 4 ? gp[2 % (NCHP / 2)].x : 0.0f, NCHP > 4 ? gp[2 % (NCHP / 2)].y : 0.0f,
+                        NCHP > 4 ? gp[3 % (NCHP / 2)].x : 0.0f, NCHP > 4 ? gp[3 % (NCHP / 2)].y : 0.0f, l16);
+                    // plain read-modify-write: only this wave touches its table and a wave's LDS operations
+                    // execute in order (measured: ds_add_f32 costs ~120 LDS cycles per wave instruction; with
+                    // it on every iteration the kernel was LDS bound at 1.44 ms)
+                    accumulate(row, acc_old[0], tot, LIVE >> l16 & 1u);
+                }
+#pragma unroll
+                for (int gi = 1; gi < NGRP; ++gi) {   // payload channels 16 gi - 8 .. 16 gi + 7
 #define GPC(j) ((16 * gi - 8 + (j)) < NCHP ? gp[((16 * gi - 8 + (j)) / 2) % (NCHP / 2)][(j) & 1] : 0.0f)
-                        const float tot = row_reduce16_transposed<0xFFFFu>(GPC(0), GPC(1), GPC(2), GPC(3), GPC(4), GPC(5), GPC(6), GPC(7),
-                                                                            GPC(8), GPC(9), GPC(10), GPC(11), GPC(12), GPC(13), GPC(14), GPC(15), l16);
+                    const float tot = row_reduce16_transposed<0xFFFFu>(GPC(0), GPC(1), GPC(2), GPC(3), GPC(4), GPC(5), GPC(6), GPC(7),
+                                                                        GPC(8), GPC(9), GPC(10), GPC(11), GPC(12), GPC(13), GPC(14), GPC(15), l16);
 #undef GPC
-                        accumulate(row + 16 * gi, acc_old[gi], tot, true);
-                    }
+                    accumulate(row + 16 * gi, acc_old[gi], tot, true);
                 }
             }
             wave_lds_fence_bwd();
-            // ---- flush: one global record-add per staged entry that reached an owned sub-block ----
+            // ---- flush: one global record-add per staged entry (every list entry reaches one of the quadrant's sub-blocks) ----
 #pragma unroll 1
             for (int e0 = 0; e0 < LSR_WAVE; e0 += 4) {
                 if (!((staged >> e0) & 0xFull)) continue;   // wave-uniform
@@ -600,7 +579,7 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     p.views = in.views;
     p.geo = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
     p.tile_start = (const uint32_t *)(geom + L.tile_start);
-    p.point_list = (const uint32_t *)(bin + B.point_list);
+    p.quad_list = (const uint32_t *)(bin + B.quad_list);
     p.final_T = (const float *)(img + I.final_T); p.n_contrib = (const uint32_t *)(img + I.n_contrib);
     p.g_color = gout.color; p.g_feat = gout.feature; p.g_mask = gout.mask; p.g_depth = gout.depth;
     p.f_color = fwd.color; p.f_feat = fwd.feature; p.f_depth = fwd.depth;

@@ -2,22 +2,26 @@
 // Outputs colour (+ bg), features (bg 0), mask = 1 - T, depth = sum alpha T z, and keeps
 // final_T / n_contrib for the backward pass.  Spec: SURVEY.md Appendix A.3 step 7 + A.4.
 //
-// Execution shape (CDNA4): persistent waves process work items — (view, tile, set of 8x8
-// quadrants), sorted by list length (lsr_internal.h kItem*): the first one per wave by a static
+// Execution shape (CDNA4): persistent waves process work items — one 8x8 QUADRANT of one (view,
+// tile) each (lsr_internal.h kItem*), sorted by list length: the first one per wave by a static
 // balanced assignment, further ones from a global queue.
 //
-// Inside an item the wave works on one 8x8 quadrant at a time ("round"), and the quadrant is
-// split into four 4x4-pixel SUB-BLOCKS, one per 16-lane group (one pixel per lane, 4 pixels per
-// lane over the four rounds).  The 64 list entries staged per batch are compacted into 16
-// per-sub-block lists in LDS (ballot + mbcnt, entries keep their depth order); in a round every
-// lane group then walks ITS sub-block's list, so one wave instruction evaluates up to four
-// different entries, each only on a sub-block its alpha >= 1/255 footprint can reach
-// (lsr_blend.h subblock_mask, lossless).  Round 1 of this kernel evaluated an entry on whole 8x8
-// quadrants (wave-uniform entry): 77 pixel evaluations per (Gaussian, tile) pair, 19 % of them
-// passing the alpha test; sub-blocks need 39, and the number of lock-step iterations per pair
-// drops from 1.23 to 0.75 (max over the four lists of a round; census in DESIGN.md).
-// The kernel is bound by f32 VALU issue, so that ratio is the speed-up; per-pixel blend / skip /
-// stop decisions stay scalar lane-mask algebra (SALU) — a lane is still exactly one pixel.
+// A wave walks ITS quadrant's render list (written by k_sort_tiles: the depth-ordered entries whose
+// alpha >= 1/255 footprint reaches the quadrant, each with a 4-bit mask of the quadrant's 4x4-pixel
+// SUB-BLOCKS it can reach).  One lane = one pixel, one 16-lane group = one sub-block.  The 64 list
+// entries staged per batch are compacted into 4 per-sub-block lists in LDS (ballot + mbcnt, entries
+// keep their depth order); every lane group then walks ITS sub-block's list, so one wave instruction
+// evaluates up to four different entries, each only on a sub-block it can reach (lossless).
+// History: round 1 evaluated wave-uniform entries on whole quadrants (77 pixel evaluations
+// per (Gaussian, tile) pair); round 2 introduced the sub-block lists but staged the CANONICAL tile list
+// per item and derived the masks per staged entry (39 evaluations, 0.75 lock-step iterations per pair;
+// a quarter of the staged pairs reached no pixel, and splitting a tile into quadrant items re-staged
+// its whole list, so a 16-view launch ran one whole tile per wave and ended 25 % after its average
+// wave).  Round 3: per-quadrant lists — an item stages exactly what it evaluates (0.69 iterations per
+// pair, dense batches, 4 ballots per batch instead of 16 + a log/rcp/sqrt box), four times as many,
+// four times smaller items on twice as many resident waves.
+// The kernel is bound by f32 VALU issue; per-pixel blend / skip / stop decisions stay scalar lane-mask
+// algebra (SALU) — a lane is exactly one pixel.
 #include <stdio.h>
 
 #include <vector>
@@ -38,8 +42,8 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 
 struct RenderFwdParams {
     int H, W, gx, T, G, C, has_color;
-    int num_cus;                  // compute units (one workgroup of WPB waves each, or several smaller ones)
-    int waves_per_cu;             // resident compositing waves per CU the launch provides (16, or 12: see launch)
+    int num_cus;                  // compute units
+    int waves_per_cu;             // resident compositing waves per CU the launch provides
     const uint32_t *items;        // work items, costliest first
     const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t *queue;              // work-queue head (zeroed per forward)
@@ -47,23 +51,21 @@ struct RenderFwdParams {
     const float *views;
     const float4 *rec;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
     int rec_f4;
-    const uint32_t *tile_start, *point_list;
+    const uint32_t *tile_start, *quad_count, *quad_list;
     float *out_color, *out_feat, *out_mask, *out_depth;
     float *final_T;
     uint32_t *n_contrib;
 };
 
-// One workgroup of 16 independent waves per CU (4 per SIMD; the waves never synchronise with each
-// other).  Waves w, w+4, w+8, w+12 of a workgroup share a SIMD, which lets the kernel decide
-// WHICH work items share a SIMD: items arrive sorted by cost, and SIMD-bin b takes items
-// b, 2B-1-b, 2B+b, 4B-1-b, ... (B = number of bins) — pairing expensive with cheap tiles so every
-// SIMD gets nearly the same total.
-// WPB = waves per workgroup: 16 (one workgroup per CU) unless the LDS slices do not fit, then 4
-// workgroups of 4 waves stand in for it (same bins, placement then up to the dispatcher).
+// Workgroups of WPB independent waves (the waves never synchronise with each other); the launch
+// provides waves_per_cu / WPB workgroups per CU.  Waves w, w+4, w+8, ... of a workgroup share a SIMD,
+// which lets the kernel decide WHICH work items share a SIMD: items arrive sorted by cost, and SIMD-bin b
+// takes items b, 2B-1-b, 2B+b, 4B-1-b, ... (B = number of bins) — pairing expensive with cheap items
+// so every SIMD starts with nearly the same total; everything beyond the first item per wave comes from
+// the queue.
 template <int NCHP, int UNR, int WPB>
 __global__ void __launch_bounds__(LSR_WAVE * WPB)
 k_render_fwd(RenderFwdParams p) {
-    constexpr int PXL = 4;
     // Staged entries, one record per list entry: (x, y, a2, c2) (b2, log2 o, z, -1) payload...
     // ((x, y), (a2, c2) and (z, -1) are operand pairs of the packed f32 instructions below)
     // The odd float4 stride keeps the per-lane staging stores bank-conflict free.  Slot 64 is a
@@ -73,7 +75,10 @@ k_render_fwd(RenderFwdParams p) {
     // addresses (base 0 folds into the ds_read immediate, no address arithmetic per entry).
     struct Lds {
         float4 ent[WPB][LSR_WAVE + 1][kEnt];
-        uint32_t list[WPB][16][LSR_WAVE];   // list[b][i] = offset of the i-th staged entry that can reach sub-block b
+        // list[b][i] = offset of the i-th staged entry that can reach sub-block b.  Rows are 65 words apart:
+        // the four lane groups read list[b][i] for four b at the same i — with a 64-word stride that was one
+        // LDS bank for all four (the 11 % bank-conflict cycles of round 2's profile)
+        uint32_t list[WPB][4][LSR_WAVE + 1];
     };
     __shared__ Lds s_lds;
 
@@ -82,11 +87,12 @@ k_render_fwd(RenderFwdParams p) {
     // per-pixel lane masks then live in SGPRs and the item loop is scalar control flow
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / LSR_WAVE);
     float4 (*s_ent)[kEnt] = s_lds.ent[wid];
-    uint32_t (*s_list)[LSR_WAVE] = s_lds.list[wid];
+    uint32_t (*s_list)[LSR_WAVE + 1] = s_lds.list[wid];
     const char *ent_base = (const char *)&s_lds.ent[0][0][0];
     const uint32_t wave_off = (uint32_t)(wid * (LSR_WAVE + 1) * kEnt * 16);
     const uint32_t my_off = wave_off + (uint32_t)(lane * kEnt * 16);
     const uint32_t null_off = wave_off + (uint32_t)(LSR_WAVE * kEnt * 16);
+    if (lane < 4) s_list[lane][LSR_WAVE] = null_off;   // the rows' pad word (never a real entry)
     if (lane == 0) {
         s_ent[LSR_WAVE][0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         s_ent[LSR_WAVE][1] = make_float4(0.0f, -INFINITY, 0.0f, -1.0f);  // log2(opacity) = -inf
@@ -96,15 +102,14 @@ k_render_fwd(RenderFwdParams p) {
     const uint32_t num_items = p.header[kHdrNumItems];
     const int coff = p.has_color ? 3 : 0;
     const size_t HW = (size_t)p.H * p.W;
-    // lane group -> sub-block of the round's quadrant; lane -> pixel of the sub-block
+    // lane group -> sub-block of the quadrant (bit 2*row + col of the list entries' mask); lane -> pixel of the sub-block
     const int grp = lane >> 4, gcol = grp & 1, grow = grp >> 1;
-    const int gsb = 4 * grow + gcol;   // + 8*(k>>1) + 2*(k&1) = this group's sub-block in round k
     const int lx = lane & 3, ly = (lane >> 2) & 3;
 
     const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = (uint32_t)p.num_cus * (uint32_t)p.waves_per_cu;
-    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);   // 0..15
+    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);   // 0 .. waves_per_cu - 1
     const uint32_t bin = (blockIdx.x % (uint32_t)p.num_cus) * 4u + (vwave & 3u);
-    // First item of every wave: static, folded (boustrophedon) over the cost-sorted list, so the 4
+    // First item of every wave: static, folded (boustrophedon) over the cost-sorted list, so the
     // waves of a SIMD start with a balanced total.  Everything beyond the first `slots` items
     // is pulled from a global queue (costliest first) as waves become free.
     const uint32_t j0 = vwave >> 2;
@@ -128,165 +133,147 @@ k_render_fwd(RenderFwdParams p) {
 #endif
         qi = __builtin_amdgcn_readfirstlane(qi);
         const uint32_t item = p.items[qi];
-        const uint32_t vt = item & kItemTileMask, own = item >> kItemOwnShift;
-        const uint32_t own16 = own_subblocks(own);
+        const uint32_t vt = item & kItemTileMask, quad = item >> kItemQuadShift;
         const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
-        const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE;
+        const int tx0 = (tile % p.gx) * LSR_TILE + 8 * (int)(quad & 1u), ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)(quad >> 1);
         const size_t vG = (size_t)v * p.G;
-        const uint32_t start = p.tile_start[vt], end = p.tile_start[vt + 1];
+        const uint32_t tstart = p.tile_start[vt], tn = p.tile_start[vt + 1] - tstart;
+        const uint32_t qn = p.quad_count[4 * (size_t)vt + quad];
+        const uint32_t *qlist = p.quad_list + 4 * (size_t)tstart + (size_t)quad * tn;
 
         // per-pixel state; (x, y), (depth sum, T) and the payload channels two by two are register
         // pairs so the blend runs on packed f32 instructions
-        float2_t pxy[PXL], dT[PXL];          // pixel centre; (sum alpha T z, transmittance)
-        float2_t acc[PXL][NCHP / 2];
-        uint32_t stop_pos[PXL];
-        // Per-pixel "finished" flags live in scalar registers as 64-bit lane masks, so the skip /
+        const int px = tx0 + 4 * gcol + lx, py = ty0 + 4 * grow + ly;
+        const float2_t pxy = float2_t{(float)px, (float)py};
+        const bool inside = px < p.W && py < p.H;
+        float2_t dT = float2_t{0.0f, 1.0f};          // (sum alpha T z, transmittance)
+        float2_t acc[NCHP / 2];
+#pragma unroll
+        for (int c = 0; c < NCHP / 2; ++c) acc[c] = float2_t{0.0f, 0.0f};
+        uint32_t stop_pos = 0;
+        // The per-pixel "finished" flags live in a scalar register pair as a 64-bit lane mask, so the skip /
         // blend / stop decisions are SALU mask algebra instead of per-lane VALU selects.
-        uint64_t done[PXL];
-        bool inside[PXL];
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) {
-            const int px = tx0 + 8 * (k & 1) + 4 * gcol + lx, py = ty0 + 8 * (k >> 1) + 4 * grow + ly;
-            pxy[k] = float2_t{(float)px, (float)py};
-            inside[k] = px < p.W && py < p.H && ((own >> k) & 1u);
-            done[k] = __ballot(!inside[k]);
-            dT[k] = float2_t{0.0f, 1.0f}; stop_pos[k] = 0;
-#pragma unroll
-            for (int c = 0; c < NCHP / 2; ++c) acc[k][c] = float2_t{0.0f, 0.0f};
-        }
+        uint64_t done = __ballot(!inside);
 
         // Software-pipelined staging: while batch b is composited, the records of batch b+1 and the
-        // list indices of batch b+2 are already in flight (two dependent global latencies per batch
-        // otherwise sit on the serial path of the wave that walks the longest list).
+        // list entries of batch b+2 are already in flight (two dependent global latencies per batch
+        // otherwise sit on the serial path of the wave).
         // The loads are UNCONDITIONAL at clamped positions (slots past the end re-read the last entry, which
-        // the `e < end` tests below ignore): a load under a per-lane condition is followed by a wait for it at
+        // the `e < qn` tests below ignore): a load under a per-lane condition is followed by a wait for it at
         // the join, which put both latencies back on the serial path of every batch.
-        struct StageRec { float4 a, b, pay[NCHP / 4]; };
-        const uint32_t last = end - 1u;   // only used when the list is not empty
-        auto load_idx = [&](uint32_t e) -> uint32_t { return p.point_list[min(e, last)]; };
-        auto load_rec = [&](uint32_t g) {
+        struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t w; };
+        const uint32_t last = qn - 1u;   // only used when the list is not empty
+        auto load_ent = [&](uint32_t e) -> uint32_t { return qlist[min(e, last)]; };
+        auto load_rec = [&](uint32_t w) {
             StageRec r;
-            const float4 *R = p.rec + (vG + g) * (size_t)p.rec_f4;
+            r.w = w;
+            const float4 *R = p.rec + (vG + (w & kQuadIndexMask)) * (size_t)p.rec_f4;
             r.a = R[0]; r.b = R[1];  // (x,y,A,B) (C,o,z,-)
 #pragma unroll
             for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];  // payload, zero padded
             return r;
         };
-        uint32_t g_ahead = 0;
+        uint32_t w_ahead = 0;
         StageRec nxt;
+        nxt.w = 0;
         nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
         for (int c4 = 0; c4 < NCHP / 4; ++c4) nxt.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (start < end) {   // wave-uniform
-            g_ahead = load_idx(start + lane);
-            nxt = load_rec(g_ahead);
-            g_ahead = load_idx(start + LSR_WAVE + lane);
+        if (qn > 0) {   // wave-uniform
+            w_ahead = load_ent(lane);
+            nxt = load_rec(w_ahead);
+            w_ahead = load_ent(LSR_WAVE + lane);
         }
 
-        for (uint32_t base = start; base < end; base += LSR_WAVE) {
-            uint64_t all_done = ~0ull;
-#pragma unroll
-            for (int k = 0; k < PXL; ++k) all_done &= done[k];
-            if (all_done == ~0ull) break;
+        for (uint32_t base = 0; base < qn; base += LSR_WAVE) {
+            if (done == ~0ull) break;
 
             const StageRec cur = nxt;
-            nxt = load_rec(g_ahead);
-            g_ahead = load_idx(base + 2 * LSR_WAVE + lane);
+            nxt = load_rec(w_ahead);
+            w_ahead = load_ent(base + 2 * LSR_WAVE + lane);
             // ---- stage up to 64 list entries (one per lane) ----
             {   // every list slot starts as the null record; the compaction below overwrites a prefix
-                const uint4 nul = make_uint4(null_off, null_off, null_off, null_off);
-                uint4 *L4 = (uint4 *)&s_list[0][0];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) L4[q * LSR_WAVE + lane] = nul;
+                for (int b = 0; b < 4; ++b) s_list[b][lane] = null_off;
             }
             const uint32_t e = base + lane;
-            uint32_t m = 0;
-            if (e < end) {
+            const uint32_t m = e < qn ? (cur.w >> kQuadBitsShift) : 0u;   // sub-blocks of this quadrant the entry can reach (never 0 for a list entry)
+            if (m) {
                 const float4 a = cur.a, b = cur.b;
-                m = subblock_mask(a.x, a.y, a.z, a.w, b.x, b.y, (float)tx0, (float)ty0) & own16;
-                if (m) {
-                    const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
-                    s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
-                    s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z, -1.0f);
+                const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
+                s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
+                s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z, -1.0f);
 #pragma unroll
-                    for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[lane][2 + c4] = cur.pay[c4];
-                }
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[lane][2 + c4] = cur.pay[c4];
             }
             // compaction: per sub-block, the staged entries that can reach it, in list order
-            uint32_t cnt[16];
+            uint32_t nk = 0;
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                cnt[b] = 0;
-                if (!((own16 >> b) & 1u)) continue;   // wave-uniform
+            for (int b = 0; b < 4; ++b) {
                 const uint64_t bal = __ballot((m >> b) & 1u);
-                cnt[b] = (uint32_t)__builtin_popcountll(bal);
+                nk = max(nk, (uint32_t)__builtin_popcountll(bal));
                 if (__builtin_amdgcn_inverse_ballot_w64(bal)) {
                     const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                     s_list[b][at] = my_off;
                 }
             }
+            nk = __builtin_amdgcn_readfirstlane(nk);
             wave_lds_fence();  // staged records and lists are visible to this wave's reads below
 
-            // One round per quadrant: lane group g walks the list of ITS sub-block, front to back,
-            // UNR entries at a time (independent alpha evaluations; only the short transmittance
-            // chain is serial).  Shorter lists of the round are padded with the null record.
-#pragma unroll
-            for (int k = 0; k < PXL; ++k) {
-                const int b0 = 8 * (k >> 1) + 2 * (k & 1);
-                const uint32_t nk = __builtin_amdgcn_readfirstlane(max(max(cnt[b0], cnt[b0 + 1]), max(cnt[b0 + 4], cnt[b0 + 5])));
-                if (nk == 0 || done[k] == ~0ull) continue;   // wave-uniform
-                const uint32_t *lp = &s_list[b0 + gsb][0];
+            // Lane group g walks the list of ITS sub-block, front to back, UNR entries at a time
+            // (independent alpha evaluations; only the short transmittance chain is serial).  Shorter
+            // lists are padded with the null record.
+            const uint32_t *lp = &s_list[grp][0];
 #ifdef LSR_ENABLE_TRACE
-                trace_iters += nk;
+            trace_iters += nk;
 #endif
-                for (uint32_t i = 0; i < nk; i += UNR) {
-                    float4 a[UNR], b[UNR];
-                    float2_t pay[UNR][NCHP / 2];
-                    uint32_t off[UNR];
+            for (uint32_t i = 0; i < nk; i += UNR) {
+                float4 a[UNR], b[UNR];
+                float2_t pay[UNR][NCHP / 2];
+                uint32_t off[UNR];
 #pragma unroll
-                    for (int u = 0; u < UNR; ++u) {
-                        off[u] = lp[i + u];
-                        const float4 *E = (const float4 *)(ent_base + off[u]);
-                        a[u] = E[0]; b[u] = E[1];
+                for (int u = 0; u < UNR; ++u) {
+                    off[u] = lp[i + u];      // (i + u can be nk: the row's 65th word / the padding, a null record either way)
+                    const float4 *E = (const float4 *)(ent_base + off[u]);
+                    a[u] = E[0]; b[u] = E[1];
 #pragma unroll
-                        for (int c4 = 0; c4 < NCHP / 4; ++c4) {
-                            const float4 t = E[2 + c4];
-                            pay[u][2 * c4] = float2_t{t.x, t.y}; pay[u][2 * c4 + 1] = float2_t{t.z, t.w};
-                        }
+                    for (int c4 = 0; c4 < NCHP / 4; ++c4) {
+                        const float4 t = E[2 + c4];
+                        pay[u][2 * c4] = float2_t{t.x, t.y}; pay[u][2 * c4 + 1] = float2_t{t.z, t.w};
                     }
-                    float alpha[UNR];
-                    uint64_t ok[UNR];
+                }
+                float alpha[UNR];
+                uint64_t ok[UNR];
 #pragma unroll
-                    for (int u = 0; u < UNR; ++u) {
-                        // same operations as blend_exponent (lsr_blend.h), two of them packed
-                        const float2_t d = float2_t{a[u].x, a[u].y} - pxy[k];
-                        const float2_t q = float2_t{a[u].z, a[u].w} * d;              // (a2 dx, c2 dy)
-                        const float p1 = __builtin_fmaf(b[u].x, d.y, q.x);
-                        const float p2 = __builtin_fmaf(q.y, d.y, b[u].y);
-                        const float ex = __builtin_fmaf(p1, d.x, p2);
-                        alpha[u] = fminf(LSR_ALPHA_MAX, fast_exp2(ex));
-                        // skip if power > 0 or alpha < 1/255 (NaN-safe: comparisons are "keep" tests)
-                        ok[u] = __ballot(ex <= b[u].y) & __ballot(alpha[u] >= LSR_ALPHA_MIN);
-                    }
+                for (int u = 0; u < UNR; ++u) {
+                    // same operations as blend_exponent (lsr_blend.h), two of them packed
+                    const float2_t d = float2_t{a[u].x, a[u].y} - pxy;
+                    const float2_t q = float2_t{a[u].z, a[u].w} * d;              // (a2 dx, c2 dy)
+                    const float p1 = __builtin_fmaf(b[u].x, d.y, q.x);
+                    const float p2 = __builtin_fmaf(q.y, d.y, b[u].y);
+                    const float ex = __builtin_fmaf(p1, d.x, p2);
+                    alpha[u] = fminf(LSR_ALPHA_MAX, fast_exp2(ex));
+                    // skip if power > 0 or alpha < 1/255 (NaN-safe: comparisons are "keep" tests)
+                    ok[u] = __ballot(ex <= b[u].y) & __ballot(alpha[u] >= LSR_ALPHA_MIN);
+                }
 #pragma unroll
-                    for (int u = 0; u < UNR; ++u) {
-                        const float aT = alpha[u] * dT[k].y;
-                        const float tT = dT[k].y - aT;
-                        const uint64_t live = ok[u] & ~done[k];
-                        const uint64_t room = __ballot(tT >= LSR_T_EPS);
-                        const uint64_t blend = live & room, stop = live & ~room;
-                        const float w = __builtin_amdgcn_inverse_ballot_w64(blend) ? aT : 0.0f;
-                        const float2_t ww = float2_t{w, w};
+                for (int u = 0; u < UNR; ++u) {
+                    const float aT = alpha[u] * dT.y;
+                    const float tT = dT.y - aT;
+                    const uint64_t live = ok[u] & ~done;
+                    const uint64_t room = __ballot(tT >= LSR_T_EPS);
+                    const uint64_t blend = live & room, stop = live & ~room;
+                    const float w = __builtin_amdgcn_inverse_ballot_w64(blend) ? aT : 0.0f;
+                    const float2_t ww = float2_t{w, w};
 #pragma unroll
-                        for (int c = 0; c < NCHP / 2; ++c) acc[k][c] = __builtin_elementwise_fma(pay[u][c], ww, acc[k][c]);
-                        // (depth sum, T) += w * (z, -1)
-                        dT[k] = __builtin_elementwise_fma(float2_t{b[u].z, b[u].w}, ww, dT[k]);
-                        if (stop) {  // rare, wave-uniform: a pixel's transmittance ran out here
-                            // 1-based list position of the stopping entry, from its staging slot
-                            const uint32_t pos = base - start + 1u + (off[u] - wave_off) / (uint32_t)(kEnt * 16);
-                            stop_pos[k] = __builtin_amdgcn_inverse_ballot_w64(stop) ? pos : stop_pos[k];
-                            done[k] |= stop;
-                        }
+                    for (int c = 0; c < NCHP / 2; ++c) acc[c] = __builtin_elementwise_fma(pay[u][c], ww, acc[c]);
+                    // (depth sum, T) += w * (z, -1)
+                    dT = __builtin_elementwise_fma(float2_t{b[u].z, b[u].w}, ww, dT);
+                    if (stop) {  // rare, wave-uniform: a pixel's transmittance ran out here
+                        // 1-based list position of the stopping entry, from its staging slot
+                        const uint32_t pos = base + 1u + (off[u] - wave_off) / (uint32_t)(kEnt * 16);
+                        stop_pos = __builtin_amdgcn_inverse_ballot_w64(stop) ? pos : stop_pos;
+                        done |= stop;
                     }
                 }
             }
@@ -297,27 +284,25 @@ k_render_fwd(RenderFwdParams p) {
         // earlier launch) — as plain loads these were three waited-for vector loads per pixel row
         typedef const float __attribute__((address_space(4))) *kfloat_ptr;
         const kfloat_ptr vw = (kfloat_ptr)(p.views + (size_t)v * LSR_VIEW_FLOATS);
-#pragma unroll
-        for (int k = 0; k < PXL; ++k) {
-            if (!inside[k]) continue;
-            const size_t pix = (size_t)pxy[k].y * p.W + (size_t)pxy[k].x;
+        if (inside) {
+            const size_t pix = (size_t)py * p.W + (size_t)px;
             const size_t vp = (size_t)v * HW + pix;
-            const float Tk = dT[k].y;
+            const float Tk = dT.y;
             p.final_T[vp] = Tk;
-            // number of leading list entries the backward pass has to consider for this pixel: all
-            // of them, or everything before the entry at which the transmittance test stopped it
-            p.n_contrib[vp] = stop_pos[k] ? stop_pos[k] - 1u : end - start;
+            // number of leading entries of the QUADRANT's render list the backward pass has to consider for
+            // this pixel: all of them, or everything before the entry at which the transmittance test stopped it
+            p.n_contrib[vp] = stop_pos ? stop_pos - 1u : qn;
             p.out_mask[vp] = 1.0f - Tk;
-            p.out_depth[vp] = dT[k].x;
+            p.out_depth[vp] = dT.x;
             if (p.has_color) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(Tk, vw[37 + c], acc[k][c / 2][c & 1]);
+                    p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(Tk, vw[37 + c], acc[c / 2][c & 1]);
             }
 #pragma unroll
             for (int c = 0; c < NCHP; ++c)
                 if (c >= coff && c - coff < p.C)
-                    p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[k][c / 2][c & 1];
+                    p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[c / 2][c & 1];
         }
 #ifdef LSR_ENABLE_TRACE
         if (p.trace && lane == 0) {
@@ -327,7 +312,7 @@ k_render_fwd(RenderFwdParams p) {
             p.trace[4 * (size_t)qi + 0] = t_begin;
             p.trace[4 * (size_t)qi + 1] = __builtin_readcyclecounter();
             p.trace[4 * (size_t)qi + 2] = ((unsigned long long)xcc << 32) | hwid;
-            p.trace[4 * (size_t)qi + 3] = ((unsigned long long)trace_iters << 32) | (end - start);
+            p.trace[4 * (size_t)qi + 3] = ((unsigned long long)trace_iters << 32) | qn;
         }
 #endif
     }  // persistent item loop
@@ -349,7 +334,8 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.views = in.views;
     p.rec = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
     p.tile_start = (const uint32_t *)(geom + L.tile_start);
-    p.point_list = (const uint32_t *)(bin + B.point_list);
+    p.quad_count = (const uint32_t *)(geom + L.quad_count);
+    p.quad_list = (const uint32_t *)(bin + B.quad_list);
     p.out_color = out.color; p.out_feat = out.feature; p.out_mask = out.mask; p.out_depth = out.depth;
     p.final_T = (float *)(img + I.final_T); p.n_contrib = (uint32_t *)(img + I.n_contrib);
     const int nch = (p.has_color ? 3 : 0) + d.feat_channels;
@@ -365,12 +351,18 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     }
 #endif
     prof_begin(kStRenderFwd, s);
-#define LSR_RF(N, U, WPB) hipLaunchKernelGGL((k_render_fwd<N, U, WPB>), dim3(p.num_cus * ((WPB) >= 12 ? 1 : 16 / (WPB))), dim3(LSR_WAVE * WPB), 0, s, p)
-    p.waves_per_cu = 16;
-    if (nchp == 4) LSR_RF(4, 2, 16);
-    else if (nchp == 8) LSR_RF(8, 2, 16);
-    else if (nchp == 12) LSR_RF(12, 1, 16);
-    else LSR_RF(36, 1, 4);
+    // WPC = resident waves per CU = (workgroups per CU) x WPB: as many as registers (UNR) and LDS slices allow.
+    // LSR_FWD_VARIANT (development knob, read once) selects the alternatives measured in DESIGN.md.
+#define LSR_RF(N, U, WPB, WPC)                                                                             \
+    do {                                                                                                   \
+        p.waves_per_cu = (WPC);                                                                            \
+        hipLaunchKernelGGL((k_render_fwd<N, U, WPB>), dim3(p.num_cus * ((WPC) / (WPB))), dim3(LSR_WAVE * WPB), 0, s, p); \
+    } while (0)
+    const int variant = env_int("LSR_FWD_VARIANT", 0);
+    if (nchp == 4) { if (variant == 1) LSR_RF(4, 2, 12, 24); else if (variant == 2) LSR_RF(4, 2, 16, 16); else LSR_RF(4, 1, 16, 32); }
+    else if (nchp == 8) { if (variant == 2) LSR_RF(8, 2, 16, 16); else LSR_RF(8, 1, 12, 24); }   // 2 x 12 waves: what the LDS slices allow
+    else if (nchp == 12) LSR_RF(12, 1, 16, 16);
+    else LSR_RF(36, 1, 4, 16);
 #undef LSR_RF
     prof_end(kStRenderFwd, s);
 #ifdef LSR_ENABLE_TRACE

@@ -42,7 +42,7 @@ struct ShParams {
     lsr_dims d;
     lsr_inputs in;
     const float *vis;         // depth word of the (view, Gaussian) bin records: > 0 <=> visible
-    int vis_stride;           // in floats (2 narrow, 4 wide records)
+    int vis_stride;           // in floats (3 narrow, 4 wide records)
     float *rec;               // screen-space records (forward writes the payload slots)
     uint8_t *clamp;           // [V*G] bit c set: colour channel c clamped at 0
     const float *grec;        // backward: packed gradient records

@@ -21,7 +21,7 @@ def _check_forward(bi, run, views=None):
     T = run.T
     rect = run.rect()
     q0, q1 = run.q()
-    ncontrib = run.n_contrib()
+    ncontrib = run.n_considered()
     total_P = 0
     for v in (range(V) if views is None else views):
         o = util.oracle_forward(bi, v)
@@ -86,14 +86,75 @@ def test_forward_parity(hip_device, name):
     _check_forward(bi, run)
 
 
-@pytest.mark.parametrize("split", ["1", "2", "4"])
-def test_forward_parity_all_item_splits(hip_device, monkeypatch, split):
-    """Work items of 4 / 2 / 1 quadrants per (view, tile) must all give the same render."""
-    monkeypatch.setenv("LSR_SPLIT", split)
-    sc, H, W = _scene(CASES["rgb_deg4_feat4_deg2_v3"])
-    bi = util.boundary_inputs(sc, H, W, bg=(0.2, 0.4, 0.6))
+def _box_masks(xy, co, lst, tx0, ty0):
+    """float64 restatement of the kernels' footprint box (lsr_blend.h footprint_cells) -> 16-bit sub-block masks."""
+    A, B, C, o = (co[lst, k].astype(np.float64) for k in range(4))
+    x, y = xy[lst, 0].astype(np.float64), xy[lst, 1].astype(np.float64)
+    det = A * C - B * B
+    tau = np.log(np.maximum(255.0 * o, 1e-300)) * 1.0001 + 1e-4
+    s2 = 2.0 * np.maximum(tau, 0.0) / det
+    ex, ey = np.sqrt(s2 * C) * 1.001 + 0.05, np.sqrt(s2 * A) * 1.001 + 0.05
+    m = np.zeros(len(lst), np.int64)
+    for r in range(4):
+        for c in range(4):
+            hit = (x - ex <= tx0 + 4 * c + 3) & (x + ex >= tx0 + 4 * c) & (y - ey <= ty0 + 4 * r + 3) & (y + ey >= ty0 + 4 * r)
+            m |= np.where(hit & (o >= 1.0 / 255.0), 1 << (4 * r + c), 0)
+    return m
+
+
+@pytest.mark.parametrize("name", ["feat4", "ragged_image", "big_splats"])
+def test_quadrant_render_lists(hip_device, name):
+    """The per-quadrant render lists the compositing kernels walk (k_sort_tiles, ABI v6 layout) against the
+    canonical, bit-exact tile lists: every quadrant list is an order-preserving sub-list of its tile's
+    canonical list; LOSSLESS — an entry that reaches alpha >= 1/255 on any pixel of a 4x4 sub-block (dense
+    float64 evaluation) is in that quadrant's list with the sub-block's bit set; and tight — the listed
+    (entry, sub-block) pairs are those of the footprint box (+ at most 2 % from float rounding)."""
+    sc, H, W = _scene(CASES[name])
+    bi = util.boundary_inputs(sc, H, W)
     run = util.HipRun(bi, hip_device)
-    _check_forward(bi, run)
+    ts, pl, qc, ql, T = run.tile_start(), run.point_list(), run.quad_count(), run.quad_list(), run.T
+    gx = (W + 15) // 16
+    listed = boxed = 0
+    for v in range(bi["V"]):
+        o = util.oracle_forward(bi, v)
+        xy, co = o["xy"], o["conic_opacity"]
+        for t in range(T):
+            s0, s1 = ts[v * T + t], ts[v * T + t + 1]
+            n = s1 - s0
+            canon = pl[s0:s1]
+            ty, tx = divmod(t, gx)
+            got = np.zeros(n, np.int64)            # 16-bit sub-block masks reassembled from the four lists
+            pos = {int(g): i for i, g in enumerate(canon)}
+            for q in range(4):
+                cnt = qc[v * T + t, q]
+                assert 0 <= cnt <= n
+                words = ql[4 * s0 + q * n: 4 * s0 + q * n + cnt]
+                idx, bits = (words & 0x0FFFFFFF).astype(np.int64), (words >> 28).astype(np.int64)
+                where = np.array([pos[int(g)] for g in idx], np.int64)
+                assert (np.diff(where) > 0).all(), "quadrant list is not an ordered sub-list of the canonical list"
+                assert (bits != 0).all(), "list entry without a reachable sub-block"
+                q0 = 8 * (q >> 1) + 2 * (q & 1)
+                got[where] |= ((bits & 3) << q0) | (((bits >> 2) & 3) << (q0 + 4))
+            if n == 0:
+                continue
+            # dense truth: alpha >= 1/255 (and power <= 0) anywhere in the sub-block
+            px = tx * 16 + np.arange(16, dtype=np.float64)[None, None, :]
+            py = ty * 16 + np.arange(16, dtype=np.float64)[None, :, None]
+            dx = xy[canon, 0].astype(np.float64)[:, None, None] - px
+            dy = xy[canon, 1].astype(np.float64)[:, None, None] - py
+            A, B, C, op = (co[canon, k].astype(np.float64)[:, None, None] for k in range(4))
+            power = -0.5 * (A * dx * dx + C * dy * dy) - B * dx * dy
+            reach = (power <= 0) & (np.minimum(0.99, op * np.exp(np.minimum(power, 0))) >= 1.0 / 255.0)
+            need = np.zeros(n, np.int64)
+            for r in range(4):
+                for c in range(4):
+                    need |= np.where(reach[:, 4 * r:4 * r + 4, 4 * c:4 * c + 4].any((1, 2)), 1 << (4 * r + c), 0)
+            assert ((need & ~got) == 0).all(), f"view {v} tile {t}: a reachable sub-block is missing from the render lists"
+            box = _box_masks(xy, co, canon, tx * 16, ty * 16)
+            listed += sum(bin(int(m)).count("1") for m in got)
+            boxed += sum(bin(int(m)).count("1") for m in box)
+    assert listed <= 1.02 * boxed + 16, f"render lists hold {listed} (entry, sub-block) pairs, the footprint boxes {boxed}"
+    assert listed >= 0.98 * boxed - 16
 
 
 def test_forward_shared_scene_equals_per_view(hip_device):
@@ -110,11 +171,8 @@ def test_forward_shared_scene_equals_per_view(hip_device):
     _check_forward(bi, b)
 
 
-def _grad_case(hip_device, case, with_aux, pxl_env=None, monkeypatch=None):
+def _grad_case(hip_device, case, with_aux):
     from latentsplat_amd.rasterizer import rasterize_views
-    if pxl_env is not None:
-        monkeypatch.setenv("LSR_PXL_BWD", pxl_env)
-        monkeypatch.setenv("LSR_SPLIT", {"1": "4", "2": "2", "4": "1"}[pxl_env])
     sc, H, W = _scene(case)
     bi = util.boundary_inputs(sc, H, W, bg=(0.3, 0.1, 0.5))
     V = bi["V"]
@@ -186,11 +244,6 @@ GRAD_CASES = {
 @pytest.mark.parametrize("with_aux", [False, True])
 def test_backward_parity(hip_device, name, with_aux):
     _grad_case(hip_device, GRAD_CASES[name], with_aux)
-
-
-@pytest.mark.parametrize("pxl", ["1", "2", "4"])
-def test_backward_parity_all_wave_shapes(hip_device, monkeypatch, pxl):
-    _grad_case(hip_device, GRAD_CASES["feat4"], False, pxl_env=pxl, monkeypatch=monkeypatch)
 
 
 # ------------------------------------------------------------------------------------------

@@ -372,7 +372,7 @@ def test_large_image_uses_global_histogram_paths(hip_device):
         bi = util.boundary_inputs(sc, H, W, bg=(0.1, 0.2, 0.3))
         run = util.HipRun(bi, hip_device)
         o = util.oracle_forward(bi, 0)
-        assert run.layout.geom_bin_stride == (16 if W > 4080 else 8)
+        assert run.layout.geom_bin_stride == (16 if W > 4080 else 12)
         np.testing.assert_array_equal(run.rect()[0], o["rect"])
         np.testing.assert_array_equal(run.radii[0].cpu().numpy(), o["radii"])
         ts = run.tile_start()

@@ -132,9 +132,9 @@ class HipRun:
 
     def rect(self):
         n = self.d.num_views * self.d.num_gaussians
-        if self.layout.geom_bin_stride == 8:   # narrow records: u8 tile coordinates
-            b = self._view(self.geom, self.layout.geom_bin, n * 8, torch.uint8).cpu().numpy().astype(np.int32).reshape(
-                self.d.num_views, self.d.num_gaussians, 8)
+        if self.layout.geom_bin_stride == 12:   # narrow records: u8 tile coordinates, f32 depth, u8 span[4]
+            b = self._view(self.geom, self.layout.geom_bin, n * 12, torch.uint8).cpu().numpy().astype(np.int32).reshape(
+                self.d.num_views, self.d.num_gaussians, 12)
             return b[:, :, :4]
         b = self._view(self.geom, self.layout.geom_bin, n * 16, torch.int16).cpu().numpy().astype(np.int32).reshape(
             self.d.num_views, self.d.num_gaussians, 8)
@@ -147,6 +147,47 @@ class HipRun:
         r = self._view(self.geom, self.layout.geom_rec, n * rf * 4, torch.float32).cpu().numpy().reshape(
             self.d.num_views, -1, rf)
         return r[:, :, 0:4], r[:, :, 4:8]
+
+    def quad_count(self):
+        """(V*T, 4) lengths of the quadrant render lists."""
+        n = self.d.num_views * self.T * 4
+        return self._view(self.geom, self.layout.geom_quad_count, n * 4, torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 4)
+
+    def quad_list(self):
+        """Raw quadrant-list area: [4P] words `index | sub-block bits << 28` (tile with canonical list [s, s+n)
+        owns [4s, 4s+4n), quadrant q at 4s + q*n)."""
+        return self._view(self.bin, self.layout.bin_quad_list, max(self.P, 0) * 16, torch.int32).cpu().numpy().view(np.uint32)
+
+    def n_considered(self):
+        """n_contrib translated from positions in the QUADRANT render lists (what the kernels keep) to
+        positions in the canonical tile lists (what the published algorithm / the oracle keeps): a pixel
+        that considered all of its quadrant's list considered the whole tile list; otherwise it stopped
+        at a specific entry, whose canonical position is looked up."""
+        nc = self.n_contrib()
+        ts, pl, qc, ql = self.tile_start(), self.point_list(), self.quad_count(), self.quad_list()
+        V, H, W, T = self.d.num_views, self.d.height, self.d.width, self.T
+        gx = (W + 15) // 16
+        out = np.zeros_like(nc)
+        for v in range(V):
+            for t in range(T):
+                s0, s1 = ts[v * T + t], ts[v * T + t + 1]
+                n = s1 - s0
+                ty, tx = divmod(t, gx)
+                canon = pl[s0:s1]
+                for q in range(4):
+                    y0, x0 = ty * 16 + 8 * (q >> 1), tx * 16 + 8 * (q & 1)
+                    if y0 >= H or x0 >= W:
+                        continue
+                    blk = nc[v, y0:y0 + 8, x0:x0 + 8]
+                    cnt = qc[v * T + t, q]
+                    lst = ql[4 * s0 + q * n: 4 * s0 + q * n + cnt] & 0x0FFFFFFF
+                    res = np.full(blk.shape, n, np.int64)
+                    stopped = blk < cnt
+                    if stopped.any():
+                        pos = {int(g): i for i, g in enumerate(canon)}
+                        res[stopped] = [pos[int(lst[k])] for k in blk[stopped]]
+                    out[v, y0:y0 + 8, x0:x0 + 8] = res
+        return out
 
     def n_contrib(self):
         n = self.d.num_views * self.d.height * self.d.width
