@@ -157,17 +157,17 @@ typedef struct lsr_layout {
      *           depth 0 = culled; span = footprint of alpha >= 1/255 in 4-pixel cells relative to the rectangle
      * bin_point_list: [P] canonical per-tile lists (depth order, ties by index): tile t of view v owns
      *           [tile_start[v*T+t], tile_start[v*T+t+1])
-     * bin_quad_list: [4P] render lists (ABI v6): the tile with canonical list [s, s+n) owns [4s, 4s+4n); the list of
-     *           its 8x8 quadrant q (q = 2*(y>=8) + (x>=8)) starts at 4s + q*n and has geom_quad_count[4*(v*T+t)+q]
-     *           entries `index | sub-block bits << 28`: the canonical list restricted to the entries whose
-     *           alpha >= 1/255 footprint box reaches the quadrant, in canonical order; bit (2*r + c) = the entry can
-     *           reach the quadrant's 4x4-pixel sub-block (c, r).  img_n_contrib counts positions of THESE lists.
-     * key_index_shift: 8 when the sort keys are `depth << 32 | index << 8 | sub-block code`, 0 for plain indices */
+     * bin_half_list: [2P] render lists (ABI v6): the tile with canonical list [s, s+n) owns [2s, 2s+2n); the list of
+     *           its upper (h = 0: pixel rows 0-7) / lower (h = 1: rows 8-15) half starts at 2s + h*n and has
+     *           geom_half_count[2*(v*T+t)+h] entries `index | sub-block bits << 24`: the canonical list restricted to
+     *           the entries whose alpha >= 1/255 footprint box reaches the half, in canonical order; bit (4*r + c) =
+     *           the entry can reach the half's 4x4-pixel sub-block (c, r).  img_n_contrib counts positions of THESE
+     *           lists.  (Sort keys are `depth << 32 | index << 8 | sub-block code`: at most 2^24 Gaussians per scene.) */
     size_t geom_rec, geom_rec_floats, geom_bin, geom_tile_count, geom_tile_start, geom_header;
     size_t bin_keys, bin_point_list;
     size_t img_final_T, img_n_contrib;
     size_t geom_bin_stride;
-    size_t bin_quad_list, geom_quad_count, key_index_shift;
+    size_t bin_half_list, geom_half_count;
 } lsr_layout;
 
 int lsr_abi_version(void);
@@ -207,17 +207,26 @@ int lsr_pack_view(const float *viewmatrix, const float *projmatrix, const float 
  * Also starts the view-dependent payload pass (colour / latent features from SH), which only depends on
  * the preprocess: it runs on a library-owned side stream (one per device, forked from `stream` with an
  * event) while the host fetches the pair count and the binning of phase 2 runs; phase 2 joins it
- * before compositing.  lsr_forward_nosync does the same inside one call (event fork / join are
+ * before compositing.  Every lsr_forward_prepare must be followed by lsr_forward_render or, if the forward
+ * is given up, by lsr_forward_abandon before geom_ws is released.  lsr_forward_nosync does the same inside one call (event fork / join are
  * captured by a stream capture).  LSR_SH_SIDE_STREAM=0 keeps every launch on `stream`. */
 int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii,
                         int64_t *num_pairs_host, int32_t *max_tile_pairs_host,
                         lsr_stream_t stream);
 
 /* ---- forward, phase 2: binning, per-tile depth sort, front-to-back compositing. Async.  Must follow
- * the lsr_forward_prepare of the same geom_ws on the same device (it waits for that call's SH pass). */
+ * the lsr_forward_prepare of the same geom_ws on the same device (it waits for that call's SH pass).
+ * With enough views the work runs as chunks of views: the binning of chunk c + 1 on the library's side
+ * stream beside the compositing of chunk c (forked and joined with events inside this call). */
 int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, void *bin_ws,
                        void *img_ws, int64_t num_pairs, int32_t max_tile_pairs,
                        const lsr_outputs *out, lsr_stream_t stream);
+
+/* ---- a forward that is given up between lsr_forward_prepare and lsr_forward_render (e.g. the binning
+ * workspace could not be allocated): lsr_forward_prepare may have left the SH payload pass running on the
+ * library's side stream, writing into geom_ws.  This makes `stream` wait for everything on the side stream,
+ * so that geom_ws can be released in `stream` order (what a caching allocator does).  Async. */
+int lsr_forward_abandon(lsr_stream_t stream);
 
 /* ---- forward WITHOUT host synchronisation (latency mode; graph-capturable).  The same stages as
  * lsr_forward_prepare + lsr_forward_render, but the pair count never travels to the host (upstream's

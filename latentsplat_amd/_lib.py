@@ -61,7 +61,7 @@ class Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
                 ("geom_rec", "geom_rec_floats", "geom_bin", "geom_tile_count", "geom_tile_start",
                  "geom_header", "bin_keys", "bin_point_list", "img_final_T", "img_n_contrib", "geom_bin_stride",
-                 "bin_quad_list", "geom_quad_count", "key_index_shift")]
+                 "bin_half_list", "geom_half_count")]
 
 
 class AdapterDims(C.Structure):      # lsr_adapter_dims (include/lsr_adapter.h, include/lsr_latent.h, include/lsr_ply.h)
@@ -118,7 +118,7 @@ EXPORTS = (
     "lsr_abi_version", "lsr_error_string", "lsr_last_hip_error", "lsr_geom_workspace_bytes",
     "lsr_image_workspace_bytes", "lsr_binning_workspace_bytes", "lsr_grad_workspace_bytes",
     "lsr_get_layout", "lsr_build_views", "lsr_pack_view", "lsr_forward_prepare", "lsr_forward_render", "lsr_forward_nosync",
-    "lsr_forward_status", "lsr_backward",
+    "lsr_forward_status", "lsr_forward_abandon", "lsr_backward",
     "lsr_profile_enable", "lsr_profile_num_stages", "lsr_profile_stage_name", "lsr_profile_read",
     "lsr_adapter_forward", "lsr_adapter_backward", "lsr_latent_forward", "lsr_latent_backward",
     "lsr_ply_pack", "lsr_ply_write_host",
@@ -178,6 +178,8 @@ def load():
                                        C.POINTER(Outputs), P]
     lib.lsr_forward_nosync.restype = C.c_int
     lib.lsr_forward_nosync.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, I32, C.POINTER(Outputs), P]
+    lib.lsr_forward_abandon.restype = C.c_int
+    lib.lsr_forward_abandon.argtypes = [P]
     lib.lsr_forward_status.restype = C.c_int
     lib.lsr_forward_status.argtypes = [C.POINTER(Dims), P, C.POINTER(I64), C.POINTER(I32), C.POINTER(I32), P]
     lib.lsr_backward.restype = C.c_int

@@ -124,9 +124,9 @@ static int check_dims(const lsr_dims *d) {
     if (tiles_x(*d) > 65535 || tiles_y(*d) > 65535) return LSR_EUNSUPPORTED;
     // work items pack (view*T + tile) into 28 bits (kItemTileMask)
     if ((int64_t)d->num_views * num_tiles(*d) >= (int64_t)1 << 28) return LSR_EUNSUPPORTED;
-    // (view, Gaussian) slots are indexed with 31 bits; a quadrant-list entry keeps the Gaussian index in 28
+    // (view, Gaussian) slots are indexed with 31 bits; sort keys and render-list entries keep the Gaussian index in 24
     if ((int64_t)d->num_views * d->num_gaussians >= (int64_t)1 << 31) return LSR_EUNSUPPORTED;
-    if ((int64_t)d->num_gaussians > (int64_t)1 << 28) return LSR_EUNSUPPORTED;
+    if ((int64_t)d->num_gaussians > (int64_t)kMaxGaussians) return LSR_EUNSUPPORTED;
     // per-view strides: 0 (shared scene) or exactly one dense (G, ...) array per view
     const int64_t G = d->num_gaussians;
     const int64_t color_elems = d->color_mode == LSR_COLOR_SH ? (int64_t)d->sh_coeffs * 3 : 3;
@@ -187,15 +187,23 @@ static int for_each_view_group(const lsr_dims &d, const lsr_inputs &in, const ls
     }
     return LSR_OK;
 }
-// The SH payload pass (sh.hip) depends on k_preprocess only and touches nothing that tile_scan / scatter /
-// sort read or write, so the forward runs it on a library-owned side stream: forked after the preprocess
-// launch, joined before the compositing launch.  In the synchronous forward this also fills the host's
-// round trip for the pair count (the device used to idle ~45 us there).  One side stream and one pair of
-// events per device, shared by all host threads: stream order on the side stream makes a wait on the
-// LATEST join record cover every earlier fork.  LSR_SH_SIDE_STREAM=0 keeps everything on the caller's stream.
+// The library owns ONE side stream per device, shared by all host threads, for work that may run beside
+// the caller's stream inside a call:
+//   * the SH payload pass (sh.hip) depends on k_preprocess only and touches nothing that tile_scan / scatter /
+//     sort read or write: forked after the preprocess launch, joined before the first compositing launch
+//     (in the synchronous forward this also fills the host's round trip for the pair count);
+//   * the binning of view chunk c + 1 runs beside the compositing of chunk c (view chunks, lsr_internal.h);
+//   * the backward's per-scene geometry / SH kernels of odd scenes.
+// Every cross-stream edge is an event record + a stream wait.  The events are shared too, so a record and the
+// wait that consumes it are issued under the context's mutex (a wait binds to the record that precedes it):
+// another host thread re-recording the same event can then only make a LATER wait cover more work, never less
+// — the side stream executes in order, so a wait on the latest record covers every earlier one.
+// LSR_SH_SIDE_STREAM=0 keeps everything on the caller's stream (and view chunks off).
 struct SideCtx {
     hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;            // caller -> side, side -> caller
+    hipEvent_t chunk[kMaxViewChunks] = {};                // side -> caller: binning of view chunk c is done
+    std::mutex mu;
     bool tried = false;
 };
 static SideCtx *side_ctx() {
@@ -208,15 +216,40 @@ static SideCtx *side_ctx() {
     SideCtx &c = ctx[dev];
     if (!c.tried) {
         c.tried = true;
-        if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c.join, hipEventDisableTiming) != hipSuccess) {
+        bool ok = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&c.join, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < kMaxViewChunks; ++i) ok = hipEventCreateWithFlags(&c.chunk[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
             (void)hipGetLastError();
             c.side = nullptr;
         }
     }
     return c.side ? &c : nullptr;
 }
+// `to` waits for everything queued on `from` so far (ev: one of the context's events)
+static hipError_t cross_edge(SideCtx *c, hipEvent_t ev, hipStream_t from, hipStream_t to) {
+    std::lock_guard<std::mutex> lock(c->mu);
+    hipError_t e = hipEventRecord(ev, from);
+    if (e != hipSuccess) return e;
+    return hipStreamWaitEvent(to, ev, 0);
+}
+
+// View chunks of the pipelined forward (lsr_internal.h).  LSR_PIPE_CHUNKS (development knob, read once):
+// unset / 0 / 1 = one chunk (the default), n = n chunks whenever the views divide evenly.
+// Measured on MI355X (16 views x 300 k Gaussians): 2 chunks 0.567 vs 0.577 ms per step with 32
+// compositing waves per CU, 0.626 vs 0.566 with 16 — beside a compositing kernel the next chunk's scatter / sort
+// run two to three times longer and slow the compositing down by as much as they hide; the mechanism stays
+// (tested for bitwise equal results) but is off by default.
+int lsr::view_chunks(const lsr_dims &d) {
+    if (!env_int("LSR_SH_SIDE_STREAM", 1)) return 1;
+    int K = env_int("LSR_PIPE_CHUNKS", 1);
+    if (K < 1) K = 1;
+    if (K > kMaxViewChunks) K = kMaxViewChunks;
+    while (K > 1 && d.num_views % K != 0) --K;
+    return K;
+}
+
 static bool has_sh_payload(const lsr_dims &d) {
     return d.num_gaussians > 0 && (d.color_mode == LSR_COLOR_SH || (d.feat_channels > 0 && d.feat_mode == LSR_FEAT_SH));
 }
@@ -227,11 +260,7 @@ static int sh_forward_fork(const lsr_dims &d, const lsr_inputs &in, char *geom, 
     SideCtx *c = side_ctx();
     hipStream_t q = s;
     if (c) {
-        // record + wait as one step: another host thread forking on the same device re-records the same event
-        static std::mutex fork_mu;
-        std::lock_guard<std::mutex> lock(fork_mu);
-        LSR_HIP(hipEventRecord(c->fork, s));
-        LSR_HIP(hipStreamWaitEvent(c->side, c->fork, 0));
+        LSR_HIP(cross_edge(c, c->fork, s, c->side));
         q = c->side;
     }
     const int rc = for_each_view_group(d, in, nullptr, [&](const lsr_dims &dg, const lsr_inputs &ig, const lsr_in_grads &, const lsr_dims *layout, int view0) -> int {
@@ -239,12 +268,56 @@ static int sh_forward_fork(const lsr_dims &d, const lsr_inputs &in, char *geom, 
         return LSR_OK;
     });
     if (rc) return rc;
-    if (c) LSR_HIP(hipEventRecord(c->join, c->side));
+    if (c) {
+        std::lock_guard<std::mutex> lock(c->mu);
+        LSR_HIP(hipEventRecord(c->join, c->side));
+    }
     return LSR_OK;
 }
+// The caller's stream waits for the SH pass (the latest record of the join event: this call's, or a later one
+// of another host thread, which the in-order side stream completes after this call's).
 static int sh_forward_join(const lsr_dims &d, hipStream_t s) {
     if (!has_sh_payload(d)) return LSR_OK;
-    if (SideCtx *c = side_ctx()) LSR_HIP(hipStreamWaitEvent(s, c->join, 0));
+    if (SideCtx *c = side_ctx()) {
+        std::lock_guard<std::mutex> lock(c->mu);
+        LSR_HIP(hipStreamWaitEvent(s, c->join, 0));
+    }
+    return LSR_OK;
+}
+
+// Binning + forward compositing of all view chunks.  One chunk: everything on `s`.  K chunks:
+//   s    : scatter_0 sort_0 | render_0 | render_1 | ...          (render_c waits for chunk c's binning)
+//   side :                 | scatter_1 sort_1 | scatter_2 ...    (starts when chunk 0's binning is done)
+// so the binning of the later chunks runs beside the compositing of the earlier ones.
+static int forward_chunks(const lsr_dims &d, const lsr_inputs &in, char *geom, char *bin, char *img, int64_t num_pairs,
+                          int32_t max_tile_pairs, const lsr_outputs &out, hipStream_t s, bool device_counts) {
+    const int K = view_chunks(d);
+    SideCtx *c = K > 1 ? side_ctx() : nullptr;
+    if (!c) {   // (K is 1 whenever the side stream is switched off; a failed stream creation falls back to in-order chunks)
+        for (int k = 0; k < K; ++k)
+            LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts, view_chunk(d, K, k)));
+        int rc = sh_forward_join(d, s);
+        if (rc) return rc;
+        for (int k = 0; k < K; ++k)
+            LSR_STAGE("render_forward", s, launch_render_forward(d, in, geom, bin, num_pairs, img, out, s, view_chunk(d, K, k)));
+        return LSR_OK;
+    }
+    LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts, view_chunk(d, K, 0)));
+    LSR_HIP(cross_edge(c, c->fork, s, c->side));            // the side stream starts behind chunk 0's binning (and behind the SH pass it may carry)
+    for (int k = 1; k < K; ++k) {
+        LSR_STAGE("binning", c->side, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, c->side, device_counts, view_chunk(d, K, k)));
+        std::lock_guard<std::mutex> lock(c->mu);
+        LSR_HIP(hipEventRecord(c->chunk[k], c->side));
+    }
+    int rc = sh_forward_join(d, s);   // (the join event was recorded behind the SH pass, before this call's chunk work: only the SH pass is waited for)
+    if (rc) return rc;
+    for (int k = 0; k < K; ++k) {
+        if (k > 0) {
+            std::lock_guard<std::mutex> lock(c->mu);
+            LSR_HIP(hipStreamWaitEvent(s, c->chunk[k], 0));
+        }
+        LSR_STAGE("render_forward", s, launch_render_forward(d, in, geom, bin, num_pairs, img, out, s, view_chunk(d, K, k)));
+    }
     return LSR_OK;
 }
 
@@ -326,7 +399,7 @@ int lsr_get_layout(const lsr_dims *d, int64_t num_pairs, lsr_layout *out) {
     out->geom_rec = L.rec; out->geom_rec_floats = (size_t)L.rec_floats; out->geom_bin = L.bin;
     out->geom_tile_count = L.tile_count; out->geom_tile_start = L.tile_start; out->geom_header = L.header;
     out->bin_keys = B.keys; out->bin_point_list = B.point_list;
-    out->bin_quad_list = B.quad_list; out->geom_quad_count = L.quad_count; out->key_index_shift = (size_t)key_index_shift(d->num_gaussians);
+    out->bin_half_list = B.half_list; out->geom_half_count = L.half_count;
     out->img_final_T = I.final_T; out->img_n_contrib = I.n_contrib;
     out->geom_bin_stride = bin_stride(*d);
     return LSR_OK;
@@ -431,10 +504,13 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
     if (num_pairs < 0 || max_tile_pairs < 0) return LSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    LSR_STAGE("binning", s, launch_binning(*d, (char *)geom_ws, (char *)bin_ws, num_pairs, max_tile_pairs, out->radii, s));
-    rc = sh_forward_join(*d, s);   // the SH payload pass was launched by lsr_forward_prepare
-    if (rc) return rc;
-    LSR_STAGE("render_forward", s, launch_render_forward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs, (char *)img_ws, *out, s));
+    // binning + compositing per view chunk; waits for the SH payload pass lsr_forward_prepare launched
+    return forward_chunks(*d, *in, (char *)geom_ws, (char *)bin_ws, (char *)img_ws, num_pairs, max_tile_pairs, *out, s, false);
+}
+
+int lsr_forward_abandon(lsr_stream_t stream) {
+    g_last_hip_error = 0;
+    if (SideCtx *c = side_ctx()) LSR_HIP(cross_edge(c, c->join, c->side, (hipStream_t)stream));
     return LSR_OK;
 }
 
@@ -457,11 +533,7 @@ int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     rc = sh_forward_fork(*d, *in, geom, s);
     if (rc) return rc;
     LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, (uint32_t)pair_capacity, s));
-    LSR_STAGE("binning", s, launch_binning(*d, geom, (char *)bin_ws, pair_capacity, max_tile_hint, out->radii, s, true));
-    rc = sh_forward_join(*d, s);
-    if (rc) return rc;
-    LSR_STAGE("render_forward", s, launch_render_forward(*d, *in, geom, (const char *)bin_ws, pair_capacity, (char *)img_ws, *out, s));
-    return LSR_OK;
+    return forward_chunks(*d, *in, geom, (char *)bin_ws, (char *)img_ws, pair_capacity, max_tile_hint, *out, s, true);
 }
 
 int lsr_forward_status(const lsr_dims *d, const void *geom_ws, int64_t *num_pairs_host, int32_t *max_tile_pairs_host,
@@ -510,12 +582,7 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
     // concurrently (forked behind the compositing backward, joined at the end).
     const int groups = d->views_per_group > 1 ? (d->num_views + d->views_per_group - 1) / d->views_per_group : 1;
     SideCtx *c = groups >= 2 ? side_ctx() : nullptr;
-    if (c) {
-        static std::mutex fork_mu;
-        std::lock_guard<std::mutex> lock(fork_mu);
-        LSR_HIP(hipEventRecord(c->fork, s));
-        LSR_HIP(hipStreamWaitEvent(c->side, c->fork, 0));
-    }
+    if (c) LSR_HIP(cross_edge(c, c->fork, s, c->side));
     int g = 0;
     rc = for_each_view_group(*d, *in, gin, [&](const lsr_dims &dg, const lsr_inputs &ig, const lsr_in_grads &gg, const lsr_dims *layout, int view0) -> int {
         hipStream_t q = (c && (g++ & 1)) ? c->side : s;
@@ -524,10 +591,7 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
         return LSR_OK;
     });
     if (rc) return rc;
-    if (c) {
-        LSR_HIP(hipEventRecord(c->join, c->side));
-        LSR_HIP(hipStreamWaitEvent(s, c->join, 0));
-    }
+    if (c) LSR_HIP(cross_edge(c, c->join, c->side, s));
     return LSR_OK;
 }
 

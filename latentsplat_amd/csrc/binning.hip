@@ -4,7 +4,7 @@
 //
 //   k_tile_scan : exclusive scan of the per-tile pair counts (V*T entries) -> tile_start,
 //                 total pair count and the longest list (header[0], header[1]); also emits the
-//                 compositing work items — four (view, tile, quadrant) items per tile — ordered
+//                 compositing work items — two (view, tile, half) items per tile — ordered
 //                 longest-list-first (counting sort): the work queue order of both compositing
 //                 kernels (longest-processing-time-first balancing).
 //   k_scatter   : every visible Gaussian writes (depth_bits<<32 | index) into each tile segment
@@ -67,7 +67,7 @@ __device__ __forceinline__ uint32_t block_max(uint32_t v, uint32_t *s_wave) {
 
 __global__ void __launch_bounds__(kScanThreads)
 k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *header,
-            uint32_t *host_mirror, uint32_t *__restrict__ order, int N, uint32_t capacity) {
+            uint32_t *host_mirror, uint32_t *__restrict__ order, int N, uint32_t capacity, int K) {
     __shared__ uint32_t s_wave[kScanWaves];
     __shared__ uint32_t s_cls[kScanThreads];      // counting-sort classes: histogram -> running offsets
     const int tid = threadIdx.x;
@@ -91,24 +91,32 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
         if (host_mirror) { host_mirror[0] = total; host_mirror[1] = maxc; }
     }
     // ---- work items, costliest first: counting sort on kScanThreads classes of the per-tile cost
-    // (= canonical list length; the four quadrant items of a tile stay together).  The exact quadrant list
+    // (= canonical list length; the two half-tile items of a tile stay together).  The exact half list
     // lengths only exist after k_sort_tiles; the order is a scheduling hint (longest-processing-time
     // first for the compositing kernels' work queue), never a correctness matter. ----
+    // With K view chunks (lsr_internal.h) every chunk gets its own costliest-first list: chunk c's items are
+    // order[2 c N/K, 2 (c+1) N/K).
     const uint64_t scale = (uint64_t)maxc + 1u;
     auto cls = [&](uint32_t w) -> uint32_t { return kScanThreads - 1 - (uint32_t)(((uint64_t)w * kScanThreads) / scale); };
-    s_cls[tid] = 0;
-    __syncthreads();
-    for (int i = lo; i < hi; ++i) atomicAdd(&s_cls[cls(count[i])], 4u);
-    __syncthreads();
-    const uint32_t mine = s_cls[tid];
-    uint32_t num_items;
-    const uint32_t first = block_exclusive_scan(mine, s_wave, num_items);   // exclusive start of class tid
-    s_cls[tid] = first;
-    if (tid == 0) header[kHdrNumItems] = num_items;
-    __syncthreads();
-    for (int i = lo; i < hi; ++i) {
-        const uint32_t at = atomicAdd(&s_cls[cls(count[i])], 4u);
-        for (uint32_t q = 0; q < 4; ++q) order[at + q] = (uint32_t)i | (q << kItemQuadShift);
+    if (tid == 0) header[kHdrNumItems] = 2u * (uint32_t)N;
+    const int per_chunk = N / K;
+    for (int c = 0; c < K; ++c) {
+        const int a = max(lo, c * per_chunk), b = min(hi, (c + 1) * per_chunk);
+        s_cls[tid] = 0;
+        __syncthreads();
+        for (int i = a; i < b; ++i) atomicAdd(&s_cls[cls(count[i])], 2u);
+        __syncthreads();
+        const uint32_t mine = s_cls[tid];
+        uint32_t num_items;
+        const uint32_t first = block_exclusive_scan(mine, s_wave, num_items);   // exclusive start of class tid
+        s_cls[tid] = first;
+        __syncthreads();
+        uint32_t *ord = order + 2 * (size_t)c * per_chunk;
+        for (int i = a; i < b; ++i) {
+            const uint32_t at = atomicAdd(&s_cls[cls(count[i])], 2u);
+            ord[at] = (uint32_t)i; ord[at + 1] = (uint32_t)i | (1u << kItemHalfShift);
+        }
+        __syncthreads();
     }
 }
 
@@ -118,7 +126,7 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror
     prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
                        (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
-                       (uint32_t *)(geom + L.header), host_mirror, (uint32_t *)(geom + L.tile_order), N, pair_capacity);
+                       (uint32_t *)(geom + L.header), host_mirror, (uint32_t *)(geom + L.tile_order), N, pair_capacity, view_chunks(d));
     prof_end(kStTileScan, s);
     return hipGetLastError();
 }
@@ -129,9 +137,9 @@ constexpr int kScatItems = 12;   // most (view, Gaussian) items of one thread; t
 
 template <bool LDS_RESERVE, bool CHECK, bool NARROW>
 __global__ void __launch_bounds__(kScatThreads, 8)
-k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
+k_scatter(int G, int gx, int T, int view0, const char *__restrict__ binrec,
           const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ tile_cursor,
-          uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, int idx_shift, unsigned long long *trace) {
+          uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, unsigned long long *trace) {
 #ifdef LSR_ENABLE_TRACE
 #define LSR_STAMP(k) do { if (trace && threadIdx.x == 0) trace[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
 #else
@@ -141,7 +149,7 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
     extern __shared__ uint32_t s_mem[];  // [T] counts, [T] bases
     uint32_t *s_cnt = s_mem, *s_base = s_mem + T;
     const uint32_t unit = blockIdx.x;   // view-major (view, chunk)
-    const int v = (int)(unit / chunks);
+    const int v = view0 + (int)(unit / chunks);
     const size_t vo = (size_t)v * G;
     const uint32_t *ts = tile_start + (size_t)v * T;
     uint32_t *cur = tile_cursor + (size_t)v * T;
@@ -200,9 +208,8 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
         int x0, y0, x1, y1;
         unpack(it, x0, y0, x1, y1);
         if (x1 <= x0 || y1 <= y0) continue;
-        // key = depth bits << 32 | index << 8 | sub-block code of THIS tile (lsr_internal.h); plain index when the
-        // scene is too large for the 24-bit field (idx_shift == 0)
-        const uint64_t key = ((uint64_t)__float_as_uint(dep[it]) << 32) | (i << idx_shift);
+        // key = depth bits << 32 | index << 8 | sub-block code of THIS tile (lsr_internal.h)
+        const uint64_t key = ((uint64_t)__float_as_uint(dep[it]) << 32) | (i << kKeyIndexShift);
         const uint32_t sp = span[it];
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) {
@@ -210,7 +217,7 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
                 uint32_t pos;
                 if (LDS_RESERVE) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
                 else pos = ts[t] + atomicAdd(&cur[t], 1u);
-                const uint32_t code = idx_shift ? span_code(sp, x - x0, y - y0) : 0u;
+                const uint32_t code = span_code(sp, x - x0, y - y0);
                 if (!CHECK || pos < capacity) keys[pos] = key | code;   // CHECK (no-sync forward): tile_scan clamped the offsets to the workspace capacity
             }
     }
@@ -232,56 +239,35 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
 // ------------------------------------------------------------------------------------------
 constexpr int kSortThreads = 512;
 
-// What k_sort_tiles needs to turn a tile's sorted list into its four quadrant render lists.
-struct QuadOut {
-    const char *binrec;       // [V*G] bin records (only read when the keys carry no sub-block code: idx_shift == 0)
-    uint32_t *quad_list;      // BinLayout::quad_list
-    uint32_t *quad_count;     // GeomLayout::quad_count
-    int G, gx, narrow;
-    int idx_shift;            // key_index_shift(G): 8 = low key byte is the pair's sub-block code, 0 = plain index
+// Where k_sort_tiles puts the two half-tile render lists of a tile (BinLayout::half_list, GeomLayout::half_count).
+struct HalfOut {
+    uint32_t *half_list, *half_count;
 };
-// low key word -> Gaussian index, and the pair's 16-bit sub-block mask (from the code in the key, or from the
-// Gaussian's bin record for oversized scenes)
-struct TileCtx {
-    QuadOut qo;
-    const char *vbin;         // bin records of this tile's view
-    int tx, ty;               // tile coordinates
-    __device__ __forceinline__ uint32_t index_of(uint32_t w) const { return w >> qo.idx_shift; }
-    __device__ __forceinline__ uint32_t mask_of(uint32_t w) const {
-        if (qo.idx_shift) return code_mask(w & 0xFFu);
-        const uint32_t i = min(w, (uint32_t)qo.G - 1u);
-        int rx, ry;
-        uint32_t span;
-        if (qo.narrow) { const BinRec br = ((const BinRec *)vbin)[i]; rx = (int)(br.rect & 0xFFu); ry = (int)((br.rect >> 8) & 0xFFu); span = br.span; }
-        else { const BinRecWide br = ((const BinRecWide *)vbin)[i]; rx = br.rect.x; ry = br.rect.y; span = br.span; }
-        return code_mask(span_code(span, tx - rx, ty - ry));
-    }
-};
-constexpr int kEmitTab = 130;   // uint64 words of LDS scratch emit_quadrant_lists needs
+__device__ __forceinline__ uint32_t key_index(uint32_t low_word) { return low_word >> kKeyIndexShift; }
+constexpr int kEmitTab = 130;   // uint64 words of LDS scratch emit_half_lists needs
 
 // Block-wide (kSortThreads threads): walks the tile's depth-sorted list in order and appends every entry to
-// the list of each 8x8 quadrant its footprint can reach (order preserved), as `index | 4 sub-block
-// bits << 28`.  low_word(p) = low key word of sorted position p.  A pass covers 64 wave-chunks of 64
-// positions: per chunk and quadrant a ballot count (four 16-bit fields of one u64), one wave scans the 64
-// chunk totals, then every entry's place is chunk offset + lanes below it in the ballot.
-// qdst = quad_list + 4 * tile_start: the list of quadrant q starts at qdst + q * n.
+// the list of each half of the tile (pixel rows 0-7 / 8-15) its footprint can reach (order preserved), as
+// `index | 8 sub-block bits << 24`; the sub-block mask comes from the code in the low key byte.
+// low_word(p) = low key word of sorted position p.  A pass covers 64 wave-chunks of 64 positions: per chunk
+// and half a ballot count (two 32-bit fields of one u64), one wave scans the 64 chunk totals, then every
+// entry's place is chunk offset + lanes below it in the ballot.
+// hdst = half_list + 2 * tile_start: the list of half h starts at hdst + h * n.
 template <class LowWord>
-__device__ __forceinline__ void emit_quadrant_lists(const TileCtx &tc, uint32_t n, uint32_t *qdst, uint32_t *qcnt, uint64_t *s_tab, LowWord low_word) {
+__device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint32_t *hcnt, uint64_t *s_tab, LowWord low_word) {
     const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
     constexpr int kWaves = kSortThreads / LSR_WAVE, kSteps = LSR_WAVE / kWaves;
-    constexpr uint32_t qsb[4] = {0x0033u, 0x00CCu, 0x3300u, 0xCC00u};
-    uint32_t run[4] = {0u, 0u, 0u, 0u};
+    uint32_t run0 = 0u, run1 = 0u;
     for (uint32_t base = 0; base < n; base += LSR_WAVE * LSR_WAVE) {
-        // (nothing but `run` lives across the barriers: the second phase reads the words again — the kernel's
-        // register budget decides how many of its workgroups share a CU)
+        // (nothing but the running lengths lives across the barriers: the second phase reads the words again — the
+        // kernel's register budget decides how many of its workgroups share a CU)
 #pragma unroll
         for (int st = 0; st < kSteps; ++st) {
             const uint32_t p = base + (uint32_t)((st * kWaves + wid) * LSR_WAVE + lane);
             const uint32_t w = low_word(min(p, n - 1));            // unconditional at a clamped position
-            const uint32_t m16 = p < n ? tc.mask_of(w) : 0u;
-            uint64_t packed = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) packed |= (uint64_t)__builtin_popcountll(__ballot((m16 & qsb[q]) != 0u)) << (16 * q);
+            const uint32_t m16 = p < n ? code_mask(w & 0xFFu) : 0u;
+            const uint64_t packed = (uint64_t)__builtin_popcountll(__ballot((m16 & 0x00FFu) != 0u)) |
+                                    ((uint64_t)__builtin_popcountll(__ballot((m16 & 0xFF00u) != 0u)) << 32);
             if (lane == 0) s_tab[st * kWaves + wid] = packed;
         }
         __syncthreads();
@@ -300,24 +286,22 @@ __device__ __forceinline__ void emit_quadrant_lists(const TileCtx &tc, uint32_t 
             const uint32_t p = base + (uint32_t)((st * kWaves + wid) * LSR_WAVE + lane);
             if (base + (uint32_t)((st * kWaves + wid) * LSR_WAVE) >= n) break;   // wave-uniform
             const uint32_t w = low_word(min(p, n - 1));
-            const uint32_t idx = tc.index_of(w), m16 = p < n ? tc.mask_of(w) : 0u;
+            const uint32_t idx = key_index(w), m16 = p < n ? code_mask(w & 0xFFu) : 0u;
             const uint64_t off = s_tab[LSR_WAVE + st * kWaves + wid];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool in = (m16 & qsb[q]) != 0u;
-                const uint64_t bal = __ballot(in);
-                if (in) {
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t bits = half_bits(m16, h);
+                const uint64_t bal = __ballot(bits != 0u);
+                if (bits) {
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    qdst[(size_t)q * n + run[q] + (uint32_t)((off >> (16 * q)) & 0xFFFFu) + below] =
-                        idx | (quadrant_bits(m16, q) << kQuadBitsShift);
+                    hdst[(size_t)h * n + (h ? run1 : run0) + (uint32_t)(off >> (32 * h)) + below] = idx | (bits << kListBitsShift);
                 }
             }
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) run[q] += (uint32_t)((tot >> (16 * q)) & 0xFFFFu);
+        run0 += (uint32_t)tot; run1 += (uint32_t)(tot >> 32);
         __syncthreads();   // s_tab is reused by the next pass
     }
-    if (tid < 4) qcnt[tid] = tid == 0 ? run[0] : (tid == 1 ? run[1] : (tid == 2 ? run[2] : run[3]));
+    if (tid < 2) hcnt[tid] = tid == 0 ? run0 : run1;
 }
 
 // One workgroup per (tile, view); list length n <= CAP, keys sorted inside LDS.
@@ -342,8 +326,8 @@ constexpr uint32_t kBucketOverflow = 48;   // longest bucket the in-bucket pass 
 
 template <int CAP>
 __global__ void __launch_bounds__(kSortThreads)
-k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
-             uint32_t *__restrict__ point_list, QuadOut qo, uint32_t longer_than, unsigned long long *trace) {
+k_sort_tiles(int T, int view0, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
+             uint32_t *__restrict__ point_list, HalfOut ho, uint32_t longer_than, unsigned long long *trace) {
 #ifdef LSR_ENABLE_TRACE
 #define LSR_STAMP(k) do { if (trace && threadIdx.x == 0) trace[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
 #else
@@ -358,26 +342,22 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
     uint32_t *s_wsum = (uint32_t *)(s_keys + 2 * kWaves); // [kWaves] scan partials        } dead before the
     uint32_t *s_flag = s_wsum + kWaves;                   // bucket overflow               } first key is placed
     const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
-    const size_t vt = blockIdx.x;   // view-major (view, tile)
+    const size_t vt = blockIdx.x + (size_t)view0 * T;   // view-major (view, tile)
     const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
-    uint32_t *qcnt = qo.quad_count + 4 * vt, *qdst = qo.quad_list + 4 * (size_t)start;
-    if (n == 0) { if (longer_than == 0 && tid < 4) qcnt[tid] = 0; return; }
+    uint32_t *hcnt = ho.half_count + 2 * vt, *hdst = ho.half_list + 2 * (size_t)start;
+    if (n == 0) { if (longer_than == 0 && tid < 2) hcnt[tid] = 0; return; }
     if (n <= longer_than) return;   // shorter lists belong to another launch (no-sync forward: two variants)
     if (n > (uint32_t)CAP) return;  // handled by a larger variant / the global-memory path
     const uint64_t *src = keys + start;
-    const int tile = (int)(vt % (size_t)T);
-    TileCtx tc;
-    tc.qo = qo; tc.tx = tile % qo.gx; tc.ty = tile / qo.gx;
-    tc.vbin = qo.binrec + (vt / (size_t)T) * (size_t)qo.G * (qo.narrow ? sizeof(BinRec) : sizeof(BinRecWide));
     if (n == 1) {
         if (tid == 0) {
-            const uint32_t w = (uint32_t)src[0], idx = tc.index_of(w);
+            const uint32_t w = (uint32_t)src[0], idx = key_index(w);
             point_list[start] = idx;
-            const uint32_t m = tc.mask_of(w);
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t bits = quadrant_bits(m, q);
-                if (bits) qdst[q] = idx | (bits << kQuadBitsShift);
-                qcnt[q] = bits ? 1u : 0u;
+            const uint32_t m = code_mask(w & 0xFFu);
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t bits = half_bits(m, h);
+                if (bits) hdst[h] = idx | (bits << kListBitsShift);
+                hcnt[h] = bits ? 1u : 0u;
             }
         }
         return;
@@ -488,9 +468,9 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
                 if (tid + q * kSortThreads < n) s_out[dst[q]] = (uint32_t)kreg[q];
             __syncthreads();
             LSR_STAMP(5);
-            for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = tc.index_of(s_out[i]);
-            // quadrant render lists (the bucket offsets in s_cnt are dead: scratch of the emitter)
-            emit_quadrant_lists(tc, n, qdst, qcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return s_out[p]; });
+            for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = key_index(s_out[i]);
+            // half-tile render lists (the bucket offsets in s_cnt are dead: scratch of the emitter)
+            emit_half_lists(n, hdst, hcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return s_out[p]; });
             LSR_STAMP(6);
         } else {
             // ---- lists beyond the register budget: scatter with a second atomic (s_cnt[b] ends up as the
@@ -510,8 +490,8 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
                 }
             }
             __syncthreads();
-            for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = tc.index_of((uint32_t)s_keys[i]);
-            emit_quadrant_lists(tc, n, qdst, qcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return (uint32_t)s_keys[p]; });
+            for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = key_index((uint32_t)s_keys[i]);
+            emit_half_lists(n, hdst, hcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return (uint32_t)s_keys[p]; });
         }
     } else {
         // ---- bitonic network over the padded list ----
@@ -539,8 +519,8 @@ k_sort_tiles(int T, const uint32_t *__restrict__ tile_start, const uint64_t *__r
                 __syncthreads();
             }
         }
-        for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = tc.index_of((uint32_t)s_keys[i]);
-        emit_quadrant_lists(tc, n, qdst, qcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return (uint32_t)s_keys[p]; });
+        for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = key_index((uint32_t)s_keys[i]);
+        emit_half_lists(n, hdst, hcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return (uint32_t)s_keys[p]; });
     }
 #ifdef LSR_ENABLE_TRACE
     if (trace && tid == 0) {
@@ -562,10 +542,10 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t 
     return lo;
 }
 __global__ void __launch_bounds__(kSortThreads)
-k_sort_tiles_global(int T, uint32_t cap, const uint32_t *__restrict__ tile_start,
-                    uint64_t *keys, uint64_t *tmp, uint32_t *point_list, QuadOut qo) {
+k_sort_tiles_global(int T, int view0, uint32_t cap, const uint32_t *__restrict__ tile_start,
+                    uint64_t *keys, uint64_t *tmp, uint32_t *point_list, HalfOut ho) {
     __shared__ uint64_t s_tab[kEmitTab];
-    const size_t vt = blockIdx.x;   // view-major (view, tile)
+    const size_t vt = blockIdx.x + (size_t)view0 * T;   // view-major (view, tile)
     const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
     if (n <= cap) return;
     uint64_t *src = keys + start, *dst = tmp + start;
@@ -584,44 +564,39 @@ k_sort_tiles_global(int T, uint32_t cap, const uint32_t *__restrict__ tile_start
         __syncthreads();
         uint64_t *t = src; src = dst; dst = t;
     }
-    const int tile = (int)(vt % (size_t)T);
-    TileCtx tc;
-    tc.qo = qo; tc.tx = tile % qo.gx; tc.ty = tile / qo.gx;
-    tc.vbin = qo.binrec + (vt / (size_t)T) * (size_t)qo.G * (qo.narrow ? sizeof(BinRec) : sizeof(BinRecWide));
     for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
-        point_list[start + i] = tc.index_of((uint32_t)src[i]);
+        point_list[start + i] = key_index((uint32_t)src[i]);
     const uint64_t *sorted = src;
-    emit_quadrant_lists(tc, n, qo.quad_list + 4 * (size_t)start, qo.quad_count + 4 * vt, s_tab, [&](uint32_t p) { return (uint32_t)sorted[p]; });
+    emit_half_lists(n, ho.half_list + 2 * (size_t)start, ho.half_count + 2 * vt, s_tab, [&](uint32_t p) { return (uint32_t)sorted[p]; });
 }
 
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
-                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts) {
+                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts, ViewChunk vc) {
     (void)radii;
     const GeomLayout L = geom_layout(d);
-    if (num_pairs <= 0 || d.num_gaussians == 0)   // nothing to sort: every quadrant render list is empty
-        return launch_clear(geom + L.quad_count, align_up((size_t)d.num_views * (size_t)num_tiles(d) * 16), s);
+    if (num_pairs <= 0 || d.num_gaussians == 0)   // nothing to sort: every half-tile render list is empty
+        // (the whole array, whatever the chunk: no pairs in the call means no chunk sorts anything)
+        return launch_clear(geom + L.half_count, align_up((size_t)d.num_views * (size_t)num_tiles(d) * 8, 16), s);
     // no-sync forward: the merge scratch is always part of the layout (the longest list is unknown)
     const BinLayout B = bin_layout(d, num_pairs, device_counts ? kSortLdsMax + 1 : max_tile_pairs);
     const int T = (int)num_tiles(d), gx = tiles_x(d);
     uint64_t *keys = (uint64_t *)(bin + B.keys);
     uint32_t *plist = (uint32_t *)(bin + B.point_list);
-    QuadOut qo;
-    qo.binrec = geom + L.bin; qo.quad_list = (uint32_t *)(bin + B.quad_list);
-    qo.quad_count = (uint32_t *)(geom + L.quad_count);
-    qo.G = d.num_gaussians; qo.gx = gx; qo.narrow = narrow_bins(d) ? 1 : 0; qo.idx_shift = key_index_shift(d.num_gaussians);
     const uint32_t *ts = (const uint32_t *)(geom + L.tile_start);
+    HalfOut ho;
+    ho.half_list = (uint32_t *)(bin + B.half_list); ho.half_count = (uint32_t *)(geom + L.half_count);
     {
         const bool lds = T <= 8192;
         // Items per thread: the launch should be ONE round of resident workgroups (8 per CU, fewer when
         // the per-tile counters of a large image take the LDS) — with a fixed 2048 Gaussians per block the
         // 16-view headline needed 9.2 blocks per CU and ran a second, 15 %-full round (phase trace).
         const int64_t resident = (int64_t)device_cus() * (lds ? std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / ((int64_t)T * 8 + 64))) : 8);
-        const int64_t work = (int64_t)d.num_views * d.num_gaussians;
+        const int64_t work = (int64_t)vc.num_views * d.num_gaussians;
         const int64_t rounds = (work + resident * kScatThreads * kScatItems - 1) / (resident * kScatThreads * kScatItems);
         int items = (int)((work + resident * kScatThreads * rounds - 1) / (resident * kScatThreads * rounds));
         items = std::max(1, std::min(kScatItems, items));
         const uint32_t chunks = (uint32_t)((d.num_gaussians + kScatThreads * items - 1) / (kScatThreads * items));
-        dim3 grid(chunks * (uint32_t)d.num_views);
+        dim3 grid(chunks * (uint32_t)vc.num_views);
         unsigned long long *strace = nullptr;
 #ifdef LSR_ENABLE_TRACE
         const char *strace_path = getenv("LSR_TRACE_SCATTER");
@@ -633,8 +608,8 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         prof_begin(kStScatter, s);
         const uint32_t capacity = (uint32_t)(num_pairs < 0xFFFFFFFFll ? num_pairs : 0xFFFFFFFFll);
 #define LSR_SCAT2(LDSR, CHK, NRW, SHM)                                                                         \
-    hipLaunchKernelGGL((k_scatter<LDSR, CHK, NRW>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T,  \
-                       (const char *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, key_index_shift(d.num_gaussians), strace)
+    hipLaunchKernelGGL((k_scatter<LDSR, CHK, NRW>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T, vc.view0, \
+                       (const char *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, strace)
 #define LSR_SCAT(LDSR, CHK, SHM) do { if (narrow_bins(d)) LSR_SCAT2(LDSR, CHK, true, SHM); else LSR_SCAT2(LDSR, CHK, false, SHM); } while (0)
         if (lds) { if (device_counts) LSR_SCAT(true, true, (size_t)T * 8); else LSR_SCAT(true, false, (size_t)T * 8); }
         else { if (device_counts) LSR_SCAT(false, true, 0); else LSR_SCAT(false, false, 0); }
@@ -654,7 +629,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         if (e != hipSuccess) return e;
     }
     {
-        dim3 grid((uint32_t)T * (uint32_t)d.num_views);
+        dim3 grid((uint32_t)T * (uint32_t)vc.num_views);
         unsigned long long *trace = nullptr;
 #ifdef LSR_ENABLE_TRACE
         const char *trace_path = getenv("LSR_TRACE_SORT");
@@ -675,7 +650,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
                                       CAPV * 8 + (CAPV < 2048 ? CAPV : 2048) * 4);               \
         hipLaunchKernelGGL((k_sort_tiles<CAPV>), grid, dim3(kSortThreads),                       \
                            (size_t)CAPV * 8 + (size_t)(CAPV < 2048 ? CAPV : 2048) * 4, s,        \
-                           T, ts, (const uint64_t *)keys, plist, qo, longer_than, trace);        \
+                           T, vc.view0, ts, (const uint64_t *)keys, plist, ho, longer_than, trace); \
     } while (0)
         if (max_tile_pairs <= 1024) LSR_SORT(1024);
         else if (max_tile_pairs <= 2048) LSR_SORT(2048);
@@ -694,8 +669,8 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         }
 #undef LSR_SORT
         if (device_counts || max_tile_pairs > cap) {
-            hipLaunchKernelGGL(k_sort_tiles_global, grid, dim3(kSortThreads), 0, s, T, (uint32_t)cap,
-                               ts, keys, (uint64_t *)(bin + B.tmp), plist, qo);
+            hipLaunchKernelGGL(k_sort_tiles_global, grid, dim3(kSortThreads), 0, s, T, vc.view0, (uint32_t)cap,
+                               ts, keys, (uint64_t *)(bin + B.tmp), plist, ho);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }

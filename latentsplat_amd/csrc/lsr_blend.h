@@ -4,11 +4,12 @@
 // footprint-span / sub-block-code helpers shared by k_preprocess (writes the span), k_scatter (per-pair
 // code in the sort key) and k_sort_tiles (turns the codes into per-quadrant render lists).
 //
-// Work decomposition (CDNA4, wave64): a 16x16 tile is four 8x8 quadrants, a quadrant four 4x4-pixel
-// SUB-BLOCKS.  One wave renders one quadrant: lane l is pixel (l & 3, (l >> 2) & 3) of sub-block
-// l >> 4, so every 16-lane group (= one DPP row) owns one sub-block.  A list entry is evaluated only
-// by the lane groups whose sub-block its exact alpha >= 1/255 footprint box can reach.  Skipping is
-// lossless: a culled (entry, sub-block) would fail the alpha test at every pixel of the sub-block.
+// Work decomposition (CDNA4, wave64): a 16x16 tile is two 16x8 halves, a half eight 4x4-pixel
+// SUB-BLOCKS.  One wave renders one half with TWO horizontally adjacent pixels per lane: the 8-lane
+// group g = lane >> 3 owns sub-block (g & 3, g >> 2) of the half, lane l of the group the pixels
+// (2 (l & 1) + {0, 1}, l >> 1) of the sub-block.  A list entry is evaluated only by the lane groups whose
+// sub-block its alpha >= 1/255 footprint box can reach.  Skipping is lossless: a culled (entry,
+// sub-block) would fail the alpha test at every pixel of the sub-block.
 #pragma once
 #include "lsr_internal.h"
 
@@ -76,11 +77,8 @@ __device__ __forceinline__ uint32_t code_mask(uint32_t code) {
     const uint32_t rows = r0 <= r1 ? ((2u << r1) - (1u << r0)) : 0u;
     return cm * (((rows & 1u) ? 0x1u : 0u) | ((rows & 2u) ? 0x10u : 0u) | ((rows & 4u) ? 0x100u : 0u) | ((rows & 8u) ? 0x1000u : 0u));
 }
-// the four sub-blocks of quadrant q (origin (8*(q&1), 8*(q>>1))) as a 4-bit mask: bit (2*r + c) <-> sub-block (c, r) of the quadrant
-__device__ __forceinline__ uint32_t quadrant_bits(uint32_t m16, int q) {
-    const int q0 = 8 * (q >> 1) + 2 * (q & 1);
-    return ((m16 >> q0) & 3u) | (((m16 >> (q0 + 4)) & 3u) << 2);
-}
+// the eight sub-blocks of half h (0: pixel rows 0-7, 1: rows 8-15) as an 8-bit mask: bit (4*r + c) <-> sub-block (c, r) of the half
+__device__ __forceinline__ uint32_t half_bits(uint32_t m16, int h) { return (m16 >> (8 * h)) & 0xFFu; }
 
 __device__ __forceinline__ float f_from_u(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ unsigned u_from_f(float f) { return __builtin_bit_cast(unsigned, f); }

@@ -17,14 +17,14 @@ namespace lsr {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t header, rec, bin, tile_count, tile_start, tile_cursor, tile_order, quad_count, sh_clamp, total;
+    size_t header, rec, bin, tile_count, tile_start, tile_cursor, tile_order, half_count, sh_clamp, total;
     int rec_floats;
 };
 struct ImgLayout {
     size_t final_T, n_contrib, total;
 };
 struct BinLayout {
-    size_t keys, point_list, quad_list, tmp, total;
+    size_t keys, point_list, half_list, tmp, total;
 };
 // One packed gradient record per (view, Gaussian), accumulated by the compositing backward.  With
 // u = opacity * G * dL/dalpha per (pixel, Gaussian) and d = mean_pix - pixel:
@@ -83,9 +83,8 @@ constexpr uint32_t kSpanAll = 0xFF00FF00u;    // conic not trustworthy: every ce
 // Sort key of a (Gaussian, tile) pair: depth bits << 32 | index << 8 | code, code = c0 | c1 << 2 | r0 << 4 | r1 << 6:
 // the columns c0..c1 and rows r0..r1 (0..3) of the tile's 4x4-pixel sub-blocks the pair can reach
 // (c0 > c1: none).  Indices are distinct inside a tile, so the order is still the published
-// (depth, index) order.  Needs index < 2^24; larger scenes keep `depth << 32 | index` keys
-// (key_index_shift = 0) and k_sort_tiles derives the code from a gather of the bin record instead.
-__host__ __device__ inline int key_index_shift(int num_gaussians) { return num_gaussians <= (1 << 24) ? 8 : 0; }
+// (depth, index) order.  Needs index < 2^24 (kMaxGaussians per scene; lsr_* calls return LSR_EUNSUPPORTED beyond).
+constexpr int kKeyIndexShift = 8;
 constexpr uint32_t kCodeNone = 0x11u;   // c0 = 1 > c1 = 0, r0 = 1 > r1 = 0
 
 inline GeomLayout geom_layout(const lsr_dims &d) {
@@ -100,8 +99,8 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     L.tile_count = o; o = align_up(o + VT * 4);
     L.tile_cursor = o; o = align_up(o + VT * 4);   // adjacent to tile_count: one memset clears both
     L.tile_start = o; o = align_up(o + (VT + 1) * 4);
-    L.tile_order = o; o = align_up(o + 4 * VT * 4);   // work items (see kItem*), costliest first
-    L.quad_count = o; o = align_up(o + 4 * VT * 4);   // entries of the four quadrant render lists of every (view, tile)
+    L.tile_order = o; o = align_up(o + 2 * VT * 4);   // work items (see kItem*), costliest first
+    L.half_count = o; o = align_up(o + 2 * VT * 4);   // entries of the two half-tile render lists of every (view, tile)
     L.sh_clamp = o; o = align_up(o + VG);             // per (view, Gaussian): colour channels clamped at 0 (sh.hip)
     L.total = o;
     return L;
@@ -121,11 +120,12 @@ inline BinLayout bin_layout(const lsr_dims &d, int64_t num_pairs, int32_t max_ti
     const size_t P = (size_t)(num_pairs > 0 ? num_pairs : 1);
     L.keys = 0;
     L.point_list = align_up(P * 8);
-    // Quadrant render lists (k_sort_tiles -> compositing kernels): the tile whose canonical list is
-    // point_list[s, s + n) owns quad_list[4 s, 4 s + 4 n); the list of its quadrant q starts at 4 s + q n
-    // and holds quad_count[4 (view T + tile) + q] entries `index | sub-block bits << 28`.
-    L.quad_list = L.point_list + align_up(P * 4);
-    L.tmp = L.quad_list + align_up(P * 16);
+    // Half-tile render lists (k_sort_tiles -> compositing kernels): the tile whose canonical list is
+    // point_list[s, s + n) owns half_list[2 s, 2 s + 2 n); the list of its upper (h = 0: pixel rows 0-7) / lower
+    // (h = 1) half starts at 2 s + h n and holds half_count[2 (view T + tile) + h] entries
+    // `index | sub-block bits << 24` (bit 4 r + c: the entry can reach the 4x4-pixel sub-block (c, r) of the half).
+    L.half_list = L.point_list + align_up(P * 4);
+    L.tmp = L.half_list + align_up(P * 8);
     L.total = L.tmp + (max_tile_pairs > kSortLdsMax ? align_up(P * 8) : 0);
     return L;
 }
@@ -145,32 +145,43 @@ inline GradLayout grad_layout(const lsr_dims &d) {
     return L;
 }
 
-// Compositing work items: one wave renders ONE 8x8 quadrant of one (view, tile), walking that quadrant's
-// render list (BinLayout::quad_list: only the entries whose alpha >= 1/255 footprint box reaches the
-// quadrant, each with the 4-bit mask of the quadrant's 4x4 sub-blocks it can reach).
-//   item = (view*T + tile) | quadrant << 28.  k_tile_scan emits the four items of every tile, longest
+// Compositing work items: one wave renders one HALF (16 x 8 pixels) of one (view, tile), walking that half's
+// render list (BinLayout::half_list: only the entries whose alpha >= 1/255 footprint box reaches the half,
+// each with the 8-bit mask of the half's 4x4 sub-blocks it can reach).
+//   item = (view*T + tile) | half << 28.  k_tile_scan emits the two items of every tile, longest
 //   canonical list first (the work-queue order of both compositing kernels).
-// Rounds 1-2 walked the canonical tile list per item and re-derived the masks per staged entry; splitting a
-// tile into quadrant items then cost a full re-staging of its list, so a 16-view launch ran one
-// whole tile per wave slot and ended 25 % after its average wave.  With per-quadrant lists an item stages
-// only what it evaluates, so items are a quarter of the size and the queue levels the SIMDs.
+// Rounds 1-2 walked the canonical tile list per item and re-derived the masks per staged entry (a quarter of
+// the staged pairs reached no pixel at all).  With per-half lists an item stages exactly what it evaluates.
 
 // Input slice a view reads: its own (per-view strides), its group's, or the shared one (stride 0).
 __host__ __device__ inline int input_slice(const lsr_dims &d, int v) { return d.views_per_group > 1 ? v / d.views_per_group : v; }
 
 constexpr uint32_t kItemTileMask = 0x0FFFFFFFu;
-constexpr int kItemQuadShift = 28;
-constexpr uint32_t kQuadIndexMask = 0x0FFFFFFFu;   // quad_list entry = Gaussian index | sub-block bits << 28
-constexpr int kQuadBitsShift = 28;
+constexpr int kItemHalfShift = 28;
+constexpr uint32_t kListIndexMask = 0x00FFFFFFu;   // half_list entry = Gaussian index | sub-block bits << 24
+constexpr int kListBitsShift = 24;
+constexpr int kMaxGaussians = 1 << 24;             // index field of the sort keys (index << 8 | code) and of the list entries
 // The compositing kernels run one 16-wave workgroup (4 waves per SIMD) per compute unit; the number
 // of CUs is queried per device (api.hip), so a partitioned (CPX) or binned part gets its own static
 // assignment.  wave slots = CUs x SIMDs x resident compositing waves per SIMD.
 int device_cus();                                   // multiProcessorCount of the current device (cached per device)
-inline int wave_slots(int cus) { return cus * 4 * 4; }
+inline int wave_slots(int cus) { return cus * 4 * 4; }   // (at 4 resident compositing waves per SIMD)
 // Environment knobs are development aids; each is read ONCE per process (never on the launch path).
 int env_int(const char *name, int fallback);        // api.hip: latched on first use
-// header words of the geometry workspace
-enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrQueueFwd = 2, kHdrNumItems = 3, kHdrOverflow = 4, kHdrPreDone = 5 };
+// header words of the geometry workspace (kHdrQueueFwd + c: work-queue head of view chunk c, c < kMaxViewChunks)
+enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrNumItems = 3, kHdrOverflow = 4, kHdrPreDone = 5, kHdrQueueFwd = 8 };
+
+// ---- view chunks (pipelined forward) ----
+// A forward call over V views runs its binning + compositing as K chunks of V / K consecutive views: chunk
+// c + 1's scatter and per-tile sort (short, memory / latency bound, on the library's side stream) run beside
+// chunk c's compositing kernel (VALU bound, persistent waves that leave half of every CU's wave slots free) and
+// fill its load-imbalance tail.  K is a pure function of the dims (and of LSR_PIPE_CHUNKS, read once), because
+// k_tile_scan (work items ordered per chunk), the forward and the backward must agree on it.
+constexpr int kMaxViewChunks = 8;
+int view_chunks(const lsr_dims &d);                 // api.hip
+struct ViewChunk { int view0, num_views, index; };
+inline ViewChunk view_chunk(const lsr_dims &d, int K, int c) { const int n = d.num_views / K; return ViewChunk{c * n, n, c}; }
+inline ViewChunk all_views(const lsr_dims &d) { return ViewChunk{0, d.num_views, 0}; }
 
 // ---- optional per-stage hipEvent timing (api.hip); no-ops unless lsr_profile_enable(1) ----
 enum Stage { kStPreprocess = 0, kStTileScan, kStScatter, kStSort, kStRenderFwd, kStRenderBwd, kStPreprocessBwd, kStShFwd, kStShBwd, kStAdapterFwd, kStAdapterBwd, kStLatentFwd, kStLatentBwd, kNumStages };
@@ -206,11 +217,12 @@ hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const cha
                               const lsr_in_grads &gin, hipStream_t s, const lsr_dims *layout = nullptr, int view0 = 0);
 // device_counts: the pair count / longest list are NOT known on the host (no-sync forward):
 // `num_pairs` is then the workspace capacity and `max_tile_pairs` only a hint for the sort variant
+// (binning and forward compositing take the view chunk they work on)
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
-                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts = false);
+                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts, ViewChunk vc);
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                  const char *bin, int64_t num_pairs, char *img, const lsr_outputs &out,
-                                 hipStream_t s);
+                                 hipStream_t s, ViewChunk vc);
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                   const char *bin, int64_t num_pairs, const char *img,
                                   const lsr_outputs &fwd, const lsr_out_grads &gout, char *grad,

@@ -2,26 +2,28 @@
 // Outputs colour (+ bg), features (bg 0), mask = 1 - T, depth = sum alpha T z, and keeps
 // final_T / n_contrib for the backward pass.  Spec: SURVEY.md Appendix A.3 step 7 + A.4.
 //
-// Execution shape (CDNA4): persistent waves process work items — one 8x8 QUADRANT of one (view,
+// Execution shape (CDNA4): persistent waves process work items — one HALF (16 x 8 pixels) of one (view,
 // tile) each (lsr_internal.h kItem*), sorted by list length: the first one per wave by a static
 // balanced assignment, further ones from a global queue.
 //
-// A wave walks ITS quadrant's render list (written by k_sort_tiles: the depth-ordered entries whose
-// alpha >= 1/255 footprint reaches the quadrant, each with a 4-bit mask of the quadrant's 4x4-pixel
-// SUB-BLOCKS it can reach).  One lane = one pixel, one 16-lane group = one sub-block.  The 64 list
-// entries staged per batch are compacted into 4 per-sub-block lists in LDS (ballot + mbcnt, entries
-// keep their depth order); every lane group then walks ITS sub-block's list, so one wave instruction
-// evaluates up to four different entries, each only on a sub-block it can reach (lossless).
-// History: round 1 evaluated wave-uniform entries on whole quadrants (77 pixel evaluations
+// A wave walks ITS half's render list (written by k_sort_tiles: the depth-ordered entries whose
+// alpha >= 1/255 footprint reaches the half, each with an 8-bit mask of the half's 4x4-pixel
+// SUB-BLOCKS it can reach).  One lane = TWO horizontally adjacent pixels, one 8-lane group = one
+// sub-block.  The 64 list entries staged per batch are compacted into 8 per-sub-block lists in LDS
+// (ballot + mbcnt, entries keep their depth order); every lane group then walks ITS sub-block's
+// list, so one wave instruction evaluates up to eight different entries, each only on a sub-block it
+// can reach (lossless).
+// Why two pixels per lane (round 3): in-situ ablations showed that these kernels are bound
+// by TOTAL instruction issue — a scalar mask operation or an LDS read costs a SIMD about as much as a
+// vector operation (tools/microbench/valu_rates.hip), v_pk_* about 1.4 plain operations.  With two
+// pixels per lane the list read, the three 16-byte record reads, the loop control and the row terms of
+// the exponent (dy, b2 dy, c2 dy^2 + log2 o) are paid once per two pixel evaluations, and the two
+// pixels' independent transmittance chains interleave.
+// History: round 1 evaluated wave-uniform entries on whole 8x8 quadrants (77 pixel evaluations
 // per (Gaussian, tile) pair); round 2 introduced the sub-block lists but staged the CANONICAL tile list
-// per item and derived the masks per staged entry (39 evaluations, 0.75 lock-step iterations per pair;
-// a quarter of the staged pairs reached no pixel, and splitting a tile into quadrant items re-staged
-// its whole list, so a 16-view launch ran one whole tile per wave and ended 25 % after its average
-// wave).  Round 3: per-quadrant lists — an item stages exactly what it evaluates (0.69 iterations per
-// pair, dense batches, 4 ballots per batch instead of 16 + a log/rcp/sqrt box), four times as many,
-// four times smaller items on twice as many resident waves.
-// The kernel is bound by f32 VALU issue; per-pixel blend / skip / stop decisions stay scalar lane-mask
-// algebra (SALU) — a lane is exactly one pixel.
+// per item and derived the masks per staged entry (39 evaluations; a quarter of the staged pairs reached
+// no pixel).
+// Per-pixel blend / skip / stop decisions are scalar lane-mask algebra, one mask set per pixel of the lane.
 #include <stdio.h>
 
 #include <vector>
@@ -45,13 +47,13 @@ struct RenderFwdParams {
     int num_cus;                  // compute units
     int waves_per_cu;             // resident compositing waves per CU the launch provides
     const uint32_t *items;        // work items, costliest first
-    const uint32_t *header;       // geometry-workspace header (item count)
+    uint32_t num_items;           // items of this launch (4 per tile of the launch's view chunk)
     uint32_t *queue;              // work-queue head (zeroed per forward)
     unsigned long long *trace;    // debug builds (LSR_ENABLE_TRACE): per item {start clk, end clk, hw id, iterations << 32 | entries}
     const float *views;
     const float4 *rec;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
     int rec_f4;
-    const uint32_t *tile_start, *quad_count, *quad_list;
+    const uint32_t *tile_start, *half_count, *half_list;
     float *out_color, *out_feat, *out_mask, *out_depth;
     float *final_T;
     uint32_t *n_contrib;
@@ -63,11 +65,10 @@ struct RenderFwdParams {
 // takes items b, 2B-1-b, 2B+b, 4B-1-b, ... (B = number of bins) — pairing expensive with cheap items
 // so every SIMD starts with nearly the same total; everything beyond the first item per wave comes from
 // the queue.
-template <int NCHP, int UNR, int WPB>
+template <int NCHP, int WPB>
 __global__ void __launch_bounds__(LSR_WAVE * WPB)
 k_render_fwd(RenderFwdParams p) {
-    // Staged entries, one record per list entry: (x, y, a2, c2) (b2, log2 o, z, -1) payload...
-    // ((x, y), (a2, c2) and (z, -1) are operand pairs of the packed f32 instructions below)
+    // Staged entries, one record per list entry: (x, y, a2, c2) (b2, log2 o, z, -) payload...
     // The odd float4 stride keeps the per-lane staging stores bank-conflict free.  Slot 64 is a
     // null record (alpha == 0) that pads the sub-block lists.
     constexpr int kEnt = (2 + NCHP / 4) | 1;
@@ -76,9 +77,9 @@ k_render_fwd(RenderFwdParams p) {
     struct Lds {
         float4 ent[WPB][LSR_WAVE + 1][kEnt];
         // list[b][i] = offset of the i-th staged entry that can reach sub-block b.  Rows are 65 words apart:
-        // the four lane groups read list[b][i] for four b at the same i — with a 64-word stride that was one
-        // LDS bank for all four (the 11 % bank-conflict cycles of round 2's profile)
-        uint32_t list[WPB][4][LSR_WAVE + 1];
+        // the eight lane groups read list[b][i] for eight b at the same i — with a 64-word stride that would be
+        // one LDS bank for all of them (the 11 % bank-conflict cycles of round 2's profile)
+        uint32_t list[WPB][8][LSR_WAVE + 1];
     };
     __shared__ Lds s_lds;
 
@@ -92,19 +93,20 @@ k_render_fwd(RenderFwdParams p) {
     const uint32_t wave_off = (uint32_t)(wid * (LSR_WAVE + 1) * kEnt * 16);
     const uint32_t my_off = wave_off + (uint32_t)(lane * kEnt * 16);
     const uint32_t null_off = wave_off + (uint32_t)(LSR_WAVE * kEnt * 16);
-    if (lane < 4) s_list[lane][LSR_WAVE] = null_off;   // the rows' pad word (never a real entry)
+    if (lane < 8) s_list[lane][LSR_WAVE] = null_off;   // the rows' pad word (never a real entry)
     if (lane == 0) {
         s_ent[LSR_WAVE][0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        s_ent[LSR_WAVE][1] = make_float4(0.0f, -INFINITY, 0.0f, -1.0f);  // log2(opacity) = -inf
+        s_ent[LSR_WAVE][1] = make_float4(0.0f, -INFINITY, 0.0f, 0.0f);  // log2(opacity) = -inf
 #pragma unroll
         for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    const uint32_t num_items = p.header[kHdrNumItems];
+    const uint32_t num_items = p.num_items;
     const int coff = p.has_color ? 3 : 0;
     const size_t HW = (size_t)p.H * p.W;
-    // lane group -> sub-block of the quadrant (bit 2*row + col of the list entries' mask); lane -> pixel of the sub-block
-    const int grp = lane >> 4, gcol = grp & 1, grow = grp >> 1;
-    const int lx = lane & 3, ly = (lane >> 2) & 3;
+    // lane group -> sub-block (gcol, grow) of the half (bit 4*grow + gcol of the list entries' mask);
+    // lane -> its two pixels (lx, ly), (lx + 1, ly) of the sub-block
+    const int grp = lane >> 3, gcol = grp & 3, grow = grp >> 2;
+    const int lx = 2 * (lane & 1), ly = (lane >> 1) & 3;
 
     const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = (uint32_t)p.num_cus * (uint32_t)p.waves_per_cu;
     const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);   // 0 .. waves_per_cu - 1
@@ -133,41 +135,43 @@ k_render_fwd(RenderFwdParams p) {
 #endif
         qi = __builtin_amdgcn_readfirstlane(qi);
         const uint32_t item = p.items[qi];
-        const uint32_t vt = item & kItemTileMask, quad = item >> kItemQuadShift;
+        const uint32_t vt = item & kItemTileMask, half = item >> kItemHalfShift;
         const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
-        const int tx0 = (tile % p.gx) * LSR_TILE + 8 * (int)(quad & 1u), ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)(quad >> 1);
+        const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)half;
         const size_t vG = (size_t)v * p.G;
         const uint32_t tstart = p.tile_start[vt], tn = p.tile_start[vt + 1] - tstart;
-        const uint32_t qn = p.quad_count[4 * (size_t)vt + quad];
-        const uint32_t *qlist = p.quad_list + 4 * (size_t)tstart + (size_t)quad * tn;
+        const uint32_t hn = p.half_count[2 * (size_t)vt + half];
+        const uint32_t *hlist = p.half_list + 2 * (size_t)tstart + (size_t)half * tn;
 
-        // per-pixel state; (x, y), (depth sum, T) and the payload channels two by two are register
-        // pairs so the blend runs on packed f32 instructions
+        // per-pixel state of the lane's two pixels as register pairs (pixel 0, pixel 1): the blend runs on
+        // packed f32 instructions across the two pixels
         const int px = tx0 + 4 * gcol + lx, py = ty0 + 4 * grow + ly;
-        const float2_t pxy = float2_t{(float)px, (float)py};
-        const bool inside = px < p.W && py < p.H;
-        float2_t dT = float2_t{0.0f, 1.0f};          // (sum alpha T z, transmittance)
-        float2_t acc[NCHP / 2];
+        const float2_t pxx = float2_t{(float)px, (float)(px + 1)};
+        const float pyf = (float)py;
+        const bool inside0 = px < p.W && py < p.H, inside1 = px + 1 < p.W && py < p.H;
+        float2_t T2 = float2_t{1.0f, 1.0f};          // transmittance
+        float2_t D2 = float2_t{0.0f, 0.0f};          // sum alpha T z
+        float2_t acc[NCHP];
 #pragma unroll
-        for (int c = 0; c < NCHP / 2; ++c) acc[c] = float2_t{0.0f, 0.0f};
-        uint32_t stop_pos = 0;
-        // The per-pixel "finished" flags live in a scalar register pair as a 64-bit lane mask, so the skip /
+        for (int c = 0; c < NCHP; ++c) acc[c] = float2_t{0.0f, 0.0f};
+        uint32_t stop_pos0 = 0, stop_pos1 = 0;
+        // The per-pixel "finished" flags live in scalar register pairs as 64-bit lane masks, so the skip /
         // blend / stop decisions are SALU mask algebra instead of per-lane VALU selects.
-        uint64_t done = __ballot(!inside);
+        uint64_t done0 = __ballot(!inside0), done1 = __ballot(!inside1);
 
         // Software-pipelined staging: while batch b is composited, the records of batch b+1 and the
         // list entries of batch b+2 are already in flight (two dependent global latencies per batch
         // otherwise sit on the serial path of the wave).
         // The loads are UNCONDITIONAL at clamped positions (slots past the end re-read the last entry, which
-        // the `e < qn` tests below ignore): a load under a per-lane condition is followed by a wait for it at
+        // the `e < hn` tests below ignore): a load under a per-lane condition is followed by a wait for it at
         // the join, which put both latencies back on the serial path of every batch.
         struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t w; };
-        const uint32_t last = qn - 1u;   // only used when the list is not empty
-        auto load_ent = [&](uint32_t e) -> uint32_t { return qlist[min(e, last)]; };
+        const uint32_t last = hn - 1u;   // only used when the list is not empty
+        auto load_ent = [&](uint32_t e) -> uint32_t { return hlist[min(e, last)]; };
         auto load_rec = [&](uint32_t w) {
             StageRec r;
             r.w = w;
-            const float4 *R = p.rec + (vG + (w & kQuadIndexMask)) * (size_t)p.rec_f4;
+            const float4 *R = p.rec + (vG + (w & kListIndexMask)) * (size_t)p.rec_f4;
             r.a = R[0]; r.b = R[1];  // (x,y,A,B) (C,o,z,-)
 #pragma unroll
             for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];  // payload, zero padded
@@ -179,37 +183,36 @@ k_render_fwd(RenderFwdParams p) {
         nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
         for (int c4 = 0; c4 < NCHP / 4; ++c4) nxt.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (qn > 0) {   // wave-uniform
+        if (hn > 0) {   // wave-uniform
             w_ahead = load_ent(lane);
             nxt = load_rec(w_ahead);
             w_ahead = load_ent(LSR_WAVE + lane);
         }
 
-        for (uint32_t base = 0; base < qn; base += LSR_WAVE) {
-            if (done == ~0ull) break;
+        for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
+            if ((done0 & done1) == ~0ull) break;
 
             const StageRec cur = nxt;
             nxt = load_rec(w_ahead);
             w_ahead = load_ent(base + 2 * LSR_WAVE + lane);
             // ---- stage up to 64 list entries (one per lane) ----
-            {   // every list slot starts as the null record; the compaction below overwrites a prefix
+            // every list slot starts as the null record; the compaction below overwrites a prefix
 #pragma unroll
-                for (int b = 0; b < 4; ++b) s_list[b][lane] = null_off;
-            }
+            for (int b = 0; b < 8; ++b) s_list[b][lane] = null_off;
             const uint32_t e = base + lane;
-            const uint32_t m = e < qn ? (cur.w >> kQuadBitsShift) : 0u;   // sub-blocks of this quadrant the entry can reach (never 0 for a list entry)
+            const uint32_t m = e < hn ? (cur.w >> kListBitsShift) : 0u;   // sub-blocks of this half the entry can reach (never 0 for a list entry)
             if (m) {
                 const float4 a = cur.a, b = cur.b;
                 const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
                 s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
-                s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z, -1.0f);
+                s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z, 0.0f);
 #pragma unroll
                 for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[lane][2 + c4] = cur.pay[c4];
             }
             // compaction: per sub-block, the staged entries that can reach it, in list order
             uint32_t nk = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < 8; ++b) {
                 const uint64_t bal = __ballot((m >> b) & 1u);
                 nk = max(nk, (uint32_t)__builtin_popcountll(bal));
                 if (__builtin_amdgcn_inverse_ballot_w64(bal)) {
@@ -220,61 +223,52 @@ k_render_fwd(RenderFwdParams p) {
             nk = __builtin_amdgcn_readfirstlane(nk);
             wave_lds_fence();  // staged records and lists are visible to this wave's reads below
 
-            // Lane group g walks the list of ITS sub-block, front to back, UNR entries at a time
-            // (independent alpha evaluations; only the short transmittance chain is serial).  Shorter
-            // lists are padded with the null record.
+            // Lane group g walks the list of ITS sub-block, front to back; shorter lists are padded with the
+            // null record.  Per entry: the row terms once, then both pixels in packed arithmetic.
             const uint32_t *lp = &s_list[grp][0];
 #ifdef LSR_ENABLE_TRACE
             trace_iters += nk;
 #endif
-            for (uint32_t i = 0; i < nk; i += UNR) {
-                float4 a[UNR], b[UNR];
-                float2_t pay[UNR][NCHP / 2];
-                uint32_t off[UNR];
+            for (uint32_t i = 0; i < nk; ++i) {
+                const uint32_t off = lp[i];
+                const float4 *E = (const float4 *)(ent_base + off);
+                const float4 a = E[0], b = E[1];
+                float pay[NCHP];
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    off[u] = lp[i + u];      // (i + u can be nk: the row's 65th word / the padding, a null record either way)
-                    const float4 *E = (const float4 *)(ent_base + off[u]);
-                    a[u] = E[0]; b[u] = E[1];
-#pragma unroll
-                    for (int c4 = 0; c4 < NCHP / 4; ++c4) {
-                        const float4 t = E[2 + c4];
-                        pay[u][2 * c4] = float2_t{t.x, t.y}; pay[u][2 * c4 + 1] = float2_t{t.z, t.w};
-                    }
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) {
+                    const float4 t = E[2 + c4];
+                    pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
                 }
-                float alpha[UNR];
-                uint64_t ok[UNR];
+                // exponent e(dx) = dx (a2 dx + b2 dy) + (c2 dy^2 + log2 o) for dx = dx0, dx0 - 1 (the backward
+                // performs the identical sequence: both passes must make bit-identical alpha decisions)
+                const float2_t d2 = float2_t{a.x, a.x} - pxx;
+                const float dy = a.y - pyf;
+                const float t = b.x * dy;
+                const float s = __builtin_fmaf(a.w * dy, dy, b.y);
+                const float2_t p1 = __builtin_elementwise_fma(float2_t{a.z, a.z}, d2, float2_t{t, t});
+                const float2_t ex = __builtin_elementwise_fma(p1, d2, float2_t{s, s});
+                const float al0 = fminf(LSR_ALPHA_MAX, fast_exp2(ex.x)), al1 = fminf(LSR_ALPHA_MAX, fast_exp2(ex.y));
+                // skip if power > 0 or alpha < 1/255 (NaN-safe: comparisons are "keep" tests)
+                const uint64_t ok0 = __ballot(ex.x <= b.y) & __ballot(al0 >= LSR_ALPHA_MIN);
+                const uint64_t ok1 = __ballot(ex.y <= b.y) & __ballot(al1 >= LSR_ALPHA_MIN);
+                const float2_t aT = float2_t{al0, al1} * T2;
+                const float2_t tT = T2 - aT;
+                const uint64_t live0 = ok0 & ~done0, live1 = ok1 & ~done1;
+                const uint64_t room0 = __ballot(tT.x >= LSR_T_EPS), room1 = __ballot(tT.y >= LSR_T_EPS);
+                const uint64_t stop0 = live0 & ~room0, stop1 = live1 & ~room1;
+                const float w0 = __builtin_amdgcn_inverse_ballot_w64(live0 & room0) ? aT.x : 0.0f;
+                const float w1 = __builtin_amdgcn_inverse_ballot_w64(live1 & room1) ? aT.y : 0.0f;
+                const float2_t ww = float2_t{w0, w1};
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    // same operations as blend_exponent (lsr_blend.h), two of them packed
-                    const float2_t d = float2_t{a[u].x, a[u].y} - pxy;
-                    const float2_t q = float2_t{a[u].z, a[u].w} * d;              // (a2 dx, c2 dy)
-                    const float p1 = __builtin_fmaf(b[u].x, d.y, q.x);
-                    const float p2 = __builtin_fmaf(q.y, d.y, b[u].y);
-                    const float ex = __builtin_fmaf(p1, d.x, p2);
-                    alpha[u] = fminf(LSR_ALPHA_MAX, fast_exp2(ex));
-                    // skip if power > 0 or alpha < 1/255 (NaN-safe: comparisons are "keep" tests)
-                    ok[u] = __ballot(ex <= b[u].y) & __ballot(alpha[u] >= LSR_ALPHA_MIN);
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const float aT = alpha[u] * dT.y;
-                    const float tT = dT.y - aT;
-                    const uint64_t live = ok[u] & ~done;
-                    const uint64_t room = __ballot(tT >= LSR_T_EPS);
-                    const uint64_t blend = live & room, stop = live & ~room;
-                    const float w = __builtin_amdgcn_inverse_ballot_w64(blend) ? aT : 0.0f;
-                    const float2_t ww = float2_t{w, w};
-#pragma unroll
-                    for (int c = 0; c < NCHP / 2; ++c) acc[c] = __builtin_elementwise_fma(pay[u][c], ww, acc[c]);
-                    // (depth sum, T) += w * (z, -1)
-                    dT = __builtin_elementwise_fma(float2_t{b[u].z, b[u].w}, ww, dT);
-                    if (stop) {  // rare, wave-uniform: a pixel's transmittance ran out here
-                        // 1-based list position of the stopping entry, from its staging slot
-                        const uint32_t pos = base + 1u + (off[u] - wave_off) / (uint32_t)(kEnt * 16);
-                        stop_pos = __builtin_amdgcn_inverse_ballot_w64(stop) ? pos : stop_pos;
-                        done |= stop;
-                    }
+                for (int c = 0; c < NCHP; ++c) acc[c] = __builtin_elementwise_fma(float2_t{pay[c], pay[c]}, ww, acc[c]);
+                D2 = __builtin_elementwise_fma(float2_t{b.z, b.z}, ww, D2);
+                T2 = T2 - ww;
+                if (stop0 | stop1) {  // rare, wave-uniform: a pixel's transmittance ran out here
+                    // 1-based list position of the stopping entry, from its staging slot
+                    const uint32_t pos = base + 1u + (off - wave_off) / (uint32_t)(kEnt * 16);
+                    stop_pos0 = __builtin_amdgcn_inverse_ballot_w64(stop0) ? pos : stop_pos0;
+                    stop_pos1 = __builtin_amdgcn_inverse_ballot_w64(stop1) ? pos : stop_pos1;
+                    done0 |= stop0; done1 |= stop1;
                 }
             }
             wave_lds_fence();  // WAR on the LDS slice before the next batch is staged
@@ -284,25 +278,28 @@ k_render_fwd(RenderFwdParams p) {
         // earlier launch) — as plain loads these were three waited-for vector loads per pixel row
         typedef const float __attribute__((address_space(4))) *kfloat_ptr;
         const kfloat_ptr vw = (kfloat_ptr)(p.views + (size_t)v * LSR_VIEW_FLOATS);
-        if (inside) {
-            const size_t pix = (size_t)py * p.W + (size_t)px;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!(k ? inside1 : inside0)) continue;
+            const size_t pix = (size_t)py * p.W + (size_t)(px + k);
             const size_t vp = (size_t)v * HW + pix;
-            const float Tk = dT.y;
+            const float Tk = T2[k];
+            const uint32_t sp = k ? stop_pos1 : stop_pos0;
             p.final_T[vp] = Tk;
-            // number of leading entries of the QUADRANT's render list the backward pass has to consider for
+            // number of leading entries of the HALF's render list the backward pass has to consider for
             // this pixel: all of them, or everything before the entry at which the transmittance test stopped it
-            p.n_contrib[vp] = stop_pos ? stop_pos - 1u : qn;
+            p.n_contrib[vp] = sp ? sp - 1u : hn;
             p.out_mask[vp] = 1.0f - Tk;
-            p.out_depth[vp] = dT.x;
+            p.out_depth[vp] = D2[k];
             if (p.has_color) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(Tk, vw[37 + c], acc[c / 2][c & 1]);
+                    p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(Tk, vw[37 + c], acc[c][k]);
             }
 #pragma unroll
             for (int c = 0; c < NCHP; ++c)
                 if (c >= coff && c - coff < p.C)
-                    p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[c / 2][c & 1];
+                    p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[c][k];
         }
 #ifdef LSR_ENABLE_TRACE
         if (p.trace && lane == 0) {
@@ -312,7 +309,7 @@ k_render_fwd(RenderFwdParams p) {
             p.trace[4 * (size_t)qi + 0] = t_begin;
             p.trace[4 * (size_t)qi + 1] = __builtin_readcyclecounter();
             p.trace[4 * (size_t)qi + 2] = ((unsigned long long)xcc << 32) | hwid;
-            p.trace[4 * (size_t)qi + 3] = ((unsigned long long)trace_iters << 32) | qn;
+            p.trace[4 * (size_t)qi + 3] = ((unsigned long long)trace_iters << 32) | hn;
         }
 #endif
     }  // persistent item loop
@@ -320,7 +317,7 @@ k_render_fwd(RenderFwdParams p) {
 
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                  const char *bin, int64_t num_pairs, char *img, const lsr_outputs &out,
-                                 hipStream_t s) {
+                                 hipStream_t s, ViewChunk vc) {
     const GeomLayout L = geom_layout(d);
     const ImgLayout I = img_layout(d);
     const BinLayout B = bin_layout(d, num_pairs, 0);
@@ -328,14 +325,15 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.H = d.height; p.W = d.width; p.gx = tiles_x(d); p.T = (int)num_tiles(d); p.G = d.num_gaussians;
     p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE;
     p.num_cus = device_cus();
-    p.items = (const uint32_t *)(geom + L.tile_order);
-    p.header = (const uint32_t *)(geom + L.header);
-    p.queue = (uint32_t *)(geom + L.header) + kHdrQueueFwd;
+    // the chunk's own costliest-first item list (k_tile_scan) and queue word
+    p.items = (const uint32_t *)(geom + L.tile_order) + 2 * (size_t)vc.view0 * (size_t)p.T;
+    p.num_items = 2u * (uint32_t)vc.num_views * (uint32_t)p.T;
+    p.queue = (uint32_t *)(geom + L.header) + kHdrQueueFwd + vc.index;
     p.views = in.views;
     p.rec = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
     p.tile_start = (const uint32_t *)(geom + L.tile_start);
-    p.quad_count = (const uint32_t *)(geom + L.quad_count);
-    p.quad_list = (const uint32_t *)(bin + B.quad_list);
+    p.half_count = (const uint32_t *)(geom + L.half_count);
+    p.half_list = (const uint32_t *)(bin + B.half_list);
     p.out_color = out.color; p.out_feat = out.feature; p.out_mask = out.mask; p.out_depth = out.depth;
     p.final_T = (float *)(img + I.final_T); p.n_contrib = (uint32_t *)(img + I.n_contrib);
     const int nch = (p.has_color ? 3 : 0) + d.feat_channels;
@@ -343,7 +341,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
 
     p.trace = nullptr;
 #ifdef LSR_ENABLE_TRACE
-    const int64_t max_items = 4 * (int64_t)p.T * d.num_views;
+    const int64_t max_items = 2 * (int64_t)p.T * vc.num_views;
     const char *trace_path = getenv("LSR_TRACE");
     if (trace_path) {
         (void)hipMalloc((void **)&p.trace, (size_t)max_items * 32);
@@ -351,18 +349,18 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     }
 #endif
     prof_begin(kStRenderFwd, s);
-    // WPC = resident waves per CU = (workgroups per CU) x WPB: as many as registers (UNR) and LDS slices allow.
+    // WPC = resident waves per CU = (workgroups per CU) x WPB: as many as registers and LDS slices allow.
     // LSR_FWD_VARIANT (development knob, read once) selects the alternatives measured in DESIGN.md.
-#define LSR_RF(N, U, WPB, WPC)                                                                             \
+#define LSR_RF(N, WPB, WPC)                                                                                \
     do {                                                                                                   \
         p.waves_per_cu = (WPC);                                                                            \
-        hipLaunchKernelGGL((k_render_fwd<N, U, WPB>), dim3(p.num_cus * ((WPC) / (WPB))), dim3(LSR_WAVE * WPB), 0, s, p); \
+        hipLaunchKernelGGL((k_render_fwd<N, WPB>), dim3(p.num_cus * ((WPC) / (WPB))), dim3(LSR_WAVE * WPB), 0, s, p); \
     } while (0)
     const int variant = env_int("LSR_FWD_VARIANT", 0);
-    if (nchp == 4) { if (variant == 1) LSR_RF(4, 2, 12, 24); else if (variant == 2) LSR_RF(4, 2, 16, 16); else LSR_RF(4, 1, 16, 32); }
-    else if (nchp == 8) { if (variant == 2) LSR_RF(8, 2, 16, 16); else LSR_RF(8, 1, 12, 24); }   // 2 x 12 waves: what the LDS slices allow
-    else if (nchp == 12) LSR_RF(12, 1, 16, 16);
-    else LSR_RF(36, 1, 4, 16);
+    if (nchp == 4) { if (variant == 1) LSR_RF(4, 12, 24); else LSR_RF(4, 16, 16); }
+    else if (nchp == 8) LSR_RF(8, 16, 16);
+    else if (nchp == 12) LSR_RF(12, 12, 12);
+    else LSR_RF(36, 4, 8);
 #undef LSR_RF
     prof_end(kStRenderFwd, s);
 #ifdef LSR_ENABLE_TRACE

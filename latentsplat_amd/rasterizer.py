@@ -234,10 +234,17 @@ class _RasterizeViews(torch.autograd.Function):
                 _lib.check(lib.lsr_forward_prepare(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii),
                                                    C.byref(npairs), C.byref(maxtile), stream),
                            "lsr_forward_prepare")
-                binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), npairs.value, maxtile.value), **u8)
-                _lib.check(lib.lsr_forward_render(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img),
-                                                  npairs.value, maxtile.value, C.byref(outs), stream),
-                           "lsr_forward_render")
+                try:
+                    # the largest pair-count dependent allocation (the likeliest out-of-memory site of a forward)
+                    binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), npairs.value, maxtile.value), **u8)
+                    _lib.check(lib.lsr_forward_render(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img),
+                                                      npairs.value, maxtile.value, C.byref(outs), stream),
+                               "lsr_forward_render")
+                except BaseException:
+                    # prepare() left the SH payload pass on the library's side stream, still writing `geom`: the
+                    # current stream has to wait for it before the caching allocator may hand these blocks out again
+                    lib.lsr_forward_abandon(stream)
+                    raise
             if debug:
                 torch.cuda.synchronize(dev)
         plan = _Plan()
@@ -251,7 +258,11 @@ class _RasterizeViews(torch.autograd.Function):
         # a no-sync forward keeps its (caller-requested) plan alive so the header can be read back later
         global _LAST_PLAN, _LAST_STATUS
         if pair_capacity > 0:
-            _LAST_PLAN, _LAST_STATUS = plan, None
+            # only what lsr_forward_status reads: the dims and the geometry workspace (its header); the capacity
+            # sized binning workspace and the image workspace stay owned by the autograd graph alone
+            keep = _Plan()
+            keep.dims, keep.geom = d, geom
+            _LAST_PLAN, _LAST_STATUS = keep, None
         else:
             _LAST_PLAN, _LAST_STATUS = None, dict(num_pairs=npairs.value, max_tile_pairs=maxtile.value, overflow=False)
         ctx.debug = debug

@@ -173,6 +173,62 @@ print("HASH", h.hexdigest())
     assert digests["1"].startswith("HASH ") and digests["1"] == digests["0"], digests
 
 
+def test_view_chunk_pipeline_does_not_change_results(hip_device):
+    """A forward over V views runs its binning + compositing as K chunks of views, the binning of chunk c + 1
+    on the library's side stream beside the compositing of chunk c (lsr_internal.h view chunks).  K only
+    changes WHEN kernels run: images, the per-pixel workspaces the backward reads and the gradients must be
+    bitwise identical for K = 1, 2, 4 (LSR_PIPE_CHUNKS is read once per process, hence subprocesses), in the
+    synchronous and the no-sync forward, under back-to-back calls (forks / joins of successive calls interleave
+    on the side stream) and inside a captured hipGraph."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, hashlib
+os.environ["LSR_DETERMINISTIC"] = "1"      # order-independent backward sums: gradients comparable bit for bit
+sys.path.insert(0, %r)
+from tests.test_latency_gpu import _inputs
+from latentsplat_amd.rasterizer import rasterize_views
+dev = torch.device("cuda:0")
+bi, views, t, size = _inputs(dev, G=30000, V=8, size=96, sh=2)
+h = hashlib.sha1()
+def call(**kw):
+    leaves = [t[k].clone().requires_grad_(True) for k in ("means", "cov6", "opac", "shs", "features")]
+    out = rasterize_views(views, size, size, 2, leaves[0], leaves[1], leaves[2], shs=leaves[3], features=leaves[4], **kw)
+    return out, leaves
+for kw in ({}, dict(pair_capacity=600000, max_tile_hint=2048)):
+    for _ in range(3):
+        out, leaves = call(**kw)
+    (out[0].sum() * 0.5 + (out[1] * out[1]).sum() + out[2].sum() + out[3].sum()).backward()
+    for o in list(out[:4]) + [l.grad for l in leaves]:
+        h.update(o.detach().cpu().numpy().tobytes())
+# the no-sync launch sequence (side-stream fork / join included) captured once and replayed
+with torch.no_grad():
+    kw = dict(pair_capacity=600000, max_tile_hint=2048)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        rasterize_views(views, size, size, 2, t["means"], t["cov6"], t["opac"], shs=t["shs"], features=t["features"], **kw)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        gout = rasterize_views(views, size, size, 2, t["means"], t["cov6"], t["opac"], shs=t["shs"], features=t["features"], **kw)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for o in gout[:4]:
+        h.update(o.cpu().numpy().tobytes())
+print("HASH", h.hexdigest())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for chunks in ("1", "2", "4"):
+        env = dict(os.environ, LSR_PIPE_CHUNKS=chunks)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[chunks] = r.stdout.strip().splitlines()[-1]
+    assert digests["1"].startswith("HASH ") and digests["1"] == digests["2"] == digests["4"], digests
+
+
 def test_early_pair_count_equals_the_device_header(hip_device):
     """The synchronous forward hands the pair count to the host from the LAST workgroup of k_preprocess
     (while k_tile_scan is still running); the authoritative numbers are the ones k_tile_scan leaves in the

@@ -103,16 +103,16 @@ def _box_masks(xy, co, lst, tx0, ty0):
 
 
 @pytest.mark.parametrize("name", ["feat4", "ragged_image", "big_splats"])
-def test_quadrant_render_lists(hip_device, name):
-    """The per-quadrant render lists the compositing kernels walk (k_sort_tiles, ABI v6 layout) against the
-    canonical, bit-exact tile lists: every quadrant list is an order-preserving sub-list of its tile's
+def test_half_tile_render_lists(hip_device, name):
+    """The per-half render lists the compositing kernels walk (k_sort_tiles, ABI v6 layout) against the
+    canonical, bit-exact tile lists: every half list is an order-preserving sub-list of its tile's
     canonical list; LOSSLESS — an entry that reaches alpha >= 1/255 on any pixel of a 4x4 sub-block (dense
-    float64 evaluation) is in that quadrant's list with the sub-block's bit set; and tight — the listed
+    float64 evaluation) is in that half's list with the sub-block's bit set; and tight — the listed
     (entry, sub-block) pairs are those of the footprint box (+ at most 2 % from float rounding)."""
     sc, H, W = _scene(CASES[name])
     bi = util.boundary_inputs(sc, H, W)
     run = util.HipRun(bi, hip_device)
-    ts, pl, qc, ql, T = run.tile_start(), run.point_list(), run.quad_count(), run.quad_list(), run.T
+    ts, pl, hc, hl, T = run.tile_start(), run.point_list(), run.half_count(), run.half_list(), run.T
     gx = (W + 15) // 16
     listed = boxed = 0
     for v in range(bi["V"]):
@@ -123,18 +123,17 @@ def test_quadrant_render_lists(hip_device, name):
             n = s1 - s0
             canon = pl[s0:s1]
             ty, tx = divmod(t, gx)
-            got = np.zeros(n, np.int64)            # 16-bit sub-block masks reassembled from the four lists
+            got = np.zeros(n, np.int64)            # 16-bit sub-block masks reassembled from the two lists
             pos = {int(g): i for i, g in enumerate(canon)}
-            for q in range(4):
-                cnt = qc[v * T + t, q]
+            for h in range(2):
+                cnt = hc[v * T + t, h]
                 assert 0 <= cnt <= n
-                words = ql[4 * s0 + q * n: 4 * s0 + q * n + cnt]
-                idx, bits = (words & 0x0FFFFFFF).astype(np.int64), (words >> 28).astype(np.int64)
+                words = hl[2 * s0 + h * n: 2 * s0 + h * n + cnt]
+                idx, bits = (words & 0x00FFFFFF).astype(np.int64), (words >> 24).astype(np.int64)
                 where = np.array([pos[int(g)] for g in idx], np.int64)
-                assert (np.diff(where) > 0).all(), "quadrant list is not an ordered sub-list of the canonical list"
+                assert (np.diff(where) > 0).all(), "half list is not an ordered sub-list of the canonical list"
                 assert (bits != 0).all(), "list entry without a reachable sub-block"
-                q0 = 8 * (q >> 1) + 2 * (q & 1)
-                got[where] |= ((bits & 3) << q0) | (((bits >> 2) & 3) << (q0 + 4))
+                got[where] |= bits << (8 * h)
             if n == 0:
                 continue
             # dense truth: alpha >= 1/255 (and power <= 0) anywhere in the sub-block

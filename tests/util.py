@@ -148,23 +148,23 @@ class HipRun:
             self.d.num_views, -1, rf)
         return r[:, :, 0:4], r[:, :, 4:8]
 
-    def quad_count(self):
-        """(V*T, 4) lengths of the quadrant render lists."""
-        n = self.d.num_views * self.T * 4
-        return self._view(self.geom, self.layout.geom_quad_count, n * 4, torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 4)
+    def half_count(self):
+        """(V*T, 2) lengths of the half-tile render lists."""
+        n = self.d.num_views * self.T * 2
+        return self._view(self.geom, self.layout.geom_half_count, n * 4, torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 2)
 
-    def quad_list(self):
-        """Raw quadrant-list area: [4P] words `index | sub-block bits << 28` (tile with canonical list [s, s+n)
-        owns [4s, 4s+4n), quadrant q at 4s + q*n)."""
-        return self._view(self.bin, self.layout.bin_quad_list, max(self.P, 0) * 16, torch.int32).cpu().numpy().view(np.uint32)
+    def half_list(self):
+        """Raw half-list area: [2P] words `index | sub-block bits << 24` (tile with canonical list [s, s+n)
+        owns [2s, 2s+2n), half h at 2s + h*n)."""
+        return self._view(self.bin, self.layout.bin_half_list, max(self.P, 0) * 8, torch.int32).cpu().numpy().view(np.uint32)
 
     def n_considered(self):
-        """n_contrib translated from positions in the QUADRANT render lists (what the kernels keep) to
+        """n_contrib translated from positions in the HALF-TILE render lists (what the kernels keep) to
         positions in the canonical tile lists (what the published algorithm / the oracle keeps): a pixel
-        that considered all of its quadrant's list considered the whole tile list; otherwise it stopped
+        that considered all of its half's list considered the whole tile list; otherwise it stopped
         at a specific entry, whose canonical position is looked up."""
         nc = self.n_contrib()
-        ts, pl, qc, ql = self.tile_start(), self.point_list(), self.quad_count(), self.quad_list()
+        ts, pl, hc, hl = self.tile_start(), self.point_list(), self.half_count(), self.half_list()
         V, H, W, T = self.d.num_views, self.d.height, self.d.width, self.T
         gx = (W + 15) // 16
         out = np.zeros_like(nc)
@@ -174,19 +174,21 @@ class HipRun:
                 n = s1 - s0
                 ty, tx = divmod(t, gx)
                 canon = pl[s0:s1]
-                for q in range(4):
-                    y0, x0 = ty * 16 + 8 * (q >> 1), tx * 16 + 8 * (q & 1)
-                    if y0 >= H or x0 >= W:
+                pos = None
+                for h in range(2):
+                    y0, x0 = ty * 16 + 8 * h, tx * 16
+                    if y0 >= H:
                         continue
-                    blk = nc[v, y0:y0 + 8, x0:x0 + 8]
-                    cnt = qc[v * T + t, q]
-                    lst = ql[4 * s0 + q * n: 4 * s0 + q * n + cnt] & 0x0FFFFFFF
+                    blk = nc[v, y0:y0 + 8, x0:x0 + 16]
+                    cnt = hc[v * T + t, h]
+                    lst = hl[2 * s0 + h * n: 2 * s0 + h * n + cnt] & 0x00FFFFFF
                     res = np.full(blk.shape, n, np.int64)
                     stopped = blk < cnt
                     if stopped.any():
-                        pos = {int(g): i for i, g in enumerate(canon)}
+                        if pos is None:
+                            pos = {int(g): i for i, g in enumerate(canon)}
                         res[stopped] = [pos[int(lst[k])] for k in blk[stopped]]
-                    out[v, y0:y0 + 8, x0:x0 + 8] = res
+                    out[v, y0:y0 + 8, x0:x0 + 16] = res
         return out
 
     def n_contrib(self):
