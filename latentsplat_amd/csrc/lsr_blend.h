@@ -17,15 +17,23 @@ namespace lsr {
 
 constexpr float kLog2e = 1.4426950408889634f;
 
-// alpha_raw = opacity * exp(power), power = -0.5 (A dx^2 + C dy^2) - B dx dy, evaluated as
-// exp2(e) with e = a2 dx^2 + b2 dx dy + c2 dy^2 + log2(opacity), (a2,b2,c2) = log2(e)*(-A/2,-B,-C/2).
-__device__ __forceinline__ float blend_exponent(float dx, float dy, float a2, float b2, float c2, float l2o) {
-    float p1 = a2 * dx;
-    p1 = __builtin_fmaf(b2, dy, p1);
-    float p2 = c2 * dy;
-    p2 = __builtin_fmaf(p2, dy, l2o);
-    return __builtin_fmaf(p1, dx, p2);
-}
+// ---- per-(pixel, Gaussian) blending arithmetic --------------------------------------------------------
+// alpha_raw = opacity * exp(power), power = -0.5 (A dx^2 + C dy^2) - B dx dy.  The kernels work in the
+// exponent domain, shifted so that the alpha >= 1/255 threshold sits at zero:
+//   e' = a2 dx^2 + b2 dx dy + c2 dy^2 + l2o',   (a2,b2,c2) = log2(e) * (-A/2, -B, -C/2),   l2o' = log2(255 opacity)
+//   255 alpha_raw = exp2(e')
+// and the two skip tests of the published algorithm become ONE unsigned integer comparison of float bits
+//   keep  <=>  bits(e') <= bits(l2o')      (0 <= e': alpha >= 1/255;  e' <= l2o': power <= 0;  NaN and negative e' have larger bits)
+// (l2o' >= 0 for every list entry: Gaussians with opacity < 1/255 reach no pixel and are never listed).
+// Everything downstream stays in units of 255 alpha: staged payloads and depths carry the factor 1/255, the
+// transmittance update is T -= w' / 255.  Evaluated per lane for two horizontally adjacent pixels:
+//   e'(dx) = dx (a2 dx + b2 dy) + (c2 dy^2 + l2o'),   dx = dx0, dx0 - 1
+// with the row terms (dy, b2 dy, c2 dy^2 + l2o') shared.  The forward and the backward perform the identical
+// operation sequence: both must make bit-identical keep / skip decisions.
+constexpr float kLog2_255 = 7.994353436858858f;
+constexpr float kInv255 = 1.0f / 255.0f;
+constexpr float kAlphaMax255 = LSR_ALPHA_MAX * 255.0f;
+
 __device__ __forceinline__ float fast_exp2(float e) { return __builtin_amdgcn_exp2f(e); }
 
 struct FoldedConic { float a2, b2, c2, l2o; };
@@ -34,7 +42,7 @@ __device__ __forceinline__ FoldedConic fold_conic(float A, float B, float C, flo
     f.a2 = (-0.5f * kLog2e) * A;
     f.b2 = (-kLog2e) * B;
     f.c2 = (-0.5f * kLog2e) * C;
-    f.l2o = __log2f(o);
+    f.l2o = __log2f(o) + kLog2_255;      // log2(255 o)
     return f;
 }
 

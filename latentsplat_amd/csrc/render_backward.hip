@@ -11,8 +11,9 @@
 // matters when the remaining contribution is already ~1e-7 of the pixel's total — far below the
 // 1e-4 tolerance.
 //
-// Per (entry, pixel) the kernel recomputes alpha with the forward's exact arithmetic and emits the
-// MOMENTS of u = exp2(e) * dL/dalpha (= opacity * G * dL/dalpha) over the entry's pixels:
+// Per (entry, pixel) the kernel recomputes alpha with the forward's exact arithmetic (exponent domain, units of
+// 255 alpha: lsr_blend.h) and emits the
+// MOMENTS of u = opacity * G * dL/dalpha over the entry's pixels:
 //   m0 = sum u,   m1 = sum u (dx, dy),   m2 = sum u (dx^2, dx dy, dy^2),
 // plus w * g per payload channel and w * g_depth.  The conic / opacity factors that turn moments
 // into dL/d(x, y), dL/d(A, B, C), dL/d opacity are applied ONCE per (view, Gaussian) by
@@ -141,7 +142,7 @@ k_render_bwd(RenderBwdParams p) {
     {   // null record + cleared gradient table (rows are re-zeroed by the flush)
         if (lane == 0) {
             s_ent[LSR_WAVE][0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            s_ent[LSR_WAVE][1] = make_float4(0.0f, -INFINITY, 0.0f, __uint_as_float(0xFFFFFFFFu));  // log2(opacity) = -inf, position beyond every list
+            s_ent[LSR_WAVE][1] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));  // position beyond every list: never valid
 #pragma unroll
             for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
@@ -238,12 +239,13 @@ k_render_bwd(RenderBwdParams p) {
             float2_b r0 = float2_b{0.0f, 0.0f};
 #pragma unroll
             for (int c = 0; c < NCHP; ++c) {
-                dpix[c] = gl[c] * inm;
-                r0 = __builtin_elementwise_fma(fl[c], dpix[c], r0);     // channels that are not rendered hold zeros
+                const float2_b g = gl[c] * inm;
+                r0 = __builtin_elementwise_fma(fl[c], g, r0);     // channels that are not rendered hold zeros
+                dpix[c] = g * kInv255;                            // the loop works in units of 255 alpha (lsr_blend.h)
             }
             r0 = __builtin_elementwise_fma(-Tfin, gmask * inm, r0);  // mask = 1 - T_final
-            ddep2 = DEPTH_GRAD ? gdep * inm : float2_b{0.0f, 0.0f};
-            if (DEPTH_GRAD) r0 = __builtin_elementwise_fma(fdep, ddep2, r0);
+            if (DEPTH_GRAD) r0 = __builtin_elementwise_fma(fdep, gdep * inm, r0);
+            ddep2 = DEPTH_GRAD ? gdep * inm * kInv255 : float2_b{0.0f, 0.0f};
             R2 = r0;
         }
         // wave-uniform upper bound of the list entries any pixel has to consider
@@ -353,32 +355,33 @@ k_render_bwd(RenderBwdParams p) {
                 for (int c4 = 0; c4 < NCHP / 4; ++c4) {
                     pay[4 * c4] = t4[c4].x; pay[4 * c4 + 1] = t4[c4].y; pay[4 * c4 + 2] = t4[c4].z; pay[4 * c4 + 3] = t4[c4].w;
                 }
-                // the forward's exponent, operation for operation (both pixels packed)
+                // the forward's exponent e' and keep test, operation for operation (both pixels packed; lsr_blend.h)
                 const float2_b d2 = float2_b{a.x, a.x} - pxx;
                 const float dy = a.y - pyf;
                 const float tt = b.x * dy;
                 const float ss = __builtin_fmaf(a.w * dy, dy, b.y);
                 const float2_b p1 = __builtin_elementwise_fma(float2_b{a.z, a.z}, d2, float2_b{tt, tt});
                 const float2_b ex = __builtin_elementwise_fma(p1, d2, float2_b{ss, ss});
-                const float ar0 = fast_exp2(ex.x), ar1 = fast_exp2(ex.y);
-                const float ac0 = fminf(LSR_ALPHA_MAX, ar0), ac1 = fminf(LSR_ALPHA_MAX, ar1);
-                const uint32_t pos = __float_as_uint(b.w);
-                const bool valid0 = (pos <= last0) & (ex.x <= b.y) & (ac0 >= LSR_ALPHA_MIN);
-                const bool valid1 = (pos <= last1) & (ex.y <= b.y) & (ac1 >= LSR_ALPHA_MIN);
-                const float2_b alpha = float2_b{valid0 ? ac0 : 0.0f, valid1 ? ac1 : 0.0f};
-                const float2_b av = float2_b{valid0 ? ar0 : 0.0f, valid1 ? ar1 : 0.0f};   // opacity * exp(power)
-                const float2_b om = float2_b{1.0f, 1.0f} - alpha;
+                const float er0 = fast_exp2(ex.x), er1 = fast_exp2(ex.y);                     // 255 opacity exp(power)
+                const float ec0 = fminf(kAlphaMax255, er0), ec1 = fminf(kAlphaMax255, er1);   // 255 alpha
+                const uint32_t pos = __float_as_uint(b.w), lim = __float_as_uint(b.y);
+                const bool valid0 = (pos <= last0) & (__float_as_uint(ex.x) <= lim);
+                const bool valid1 = (pos <= last1) & (__float_as_uint(ex.y) <= lim);
+                const float2_b al = float2_b{valid0 ? ec0 : 0.0f, valid1 ? ec1 : 0.0f};      // 255 alpha (0: skipped)
+                const float2_b av = float2_b{valid0 ? er0 : 0.0f, valid1 ? er1 : 0.0f};      // 255 opacity exp(power)
+                const float2_b om = float2_b{255.0f, 255.0f} - al;                           // 255 (1 - alpha)
                 const float2_b rcp1m = float2_b{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
                 const float2_b Tk = T2;                          // transmittance in front of this entry
-                const float2_b w = alpha * Tk;
-                float2_b dsum = float2_b{pay[0], pay[0]} * dpix[0];   // g . c_i at the two pixels
+                const float2_b w = al * Tk;                      // 255 alpha T
+                float2_b dsum = float2_b{pay[0], pay[0]} * dpix[0];   // (g . c_i) / 255 at the two pixels
 #pragma unroll
                 for (int c = 1; c < NCHP; ++c) dsum = __builtin_elementwise_fma(float2_b{pay[c], pay[c]}, dpix[c], dsum);
                 if (DEPTH_GRAD) dsum = __builtin_elementwise_fma(float2_b{b.z, b.z}, ddep2, dsum);
                 R2 = __builtin_elementwise_fma(-w, dsum, R2);    // what is left behind this entry
-                T2 = Tk * om;
+                T2 = __builtin_elementwise_fma(w, float2_b{-kInv255, -kInv255}, Tk);
+                // dL/dalpha / 255 = T (g . c) / 255 - R / (255 (1 - alpha))
                 const float2_b dL_dalpha = __builtin_elementwise_fma(Tk, dsum, -(R2 * rcp1m));
-                const float2_b u = av * dL_dalpha;               // straight through the 0.99 clamp (A.6)
+                const float2_b u = av * dL_dalpha;               // opacity exp(power) dL/dalpha: straight through the 0.99 clamp (A.6)
                 // moments of u over the lane's two pixels (same dy): sum u (dx, dy), u (dx^2, dx dy, dy^2), u
                 const float2_b ud = u * d2;
                 const float2_b udd = ud * d2;

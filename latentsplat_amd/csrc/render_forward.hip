@@ -68,9 +68,9 @@ struct RenderFwdParams {
 template <int NCHP, int WPB>
 __global__ void __launch_bounds__(LSR_WAVE * WPB)
 k_render_fwd(RenderFwdParams p) {
-    // Staged entries, one record per list entry: (x, y, a2, c2) (b2, log2 o, z, -) payload...
-    // The odd float4 stride keeps the per-lane staging stores bank-conflict free.  Slot 64 is a
-    // null record (alpha == 0) that pads the sub-block lists.
+    // Staged entries, one record per list entry: (x, y, a2, c2) (b2, log2(255 o), z / 255, -1 / 255) payload / 255 ...
+    // (lsr_blend.h: the loop works in units of 255 alpha).  The odd float4 stride keeps the per-lane staging
+    // stores bank-conflict free.  Slot 64 is a null record (x = NaN: never kept) that pads the sub-block lists.
     constexpr int kEnt = (2 + NCHP / 4) | 1;
     // One shared object, entries first: the byte offsets kept in the lists are then plain LDS
     // addresses (base 0 folds into the ds_read immediate, no address arithmetic per entry).
@@ -95,8 +95,8 @@ k_render_fwd(RenderFwdParams p) {
     const uint32_t null_off = wave_off + (uint32_t)(LSR_WAVE * kEnt * 16);
     if (lane < 8) s_list[lane][LSR_WAVE] = null_off;   // the rows' pad word (never a real entry)
     if (lane == 0) {
-        s_ent[LSR_WAVE][0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        s_ent[LSR_WAVE][1] = make_float4(0.0f, -INFINITY, 0.0f, 0.0f);  // log2(opacity) = -inf
+        s_ent[LSR_WAVE][0] = make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);     // e' = NaN fails the keep test
+        s_ent[LSR_WAVE][1] = make_float4(0.0f, 0.0f, 0.0f, -kInv255);
 #pragma unroll
         for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
@@ -146,17 +146,18 @@ k_render_fwd(RenderFwdParams p) {
         // per-pixel state of the lane's two pixels as register pairs (pixel 0, pixel 1): the blend runs on
         // packed f32 instructions across the two pixels
         const int px = tx0 + 4 * gcol + lx, py = ty0 + 4 * grow + ly;
-        const float2_t pxx = float2_t{(float)px, (float)(px + 1)};
-        const float pyf = (float)py;
         const bool inside0 = px < p.W && py < p.H, inside1 = px + 1 < p.W && py < p.H;
+        // a finished (or outside) pixel gets x = NaN: its exponent is NaN and fails the keep test from then on, so
+        // the loop needs no "done" masks
+        float2_t pxx = float2_t{inside0 ? (float)px : __builtin_nanf(""), inside1 ? (float)(px + 1) : __builtin_nanf("")};
+        const float pyf = (float)py;
         float2_t T2 = float2_t{1.0f, 1.0f};          // transmittance
         float2_t D2 = float2_t{0.0f, 0.0f};          // sum alpha T z
         float2_t acc[NCHP];
 #pragma unroll
         for (int c = 0; c < NCHP; ++c) acc[c] = float2_t{0.0f, 0.0f};
         uint32_t stop_pos0 = 0, stop_pos1 = 0;
-        // The per-pixel "finished" flags live in scalar register pairs as 64-bit lane masks, so the skip /
-        // blend / stop decisions are SALU mask algebra instead of per-lane VALU selects.
+        // lanes whose two pixels are both finished (only consulted between batches)
         uint64_t done0 = __ballot(!inside0), done1 = __ballot(!inside1);
 
         // Software-pipelined staging: while batch b is composited, the records of batch b+1 and the
@@ -205,9 +206,10 @@ k_render_fwd(RenderFwdParams p) {
                 const float4 a = cur.a, b = cur.b;
                 const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
                 s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
-                s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z, 0.0f);
+                s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z * kInv255, -kInv255);
 #pragma unroll
-                for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[lane][2 + c4] = cur.pay[c4];
+                for (int c4 = 0; c4 < NCHP / 4; ++c4)
+                    s_ent[lane][2 + c4] = make_float4(cur.pay[c4].x * kInv255, cur.pay[c4].y * kInv255, cur.pay[c4].z * kInv255, cur.pay[c4].w * kInv255);
             }
             // compaction: per sub-block, the staged entries that can reach it, in list order
             uint32_t nk = 0;
@@ -233,41 +235,44 @@ k_render_fwd(RenderFwdParams p) {
                 const uint32_t off = lp[i];
                 const float4 *E = (const float4 *)(ent_base + off);
                 const float4 a = E[0], b = E[1];
-                float pay[NCHP];
+                float2_t pay[NCHP / 2];     // (c, c+1) pairs: either half is broadcast to both pixels by the packed ops' op_sel
 #pragma unroll
                 for (int c4 = 0; c4 < NCHP / 4; ++c4) {
                     const float4 t = E[2 + c4];
-                    pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
+                    pay[2 * c4] = float2_t{t.x, t.y}; pay[2 * c4 + 1] = float2_t{t.z, t.w};
                 }
-                // exponent e(dx) = dx (a2 dx + b2 dy) + (c2 dy^2 + log2 o) for dx = dx0, dx0 - 1 (the backward
-                // performs the identical sequence: both passes must make bit-identical alpha decisions)
+                const float2_t zk = float2_t{b.z, b.w};   // (z / 255, -1 / 255)
+                // e'(dx) = dx (a2 dx + b2 dy) + (c2 dy^2 + l2o') for dx = dx0, dx0 - 1 (lsr_blend.h; the backward
+                // performs the identical sequence)
                 const float2_t d2 = float2_t{a.x, a.x} - pxx;
                 const float dy = a.y - pyf;
                 const float t = b.x * dy;
                 const float s = __builtin_fmaf(a.w * dy, dy, b.y);
                 const float2_t p1 = __builtin_elementwise_fma(float2_t{a.z, a.z}, d2, float2_t{t, t});
                 const float2_t ex = __builtin_elementwise_fma(p1, d2, float2_t{s, s});
-                const float al0 = fminf(LSR_ALPHA_MAX, fast_exp2(ex.x)), al1 = fminf(LSR_ALPHA_MAX, fast_exp2(ex.y));
-                // skip if power > 0 or alpha < 1/255 (NaN-safe: comparisons are "keep" tests)
-                const uint64_t ok0 = __ballot(ex.x <= b.y) & __ballot(al0 >= LSR_ALPHA_MIN);
-                const uint64_t ok1 = __ballot(ex.y <= b.y) & __ballot(al1 >= LSR_ALPHA_MIN);
-                const float2_t aT = float2_t{al0, al1} * T2;
-                const float2_t tT = T2 - aT;
-                const uint64_t live0 = ok0 & ~done0, live1 = ok1 & ~done1;
+                const float2_t al = float2_t{fminf(kAlphaMax255, fast_exp2(ex.x)), fminf(kAlphaMax255, fast_exp2(ex.y))};   // 255 alpha
+                // keep <=> 0 <= e' <= l2o' (alpha >= 1/255 and power <= 0): one unsigned comparison of the float bits
+                const uint32_t lim = __float_as_uint(b.y);
+                const uint64_t ok0 = __ballot(__float_as_uint(ex.x) <= lim), ok1 = __ballot(__float_as_uint(ex.y) <= lim);
+                const float2_t aT = al * T2;                                                   // 255 alpha T
+                const float2_t tT = __builtin_elementwise_fma(aT, float2_t{b.w, b.w}, T2);    // T (1 - alpha)
                 const uint64_t room0 = __ballot(tT.x >= LSR_T_EPS), room1 = __ballot(tT.y >= LSR_T_EPS);
-                const uint64_t stop0 = live0 & ~room0, stop1 = live1 & ~room1;
-                const float w0 = __builtin_amdgcn_inverse_ballot_w64(live0 & room0) ? aT.x : 0.0f;
-                const float w1 = __builtin_amdgcn_inverse_ballot_w64(live1 & room1) ? aT.y : 0.0f;
+                const uint64_t stop0 = ok0 & ~room0, stop1 = ok1 & ~room1;
+                const float w0 = __builtin_amdgcn_inverse_ballot_w64(ok0 & room0) ? aT.x : 0.0f;
+                const float w1 = __builtin_amdgcn_inverse_ballot_w64(ok1 & room1) ? aT.y : 0.0f;
                 const float2_t ww = float2_t{w0, w1};
 #pragma unroll
-                for (int c = 0; c < NCHP; ++c) acc[c] = __builtin_elementwise_fma(float2_t{pay[c], pay[c]}, ww, acc[c]);
-                D2 = __builtin_elementwise_fma(float2_t{b.z, b.z}, ww, D2);
-                T2 = T2 - ww;
+                for (int c = 0; c < NCHP; ++c)
+                    acc[c] = __builtin_elementwise_fma((c & 1) ? float2_t{pay[c / 2].y, pay[c / 2].y} : float2_t{pay[c / 2].x, pay[c / 2].x}, ww, acc[c]);
+                D2 = __builtin_elementwise_fma(float2_t{zk.x, zk.x}, ww, D2);
+                T2 = __builtin_elementwise_fma(ww, float2_t{zk.y, zk.y}, T2);
                 if (stop0 | stop1) {  // rare, wave-uniform: a pixel's transmittance ran out here
                     // 1-based list position of the stopping entry, from its staging slot
                     const uint32_t pos = base + 1u + (off - wave_off) / (uint32_t)(kEnt * 16);
-                    stop_pos0 = __builtin_amdgcn_inverse_ballot_w64(stop0) ? pos : stop_pos0;
-                    stop_pos1 = __builtin_amdgcn_inverse_ballot_w64(stop1) ? pos : stop_pos1;
+                    const bool st0 = __builtin_amdgcn_inverse_ballot_w64(stop0), st1 = __builtin_amdgcn_inverse_ballot_w64(stop1);
+                    stop_pos0 = st0 ? pos : stop_pos0;
+                    stop_pos1 = st1 ? pos : stop_pos1;
+                    pxx = float2_t{st0 ? __builtin_nanf("") : pxx.x, st1 ? __builtin_nanf("") : pxx.y};   // never kept again
                     done0 |= stop0; done1 |= stop1;
                 }
             }

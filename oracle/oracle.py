@@ -124,7 +124,9 @@ def forward(view: View, means3D, cov3D, opacities, shs=None, colors_precomp=None
 
 
 def backward(view: View, means3D, cov3D, opacities, shs, colors_precomp, features, fwd: dict,
-             dL_dcolor=None, dL_dfeature=None, dL_dmask=None, dL_ddepth=None) -> dict:
+             dL_dcolor=None, dL_dfeature=None, dL_dmask=None, dL_ddepth=None, f64: bool = False) -> dict:
+    """f64=True: the compositing backward evaluated in double precision under the float32 forward's keep / skip /
+    stop decisions (oracle_render_backward_f64: the error-budget reference, not the published float32 recurrence)."""
     L = lib()
     means3D, cov3D = _f32(means3D), _f32(cov3D)
     shs, colors_precomp, features = _f32(shs), _f32(colors_precomp), _f32(features)
@@ -143,7 +145,7 @@ def backward(view: View, means3D, cov3D, opacities, shs, colors_precomp, feature
     d_rgb = np.zeros((G, 3), np.float64)
     d_feat = np.zeros((G, max(C, 1)), np.float64)
     d_z = np.zeros(G, np.float64)
-    L.oracle_render_backward(
+    (L.oracle_render_backward_f64 if f64 else L.oracle_render_backward)(
         ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(C), _p(fwd["ranges"]), _p(plist),
         _p(fwd["xy"]), _p(fwd["conic_opacity"]), _p(fwd["gdepth"]), _p(fwd["rgb"]), _p(features),
         _p(bg), _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(dL_dcolor), _p(dL_dfeature),

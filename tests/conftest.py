@@ -46,14 +46,19 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     worst = {}
     for a in acc:
         key = (a["kind"], a["what"].split("[")[0])
-        w = worst.setdefault(key, dict(n=0, total=0, strict=0, bounded=0, exempt=0, min_frac=1.0, worst=0.0))
+        w = worst.setdefault(key, dict(n=0, total=0, strict=0, bounded=0, exempt=0, min_frac=1.0, worst=0.0, row=None))
         w["n"] += 1; w["total"] += a["total"]; w["strict"] += a["held_to_bar"]; w["bounded"] += a["flip_bounded"]
         w["exempt"] += a["exempt"]; w["worst"] = max(w["worst"], a["worst_strict_err"] / a["scale"])
         w["min_frac"] = min(w["min_frac"], a["held_to_bar"] / max(a["total"], 1))
+        if "worst_clean_row_mixed" in a:
+            w["row"] = max(w["row"] or 0.0, a["worst_clean_row_mixed"])
     for (kind, what), w in sorted(worst.items()):
-        tr.write_line(f"{kind:5s} {what:28s} comparisons {w['n']:4d}  elements {w['total']:9d}  strict {w['strict']:9d} "
+        # images: largest error among the pixels on the bar; gradients: largest error of a CLEAN row (no fragile
+        # evaluation nearby) relative to the tensor's scale, and relative to max(1, |row|) ("row-mixed")
+        tail = f"worst err/scale {w['worst']:.2e}" + (f"  worst row-mixed {w['row']:.2e}" if w["row"] is not None else "")
+        tr.write_line(f"{kind:5s} {what:28s} comparisons {w['n']:4d}  elements {w['total']:9d}  on the bar {w['strict']:9d} "
                       f"({100.0 * w['strict'] / max(w['total'], 1):6.2f} %, min {100.0 * w['min_frac']:6.2f} %)  "
-                      f"flip-bounded {w['bounded']:6d}  exempt {w['exempt']:5d}  worst strict err/scale {w['worst']:.2e}")
+                      f"flip-bounded {w['bounded']:6d}  exempt {w['exempt']:5d}  {tail}")
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
         import json

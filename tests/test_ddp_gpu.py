@@ -145,6 +145,18 @@ def test_bench_multi_process_path_on_one_gpu():
     assert len(lines) == 1, r.stdout[-2000:]            # rank 0 prints, rank 1 stays silent
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
-    assert len(out["per_rank_ms_per_step"]) == 2 and max(out["per_rank_ms_per_step"]) == pytest.approx(out["ms_per_step"], rel=1e-6)
+    assert len(out["per_rank_ms_per_step"]) == 2 and max(out["per_rank_ms_per_step"]) == pytest.approx(out["ms_per_step"], abs=1e-4)
+    assert len(lines[0]) < 4096 and "roofline" in out and "fwdbwd" in out       # compact line; the full dictionary goes to gpurun_out/bench_full.json
+    # the same job WITHOUT a launcher: `python bench.py --gpus 2` starts its own two ranks ...
+    cmd2 = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gaussians", "20000",
+            "--views", "4", "--no-cpu-baseline", "--no-latency", "--no-bwd"]
+    env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r2 = subprocess.run(cmd2, env=env2, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, (r2.stdout + r2.stderr)[-3000:]
+    out2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert out2["n_gpus"] == 2
+    # ... and a launcher that provides a different world size than --gpus asks for is refused, not mis-reported
+    r3 = subprocess.run(cmd2, env=dict(env2, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=root, capture_output=True, text=True, timeout=600)
+    assert r3.returncode != 0 and "refusing" in (r3.stdout + r3.stderr)
     assert out["value"] == pytest.approx(2 * 4 * 1e3 / out["ms_per_step"], rel=1e-6)   # whole-job rate: both ranks' views over the slowest rank's time
     assert out["cpu_baseline"] is None                  # rank 0 at N = 1 only

@@ -112,7 +112,7 @@ def test_cfg3_decoder_forward_backward_against_oracle(hip_device, cfg3_scene):
     got = dict(means=gauss.means.grad[0], cov=gauss.covariances.grad[0], opac=gauss.opacities.grad[0][:, None],
                shs=gauss.color_harmonics.grad[0], fsh=gauss.feature_harmonics.grad[0])
     for k in ("means", "cov", "opac", "shs", "fsh"):
-        util.assert_grad_close_except_fragile(got[k].cpu().numpy(), cpu[k].grad.numpy(), direct, behind, 1e-4, f"cfg3 dL/d{k}")
+        util.assert_grad_close_except_fragile(got[k].cpu().numpy(), cpu[k].grad.numpy(), direct, behind, 1e-4, f"cfg3 dL/d{k}", clean_tol=5e-5)
 
 
 def test_cfg3_sorted_tile_lists_bit_exact(hip_device, cfg3_scene):

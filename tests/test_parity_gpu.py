@@ -12,6 +12,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 ABS_TOL = 1e-4
+CLEAN_TOL = 2e-5   # gradient rows with no fragile evaluation nearby (tests/util.py assert_grad_close_except_fragile)
 
 
 def _check_forward(bi, run, views=None):
@@ -49,9 +50,11 @@ def _check_forward(bi, run, views=None):
         dscale = max(1.0, float(np.abs(o["depth"]).max()))
         util.assert_close_except_fragile(run.depth_out[v].cpu().numpy(), o["depth"], o, ABS_TOL * dscale, "depth")
         # the per-pixel list prefix kept for the backward pass may differ only where exp rounding
-        # flips the transmittance-termination decision
-        mism = (ncontrib[v] != o["n_considered"].astype(np.int32)).mean()
-        assert mism < 2e-3, f"n_considered mismatch fraction {mism}"
+        # flips a decision: every mismatching pixel must be one the oracle flagged as fragile
+        mism = np.flatnonzero(ncontrib[v].reshape(-1) != o["n_considered"].astype(np.int64).reshape(-1))
+        fragile_px = set(int(x) for x in o["fragile"][:, 0]) if len(o["fragile"]) else set()
+        assert set(int(x) for x in mism) <= fragile_px, f"n_considered differs at {len(set(mism) - fragile_px)} non-fragile pixels"
+        assert len(mism) < 2e-3 * ncontrib[v].size, f"n_considered mismatch fraction {len(mism) / ncontrib[v].size}"
     if views is None:
         assert run.P == total_P
 
@@ -215,10 +218,10 @@ def _grad_case(hip_device, case, with_aux):
 
     def close_per_view(got, want, what):   # (V,G,...) tensors: exemptions of the view itself
         for v in range(V):
-            util.assert_grad_close_except_fragile(got[v].detach().cpu().numpy(), want[v], frag[v][0], frag[v][1], ABS_TOL, f"{what}[view {v}]")
+            util.assert_grad_close_except_fragile(got[v].detach().cpu().numpy(), want[v], frag[v][0], frag[v][1], ABS_TOL, f"{what}[view {v}]", clean_tol=CLEAN_TOL)
 
     def close_shared(got, want, what):     # (G,...) tensors summed over views: union of exemptions
-        util.assert_grad_close_except_fragile(got.detach().cpu().numpy(), want, all_direct, all_behind, ABS_TOL, what)
+        util.assert_grad_close_except_fragile(got.detach().cpu().numpy(), want, all_direct, all_behind, ABS_TOL, what, clean_tol=CLEAN_TOL)
 
     close_per_view(means.grad, np.stack(exp["means"]), "dL/dmeans3D")
     close_per_view(cov6.grad, np.stack(exp["cov"]), "dL/dcov3D")
@@ -311,10 +314,10 @@ def test_fused_scene_inputs_match_oracle(hip_device, cfg, shared):
             continue
         got, want = gpu[k].grad.cpu().numpy(), cpu[k].grad.numpy()
         if shared:
-            util.assert_grad_close_except_fragile(got, want, all_direct, all_behind, ABS_TOL, f"dL/d{k}")
+            util.assert_grad_close_except_fragile(got, want, all_direct, all_behind, ABS_TOL, f"dL/d{k}", clean_tol=CLEAN_TOL)
         else:
             for v in range(V):
-                util.assert_grad_close_except_fragile(got[v], want[v], frag[v][0], frag[v][1], ABS_TOL, f"dL/d{k}[view {v}]")
+                util.assert_grad_close_except_fragile(got[v], want[v], frag[v][0], frag[v][1], ABS_TOL, f"dL/d{k}[view {v}]", clean_tol=CLEAN_TOL)
 
 
 @pytest.mark.parametrize("cfg,direct", [
@@ -417,7 +420,7 @@ def test_color_sh_reference_axis_convention(hip_device):
             util.assert_close_except_fragile(color[v], o["color"], o, ABS_TOL, "colour (reference SH axes)")
             b = util.oracle_backward(bi, v, o, g_color[v].numpy(), None)
             direct, behind = util.fragile_gaussians(o, 64)
-            util.assert_grad_close_except_fragile(g_means[v], b["means3D"], direct, behind, ABS_TOL, "dL/dmeans3D (reference SH axes)")
+            util.assert_grad_close_except_fragile(g_means[v], b["means3D"], direct, behind, ABS_TOL, "dL/dmeans3D (reference SH axes)", clean_tol=CLEAN_TOL)
             want_shs += b["shs"]
         assert np.abs(g_shs - want_shs).max() <= ABS_TOL * max(1.0, np.abs(want_shs).max())
     finally:

@@ -223,6 +223,52 @@ def test_orthographic_matches_reference_wrapper_golden(hip_device):
         features=_t(g["call0_features"], dev), opacities=_t(g["call0_opacities"], dev), cov3D_precomp=_t(g["call0_cov3D_precomp"], dev))
     err = np.abs(image.cpu().numpy() - g["out_color"][0])
     assert (err > 1e-4).mean() <= 0.002 and mask.shape == (1,) + tuple(g["in_image_shape"])
+    # ... and those isolated pixels are exactly where the oracle (replayed on the recorded call) sees an evaluation
+    # within float rounding of an alpha / transmittance threshold: nowhere else may a value miss the bar
+    H, W = (int(x) for x in g["in_image_shape"])
+    view = util.orc.View(H, W, float(g["call0_tanfovx"]), float(g["call0_tanfovy"]), np.asarray(g["call0_bg"], np.float32),
+                         np.asarray(g["call0_viewmatrix"], np.float32), np.asarray(g["call0_projmatrix"], np.float32),
+                         np.asarray(g["call0_campos"], np.float32), int(g["call0_sh_degree"]))
+    o = util.orc.forward(view, g["call0_means3D"], g["call0_cov3D_precomp"], g["call0_opacities"], g["call0_shs"], None, g["call0_features"])
+    fragile_px = set(int(x) for x in o["fragile"][:, 0]) if len(o["fragile"]) else set()
+    for name, got, want in (("color", image, g["out_color"][0]), ("feature", feature_map, g["out_feature"][0]), ("mask", mask[0], g["out_mask"][0])):
+        e = np.abs(got.cpu().numpy() - want).reshape(-1, H * W).max(0)
+        off = set(int(x) for x in np.flatnonzero(e > 1e-4 * max(1.0, np.abs(want).max())))
+        assert off <= fragile_px, f"orthographic {name}: {len(off - fragile_px)} pixels off the bar without a fragile evaluation"
+
+
+def test_render_cuda_by_name_with_latent_sh(hip_device):
+    """``render_cuda`` (reference cuda_splatting.py:56-167) called by name the way every reference caller other
+    than the decoder calls it — v-fold replicated per-view inputs INCLUDING ``gaussian_feature_sh_coefficients``
+    (src/visualization/validation_in_3d.py:69-82, src/scripts/render_uncertainty.py:249,265 via the decoder):
+    bit-for-bit what the scene-major ``render_scenes`` gives for the same scene, and the oracle's images."""
+    from latentsplat_amd.decoder import render_cuda
+    from latentsplat_amd.decoder.cuda_splatting import render_scenes
+    from latentsplat_amd.rasterizer import build_view_table
+    dev, V, S = hip_device, 3, 80
+    sc = util.make_scene(5000, image_size=S, views=V, color_sh_degree=2, feature_channels=4, feature_sh_degree=2, seed=21)
+    d = sc.to(dev)
+    bg = torch.tensor([0.2, 0.1, 0.4], device=dev)
+    rep = lambda t: t[None].expand(V, *t.shape).contiguous()         # the reference's `repeat` (decoder_splatting_cuda.py:71-87)
+    out = render_cuda(d.extrinsics, d.intrinsics, d.near, d.far, (S, S), bg[None].expand(V, 3), rep(d.means), rep(d.covariances),
+                      rep(d.opacities), rep(d.color_sh), rep(d.feature_sh))
+    ref = render_scenes(d.extrinsics[None], d.intrinsics[None], d.near[None], d.far[None], (S, S), bg, d.means[None],
+                        d.covariances[None], d.opacities[None], d.color_sh[None], d.feature_sh[None])
+    for k in ("color", "feature", "mask", "depth"):
+        assert torch.equal(getattr(out, k), getattr(ref, k)), k
+    assert out.color.shape == (V, 3, S, S) and out.feature.shape == (V, 4, S, S)
+    views_cpu = build_view_table(d.extrinsics, d.intrinsics, d.near, d.far, bg, True).cpu()
+    n = lambda t: None if t is None else t.detach().contiguous().numpy()
+    for v in range(V):
+        m, c6, op, sh, cp, ft = util.to_boundary(views_cpu, v, sc.means, sc.covariances, sc.opacities[:, None], sc.color_sh, None, None,
+                                                 sc.feature_sh, True)
+        vw = views_cpu[v]
+        view = util.orc.View(S, S, float(vw[35]), float(vw[36]), vw[37:40].numpy(), vw[0:16].numpy().reshape(4, 4),
+                             vw[16:32].numpy().reshape(4, 4), vw[32:35].numpy(), 2)
+        o = util.orc.forward(view, n(m), n(c6), n(op), n(sh), None, n(ft))
+        util.assert_close_except_fragile(out.color[v].cpu().numpy(), o["color"], o, 1e-4, f"render_cuda colour[view {v}]")
+        util.assert_close_except_fragile(out.feature[v].cpu().numpy(), o["feature"], o, 1e-4, f"render_cuda latent[view {v}]")
+        util.assert_close_except_fragile(out.mask[v].cpu().numpy(), o["mask"], o, 1e-4, f"render_cuda mask[view {v}]")
 
 
 def test_orthographic_and_depth_modes_run(hip_device):
@@ -333,7 +379,12 @@ def test_full_size_backward_against_oracle(hip_device, full_run):
     for name, got, want in (("means3D", grads[0][0], b["means3D"]), ("cov3D", grads[1][0], b["cov3D"]),
                             ("opacities", grads[2], b["opacities"]), ("features", grads[3][0], b["features"])):
         got = got.cpu().numpy()
-        util.assert_grad_close_except_fragile(got, want, direct, behind, 1e-4, f"full-size dL/d{name}")
+        # clean rows (no fragile evaluation nearby): 2e-5 of the tensor's scale AND 1e-4 of max(1, |row|) — measured
+        # 1.8e-6 / 4.4e-5 (tools/grad_budget.py, which also shows the float32 oracle itself 0.7e-6 / 1.9e-5 away from
+        # a float64 evaluation).  dL/dcov3D rows mix entries of very different magnitude through the float32
+        # conic -> covariance chain (the oracle runs that stage in double): per-row bar 2e-3 there (measured 7.7e-4).
+        util.assert_grad_close_except_fragile(got, want, direct, behind, 1e-4, f"full-size dL/d{name}", clean_tol=2e-5,
+                                              row_tol=2e-3 if name == "cov3D" else 1e-4)
         err = np.abs(got - want).reshape(got.shape[0], -1).max(1)
         assert np.median(err) <= 1e-6 * max(1.0, np.abs(want).max())
 
