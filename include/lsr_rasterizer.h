@@ -255,9 +255,9 @@ int lsr_forward_status(const lsr_dims *d, const void *geom_ws, int64_t *num_pair
  * that forward produced (`fwd`: colour / feature / depth are read wherever the corresponding
  * gradient in `gout` is given; mask and radii are not used).  The compositing gradient walks the
  * tile lists front to back like the forward and gets "everything behind this entry" as
- * (rendered value - prefix), which is why the rendered values are an input.  Async.  With several scenes
- * in the call (views_per_group) the per-scene geometry / SH kernels behind the compositing backward run as
- * two chains, one of them on the library's side stream (forked and joined with events inside this call). */
+ * (rendered value - prefix), which is why the rendered values are an input.  Async, everything on `stream`.
+ * With several scenes in the call (views_per_group) the geometry and SH backward kernels behind the compositing
+ * backward still are ONE launch each (the scene is a grid dimension). */
 int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws,
                  const void *bin_ws, const void *img_ws, int64_t num_pairs,
                  const int32_t *radii, const lsr_outputs *fwd, const lsr_out_grads *gout,

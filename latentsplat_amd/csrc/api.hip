@@ -156,37 +156,6 @@ static int check_dims(const lsr_dims *d) {
     return LSR_OK;
 }
 
-// The stages that sum over views (SH kernels, preprocess backward) run once per view group.
-// fn(dims of the launch, its inputs, its input-gradient pointers, layout dims or nullptr, first view)
-template <class F>
-static int for_each_view_group(const lsr_dims &d, const lsr_inputs &in, const lsr_in_grads *gin, F fn) {
-    if (d.views_per_group <= 1) return fn(d, in, gin ? *gin : lsr_in_grads{}, (const lsr_dims *)nullptr, 0);
-    const int n = d.views_per_group;
-    for (int g = 0; g * n < d.num_views; ++g) {
-        lsr_dims ds = d;
-        ds.num_views = n; ds.views_per_group = 0;
-        ds.vs_means = ds.vs_cov = ds.vs_opac = ds.vs_color = ds.vs_feat = 0;
-        lsr_inputs is = in;
-        is.views = in.views + (size_t)g * n * LSR_VIEW_FLOATS;
-        is.means3D = in.means3D + (size_t)g * d.vs_means;
-        is.cov3D = in.cov3D + (size_t)g * d.vs_cov;
-        is.opacities = in.opacities + (size_t)g * d.vs_opac;
-        if (in.color) is.color = in.color + (size_t)g * d.vs_color;
-        if (in.features) is.features = in.features + (size_t)g * d.vs_feat;
-        lsr_in_grads gs{};
-        if (gin) {
-            gs = *gin;
-            gs.means3D = gin->means3D + (size_t)g * d.vs_means;
-            gs.cov3D = gin->cov3D + (size_t)g * d.vs_cov;
-            gs.opacities = gin->opacities + (size_t)g * d.vs_opac;
-            if (gin->color) gs.color = gin->color + (size_t)g * d.vs_color;
-            if (gin->features) gs.features = gin->features + (size_t)g * d.vs_feat;
-        }
-        const int rc = fn(ds, is, gs, &d, g * n);
-        if (rc) return rc;
-    }
-    return LSR_OK;
-}
 // The library owns ONE side stream per device, shared by all host threads, for work that may run beside
 // the caller's stream inside a call:
 //   * the SH payload pass (sh.hip) depends on k_preprocess only and touches nothing that tile_scan / scatter /
@@ -263,11 +232,7 @@ static int sh_forward_fork(const lsr_dims &d, const lsr_inputs &in, char *geom, 
         LSR_HIP(cross_edge(c, c->fork, s, c->side));
         q = c->side;
     }
-    const int rc = for_each_view_group(d, in, nullptr, [&](const lsr_dims &dg, const lsr_inputs &ig, const lsr_in_grads &, const lsr_dims *layout, int view0) -> int {
-        LSR_STAGE("sh_forward", q, launch_sh_forward(dg, ig, geom, q, layout, view0));
-        return LSR_OK;
-    });
-    if (rc) return rc;
+    LSR_STAGE("sh_forward", q, launch_sh_forward(d, in, geom, q));   // all view groups in one launch
     if (c) {
         std::lock_guard<std::mutex> lock(c->mu);
         LSR_HIP(hipEventRecord(c->join, c->side));
@@ -576,22 +541,10 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
     if (num_pairs > 0)
         LSR_STAGE("render_backward", s, launch_render_backward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs,
                                        (const char *)img_ws, *fwd, *gout, (char *)grad_ws, *gin, s));
-    // Geometry / SH backward per scene (view group).  Inside a scene the two kernels are ordered (both add into
-    // the scene's mean gradients); different scenes touch disjoint gradient slices, so with several scenes in
-    // the call the odd ones go to the side stream and two chains of these memory-bound kernels run
-    // concurrently (forked behind the compositing backward, joined at the end).
-    const int groups = d->views_per_group > 1 ? (d->num_views + d->views_per_group - 1) / d->views_per_group : 1;
-    SideCtx *c = groups >= 2 ? side_ctx() : nullptr;
-    if (c) LSR_HIP(cross_edge(c, c->fork, s, c->side));
-    int g = 0;
-    rc = for_each_view_group(*d, *in, gin, [&](const lsr_dims &dg, const lsr_inputs &ig, const lsr_in_grads &gg, const lsr_dims *layout, int view0) -> int {
-        hipStream_t q = (c && (g++ & 1)) ? c->side : s;
-        LSR_STAGE("preprocess_backward", q, launch_preprocess_backward(dg, ig, (const char *)geom_ws, radii, (const char *)grad_ws, gg, q, layout, view0));
-        LSR_STAGE("sh_backward", q, launch_sh_backward(dg, ig, (const char *)geom_ws, (const char *)grad_ws, gg, q, layout, view0));
-        return LSR_OK;
-    });
-    if (rc) return rc;
-    if (c) LSR_HIP(cross_edge(c, c->join, c->side, s));
+    // Geometry and SH backward: one launch each, all scenes (view groups) of the call at once (the scene in
+    // blockIdx.y).  Both add into the scene's mean gradients, hence in stream order.
+    LSR_STAGE("preprocess_backward", s, launch_preprocess_backward(*d, *in, (const char *)geom_ws, radii, (const char *)grad_ws, *gin, s));
+    LSR_STAGE("sh_backward", s, launch_sh_backward(*d, *in, (const char *)geom_ws, (const char *)grad_ws, *gin, s));
     return LSR_OK;
 }
 

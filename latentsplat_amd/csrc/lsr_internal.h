@@ -207,14 +207,36 @@ hipError_t launch_pack_view(const float *viewmatrix, const float *projmatrix, co
 hipError_t launch_build_views(int V, const float *extrinsics, const float *intrinsics, const float *near,
                               const float *far, const float *bg, int bg_stride, int scale_invariant,
                               float *out, hipStream_t s);
-// Stages that sum over views run once per view group (lsr_dims::views_per_group): `d` / `in` / `gin`
-// then describe ONE group (its views, its input slices, strides 0 = shared inside the group) while
-// `layout` (the full call's dims) and `view0` (first view of the group) locate its part of the
-// per-(view, Gaussian) workspace arrays.  layout == nullptr: `d` is the whole call.
-hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s,
-                             const lsr_dims *layout = nullptr, int view0 = 0);
+// Stages that sum over views (SH kernels, geometry backward) work per view group (lsr_dims::views_per_group:
+// b scenes x n views in one call).  They take the WHOLE call's dims / inputs and run all groups in ONE launch,
+// the group in blockIdx.y: inside the kernel a group looks like a call of its own n views with shared inputs
+// (strides 0), its pointers advanced by the group's slices (GroupStrides).
+struct GroupStrides {     // element offsets between consecutive groups
+    int64_t views, means, cov, opac, color, feat;   // inputs (and the matching gradient outputs)
+    int64_t slots;                                   // (view, Gaussian) slots: views_per_group * G
+};
+inline int num_view_groups(const lsr_dims &d) { return d.views_per_group > 1 ? d.num_views / d.views_per_group : 1; }
+inline GroupStrides group_strides(const lsr_dims &d) {
+    GroupStrides g{};
+    if (d.views_per_group > 1) {
+        g.views = (int64_t)d.views_per_group * LSR_VIEW_FLOATS;
+        g.means = d.vs_means; g.cov = d.vs_cov; g.opac = d.vs_opac; g.color = d.vs_color; g.feat = d.vs_feat;
+        g.slots = (int64_t)d.views_per_group * d.num_gaussians;
+    }
+    return g;
+}
+// dims of ONE group of a view-group call (the whole call when there are no groups)
+inline lsr_dims group_dims(const lsr_dims &d) {
+    lsr_dims ds = d;
+    if (d.views_per_group > 1) {
+        ds.num_views = d.views_per_group; ds.views_per_group = 0;
+        ds.vs_means = ds.vs_cov = ds.vs_opac = ds.vs_color = ds.vs_feat = 0;
+    }
+    return ds;
+}
+hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s);
 hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom, const char *grad,
-                              const lsr_in_grads &gin, hipStream_t s, const lsr_dims *layout = nullptr, int view0 = 0);
+                              const lsr_in_grads &gin, hipStream_t s);
 // device_counts: the pair count / longest list are NOT known on the host (no-sync forward):
 // `num_pairs` is then the workspace capacity and `max_tile_pairs` only a hint for the sort variant
 // (binning and forward compositing take the view chunk they work on)
@@ -229,6 +251,6 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
                                   const lsr_in_grads &gin, hipStream_t s);
 hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                       const int32_t *radii, const char *grad,
-                                      const lsr_in_grads &gin, hipStream_t s, const lsr_dims *layout = nullptr, int view0 = 0);
+                                      const lsr_in_grads &gin, hipStream_t s);
 
 }  // namespace lsr

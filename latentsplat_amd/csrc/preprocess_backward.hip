@@ -27,6 +27,7 @@ struct PreBwdParams {
     const float *rec;       // packed gradient records (lsr_internal.h GradLayout)
     int rec_floats;
     lsr_in_grads g;
+    GroupStrides gs;        // view groups (blockIdx.y): element offsets of the next group's slices
 };
 
 constexpr int kPreBwdFeat = 8;   // shared direct-feature gradients kept in registers up to this many channels
@@ -39,7 +40,18 @@ constexpr int kPreBwdShared = 3 + 6 + 1 + kPreBwdFeat + 3;   // register accumul
 
 template <int PARTS>
 __global__ void __launch_bounds__(kPreBwdThreads, 4)
-k_preprocess_bwd(PreBwdParams p) {
+k_preprocess_bwd(PreBwdParams pk) {
+    // view groups: blockIdx.y = group; its inputs, gradient outputs and workspace slices (uniform: scalar arithmetic)
+    PreBwdParams p = pk;
+    {
+        const int64_t g = blockIdx.y;
+        p.in.views += g * pk.gs.views; p.in.means3D += g * pk.gs.means; p.in.cov3D += g * pk.gs.cov; p.in.opacities += g * pk.gs.opac;
+        p.radii += g * pk.gs.slots; p.geo += g * pk.gs.slots * pk.geo_floats; p.rec += g * pk.gs.slots * pk.rec_floats;
+        p.g.means3D += g * pk.gs.means; p.g.cov3D += g * pk.gs.cov; p.g.opacities += g * pk.gs.opac;
+        if (p.g.color) p.g.color += g * pk.gs.color;
+        if (p.g.features) p.g.features += g * pk.gs.feat;
+        if (p.g.means2D) p.g.means2D += g * pk.gs.slots * 3;
+    }
     constexpr int LPP = kPreBwdThreads / PARTS;               // Gaussians per block = lanes per part
     __shared__ float s_part[PARTS > 1 ? (PARTS - 1) * kPreBwdShared * LPP : 1];
     const int part = __builtin_amdgcn_readfirstlane((int)threadIdx.x / LPP);   // wave-uniform
@@ -287,23 +299,23 @@ k_preprocess_bwd(PreBwdParams p) {
     }
 }
 
-hipError_t launch_preprocess_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
+hipError_t launch_preprocess_backward(const lsr_dims &d_all, const lsr_inputs &in, const char *geom,
                                       const int32_t *radii, const char *grad,
-                                      const lsr_in_grads &gin, hipStream_t s, const lsr_dims *layout, int view0) {
-    if (d.num_gaussians == 0) return hipSuccess;
-    const GeomLayout L = geom_layout(layout ? *layout : d);
-    const GradLayout R = grad_layout(layout ? *layout : d);
-    const size_t off = (size_t)view0 * (size_t)d.num_gaussians;   // first (view, Gaussian) slot of this launch
+                                      const lsr_in_grads &gin, hipStream_t s) {
+    if (d_all.num_gaussians == 0) return hipSuccess;
+    const GeomLayout L = geom_layout(d_all);
+    const GradLayout R = grad_layout(d_all);
+    const lsr_dims d = group_dims(d_all);      // what one view group (blockIdx.y) looks like to the kernel
     PreBwdParams p;
-    p.d = d; p.in = in; p.radii = radii + off;
-    p.geo = (const float *)(geom + L.rec) + off * L.rec_floats; p.geo_floats = L.rec_floats;
-    p.rec = (const float *)(grad + R.rec) + off * R.rec_floats; p.rec_floats = R.rec_floats;
+    p.d = d; p.in = in; p.radii = radii;
+    p.gs = group_strides(d_all);
+    p.geo = (const float *)(geom + L.rec); p.geo_floats = L.rec_floats;
+    p.rec = (const float *)(grad + R.rec); p.rec_floats = R.rec_floats;
     p.g = gin;
-    if (p.g.means2D) p.g.means2D += off * 3;
     prof_begin(kStPreprocessBwd, s);
     const int parts = d.num_views >= 4 ? 4 : (d.num_views >= 2 ? 2 : 1);
     const int per_block = kPreBwdThreads / parts;   // Gaussians per block
-    const dim3 grid((unsigned)((d.num_gaussians + per_block - 1) / per_block));
+    const dim3 grid((unsigned)((d.num_gaussians + per_block - 1) / per_block), (unsigned)num_view_groups(d_all));
     if (parts == 4) hipLaunchKernelGGL(k_preprocess_bwd<4>, grid, dim3(kPreBwdThreads), 0, s, p);
     else if (parts == 2) hipLaunchKernelGGL(k_preprocess_bwd<2>, grid, dim3(kPreBwdThreads), 0, s, p);
     else hipLaunchKernelGGL(k_preprocess_bwd<1>, grid, dim3(kPreBwdThreads), 0, s, p);

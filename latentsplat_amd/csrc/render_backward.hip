@@ -108,22 +108,22 @@ __device__ __forceinline__ float2_b group_reduce_pairs(float2_b p0, float2_b p1,
 
 __device__ __forceinline__ void atomic_add_f32(float *addr, float v) { unsafeAtomicAdd(addr, v); }
 
-// WPS = resident waves per SIMD (workgroup = 4*WPS waves = one compute unit's worth): 4 where the
-// per-wave LDS slice allows it, fewer for the wide payloads.
-template <int NCHP, bool DEPTH_GRAD, int WPS>
-__global__ void __launch_bounds__(LSR_WAVE * 4 * WPS)
+// WPB = waves per workgroup, WGS = workgroups per compute unit: as many resident waves as the per-wave LDS slice
+// and the register budget allow (the kernel is bound by instruction issue and the latencies of its dependent
+// chain: DESIGN.md).
+template <int NCHP, bool DEPTH_GRAD, int WPB, int WGS>
+__global__ void __launch_bounds__(LSR_WAVE * WPB)
 k_render_bwd(RenderBwdParams p) {
-    constexpr int WPB = 4 * WPS;
     // float4 per staged entry: odd (conflict-free staging stores) except for the 8-channel payload, whose
     // 16 floats are stored at a 64-byte stride (2-way conflicts in the staging stores only) so that the
     // slice fits 16 waves per CU
     constexpr int kEnt = NCHP == 8 ? 4 : ((2 + NCHP / 4) | 1);
     constexpr int RF = NCHP <= 8 ? 16 : (NCHP <= 12 ? 32 : 64);       // == rec_floats (lsr_internal.h)
     constexpr int NGRP = RF / 16;                                     // 16-value (8-pair) reduction passes per evaluation
-    // words per row of the LDS gradient table: the record without its never-written pair (slots 6, 7: depth
-    // gradient off) for the 8-channel payload (same LDS budget), the full record otherwise
-    constexpr bool kPackRow = NCHP == 8 && !DEPTH_GRAD;
-    constexpr int RT = kPackRow ? 14 : RF;
+    // words per row of the LDS gradient table: for the 16-float record without depth gradient only the live slots
+    // (0..5 and 8..8+NCHP-1; the pair (6, 7) and the unused payload pairs have no column), the full record otherwise
+    constexpr bool kPackRow = NCHP <= 8 && !DEPTH_GRAD;
+    constexpr int RT = kPackRow ? 6 + NCHP : RF;
     constexpr int kListRow = LSR_WAVE + 2;    // u16 per list row: 33 words, so the eight lane groups' reads of list[b][i] hit eight banks
     struct Lds {
         float4 ent[WPB][LSR_WAVE + 1][kEnt];   // (x, y, a2, c2) (b2, log2 o, z, list position) payload...; slot 64 = null record
@@ -161,9 +161,9 @@ k_render_bwd(RenderBwdParams p) {
     const int l16 = lane & 15, fgrp = lane >> 4;           // flush: one 64-byte record per 16 lanes
     const int fcol = kPackRow ? (l16 < 8 ? l16 : l16 - 2) : l16;
 
-    const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = simd_bins * (uint32_t)WPS;
-    const uint32_t vwave = (uint32_t)wid;                     // 0..WPB-1; waves w, w+4, ... share a SIMD
-    const uint32_t bin = blockIdx.x * 4u + (vwave & 3u);
+    const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = (uint32_t)p.num_cus * (uint32_t)(WPB * WGS);
+    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);   // 0 .. WPB*WGS-1
+    const uint32_t bin = (blockIdx.x % (uint32_t)p.num_cus) * 4u + (vwave & 3u);
     const uint32_t j0 = vwave >> 2;
     bool first = true;
     for (;;) {
@@ -423,7 +423,7 @@ k_render_bwd(RenderBwdParams p) {
                 const uint32_t g = s_gid[e];
 #pragma unroll
                 for (int gi = 0; gi < NGRP; ++gi) {
-                    const bool mine = !kPackRow || ((l16 & 14) != 6);   // slots 6 and 7 have no column in a packed row
+                    const bool mine = !kPackRow || l16 < 6 || (l16 >= 8 && l16 < 8 + NCHP);   // slots without a column in a packed row
                     const float val = mine ? s_acc[e][16 * gi + fcol] : 0.0f;
                     if (mine) s_acc[e][16 * gi + fcol] = 0.0f;
 #ifdef LSR_ABL_NOFLUSH     // ablation builds: what do the global record-adds cost?
@@ -448,9 +448,9 @@ __global__ void __launch_bounds__(256) k_fixed_to_float(const long long *__restr
         out[i] = (float)((double)in[i] * (1.0 / kFixedPointScale));
 }
 
-template <int NCHP, bool DG, int WPS>
+template <int NCHP, bool DG, int WPB, int WGS>
 static void launch_variant(const RenderBwdParams &p, hipStream_t s) {
-    hipLaunchKernelGGL((k_render_bwd<NCHP, DG, WPS>), dim3(p.num_cus), dim3(LSR_WAVE * 4 * WPS), 0, s, p);
+    hipLaunchKernelGGL((k_render_bwd<NCHP, DG, WPB, WGS>), dim3(p.num_cus * WGS), dim3(LSR_WAVE * WPB), 0, s, p);
 }
 
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
@@ -485,16 +485,19 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));
     const bool dg = gout.depth != nullptr;
     prof_begin(kStRenderBwd, s);
-#define LSR_RB(N, W)                                             \
+#define LSR_RB(N, WPB, WGS)                                      \
     do {                                                         \
-        if (dg) launch_variant<N, true, W>(p, s);                \
-        else launch_variant<N, false, W>(p, s);                  \
+        if (dg) launch_variant<N, true, WPB, WGS>(p, s);         \
+        else launch_variant<N, false, WPB, WGS>(p, s);           \
     } while (0)
-    if (nchp == 4) LSR_RB(4, 4);
-    else if (nchp == 8 && !dg) launch_variant<8, false, 4>(p, s);   // packed table rows: 16 waves per CU fit
-    else if (nchp == 8) launch_variant<8, true, 3>(p, s);
-    else if (nchp == 12) LSR_RB(12, 2);
-    else LSR_RB(36, 1);
+    // LSR_BWD_VARIANT (development knob, read once) selects the alternatives measured in DESIGN.md
+    const int variant = env_int("LSR_BWD_VARIANT", 0);
+    if (nchp == 4 && !dg) { if (variant == 1) launch_variant<4, false, 10, 2>(p, s); else if (variant == 2) launch_variant<4, false, 12, 1>(p, s); else launch_variant<4, false, 16, 1>(p, s); }
+    else if (nchp == 4) LSR_RB(4, 16, 1);
+    else if (nchp == 8 && !dg) launch_variant<8, false, 16, 1>(p, s);   // packed table rows: 16 waves per CU fit
+    else if (nchp == 8) launch_variant<8, true, 12, 1>(p, s);
+    else if (nchp == 12) LSR_RB(12, 8, 1);
+    else LSR_RB(36, 4, 1);
 #undef LSR_RB
     if (det) {   // fixed-point sums -> the float records the next stages read
         const size_t n = (size_t)d.num_views * (size_t)d.num_gaussians * (size_t)R.rec_floats;

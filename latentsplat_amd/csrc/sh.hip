@@ -53,7 +53,22 @@ struct ShParams {
     int offF;                 // LDS word offset of the feature rows (16-byte aligned)
     uint32_t mdiv[2];         // ceil(2^22 / ks): x / ks == (x * mdiv) >> 22 for x < 8192
     uint32_t mdivK, mdivKf;   // same for K (coefficients per colour channel) and Kf
+    GroupStrides gs;          // view groups: blockIdx.y = group, every pointer above advances by the group's slices
 };
+// the launch's parameters as seen by view group blockIdx.y (uniform: scalar arithmetic)
+__device__ __forceinline__ ShParams group_params(const ShParams &pk) {
+    ShParams p = pk;
+    const int64_t g = blockIdx.y;
+    p.in.views += g * pk.gs.views; p.in.means3D += g * pk.gs.means;
+    if (p.in.color) p.in.color += g * pk.gs.color;
+    if (p.in.features) p.in.features += g * pk.gs.feat;
+    p.vis += g * pk.gs.slots * pk.vis_stride; p.rec += g * pk.gs.slots * pk.RF; p.clamp += g * pk.gs.slots;
+    if (p.grec) p.grec += g * pk.gs.slots * pk.RF;
+    if (p.g.means3D) p.g.means3D += g * pk.gs.means;
+    if (p.g.color) p.g.color += g * pk.gs.color;
+    if (p.g.features) p.g.features += g * pk.gs.feat;
+    return p;
+}
 __device__ __forceinline__ int udiv_small(int x, uint32_t m) { return (int)(((uint32_t)x * m) >> 22); }
 
 // Stage group `grp` of view v (rows x ks floats, one contiguous 16-byte aligned run) as a flat copy
@@ -137,7 +152,8 @@ __device__ __forceinline__ bool sh_shared_scene(const ShParams &p) {
 // DEGC: colour SH degree, -1 = colour is not evaluated here.  COFF: payload slot of feature 0.
 template <int DEGC, int COFF>
 __global__ void __launch_bounds__(kShThreads)
-k_sh_fwd(ShParams p) {
+k_sh_fwd(ShParams pk) {
+    const ShParams p = group_params(pk);
     extern __shared__ float s_lds[];
     const lsr_dims &d = p.d;
     const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / LSR_WAVE);
@@ -243,7 +259,8 @@ k_sh_fwd(ShParams p) {
 // ------------------------------------------------------------------------------------------
 template <int DEGC, int COFF>
 __global__ void __launch_bounds__(kShThreads, 4)
-k_sh_bwd(ShParams p) {
+k_sh_bwd(ShParams pk) {
+    const ShParams p = group_params(pk);
     extern __shared__ float s_lds[];
     const lsr_dims &d = p.d;
     const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / LSR_WAVE);
@@ -463,14 +480,16 @@ static bool group_enabled(const lsr_dims &d, int group) {
 
 static uint32_t mdiv_of(int x) { return x > 0 ? (uint32_t)(((1u << 22) + x - 1) / x) : 0u; }
 
-static ShParams make_params(const lsr_dims &d, const lsr_inputs &in, const GeomLayout &L, const char *geom, int view0) {
+// d: the whole call's dims.  The kernels see ONE group's dims (group_dims: its views, shared inputs) and find the
+// group's slices through ShParams::gs.
+static ShParams make_params(const lsr_dims &d, const lsr_inputs &in, const GeomLayout &L, const char *geom) {
     ShParams p;
-    const size_t off = (size_t)view0 * (size_t)d.num_gaussians;   // first (view, Gaussian) slot of this launch
-    p.d = d; p.in = in;
+    p.d = group_dims(d); p.in = in;
+    p.gs = group_strides(d);
     p.vis_stride = (int)(bin_stride(d) / 4);
-    p.vis = (const float *)(geom + L.bin) + off * (size_t)p.vis_stride + (narrow_bins(d) ? 1 : 2);
-    p.rec = (float *)const_cast<char *>(geom + L.rec) + off * L.rec_floats;
-    p.clamp = (uint8_t *)const_cast<char *>(geom + L.sh_clamp) + off;
+    p.vis = (const float *)(geom + L.bin) + (narrow_bins(d) ? 1 : 2);
+    p.rec = (float *)const_cast<char *>(geom + L.rec);
+    p.clamp = (uint8_t *)const_cast<char *>(geom + L.sh_clamp);
     p.grec = nullptr; p.RF = L.rec_floats; p.g = lsr_in_grads{};
     p.has[0] = group_enabled(d, 0); p.has[1] = group_enabled(d, 1);
     p.ks[0] = p.has[0] ? d.sh_coeffs * 3 : 0;
@@ -493,14 +512,13 @@ static ShParams make_params(const lsr_dims &d, const lsr_inputs &in, const GeomL
         else hipLaunchKernelGGL((KERNEL<-1, 0>), __VA_ARGS__);                             \
     } while (0)
 
-hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s,
-                             const lsr_dims *layout, int view0) {
+hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s) {
     if (d.num_gaussians == 0) return hipSuccess;
     if (!group_enabled(d, 0) && !group_enabled(d, 1)) return hipSuccess;
-    const GeomLayout L = geom_layout(layout ? *layout : d);
-    const ShParams p = make_params(d, in, L, geom, view0);
+    const GeomLayout L = geom_layout(d);
+    const ShParams p = make_params(d, in, L, geom);
     const int degc = p.has[0] ? d.sh_degree : -1, coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
-    const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), block(kShThreads);
+    const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE, num_view_groups(d)), block(kShThreads);
     const size_t shm = ((size_t)p.offF + (size_t)LSR_WAVE * p.ks[1]) * 4;
     prof_begin(kStShFwd, s);
     LSR_SH_DISPATCH(k_sh_fwd, degc, coff, grid, block, shm, s, p);
@@ -516,15 +534,15 @@ static void allow_big_lds(size_t shm) {
 }
 
 hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom, const char *grad,
-                              const lsr_in_grads &gin, hipStream_t s, const lsr_dims *layout, int view0) {
+                              const lsr_in_grads &gin, hipStream_t s) {
     if (d.num_gaussians == 0) return hipSuccess;
     if (!group_enabled(d, 0) && !group_enabled(d, 1)) return hipSuccess;
-    const GeomLayout L = geom_layout(layout ? *layout : d);
-    const GradLayout R = grad_layout(layout ? *layout : d);
-    ShParams p = make_params(d, in, L, geom, view0);
-    p.grec = (const float *)(grad + R.rec) + (size_t)view0 * d.num_gaussians * R.rec_floats; p.g = gin;
+    const GeomLayout L = geom_layout(d);
+    const GradLayout R = grad_layout(d);
+    ShParams p = make_params(d, in, L, geom);
+    p.grec = (const float *)(grad + R.rec); p.g = gin;
     const int degc = p.has[0] ? d.sh_degree : -1, coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
-    const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE), block(kShThreads);
+    const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE, num_view_groups(d)), block(kShThreads);
     const int cs = (coff + d.feat_channels) | 1;
     const int area = std::max(p.offF + LSR_WAVE * p.ks[1], kShWaves * LSR_WAVE * kShBasisC);
     const size_t shm = ((size_t)area + (size_t)kShWaves * LSR_WAVE * cs) * 4;
