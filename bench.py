@@ -202,6 +202,57 @@ def decoder_step_timing(dev, steps=10, scenes=1):
     return res
 
 
+def path_step_timing(dev, steps=10):
+    """The three stages chained as the training step runs them (model_wrapper.py:361-385) at configs[3]'s shape:
+    Gaussian adapter tail (2 context cameras x 256^2 rays x 3 samples = 393 216 Gaussians, packed covariances)
+    -> DecoderSplattingCUDA.forward (1 x 4 views, colour SH 4 + latent SH 2) -> posterior sample + 1/8 rescale +
+    skip concatenation, gradients from the latent / skip / colour heads back to the raw adapter inputs
+    (tests/test_path_gpu.py checks the same chain against the chained CPU oracles)."""
+    from latentsplat_amd import decoder as dec
+    from latentsplat_amd.decoder.latent_epilogue import decoder_output_epilogue
+    from latentsplat_amd.gaussian_adapter import adapter_geometry
+    from latentsplat_amd.synthetic import make_scene
+    cams, rays, S, size = 2, 65536, 3, 256
+    G = cams * rays * S
+    g = torch.Generator().manual_seed(77)
+    ys, xs = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
+    coords = ((torch.stack([xs, ys], -1).reshape(rays, 2).float() + 0.5) / size)[None].repeat(cams, 1, 1).to(dev).requires_grad_()
+    E = torch.eye(4).repeat(cams, 1, 1)
+    E[1, 0, 3] = 0.3
+    K = torch.tensor([[0.8, 0, 0.5], [0, 0.8, 0.5], [0, 0, 1.0]]).repeat(cams, 1, 1)
+    depths = (1.5 + 8.0 * torch.rand(cams, rays, S, generator=g)).to(dev).requires_grad_()
+    raw = torch.randn(cams, rays, 7, generator=g).to(dev).requires_grad_()
+    sc = make_scene(G, image_size=size, views=4, color_sh_degree=4, feature_channels=4, feature_sh_degree=2, seed=77).to(dev)
+    E, K = E.to(dev), K.to(dev)
+    d = dec.get_decoder(dec.DecoderSplattingCUDACfg(name="splatting_cuda"), [0.0, 0.0, 0.0]).to(dev)
+    noise = torch.randn(1, 4, 4, size, size, device=dev)
+    gz = torch.randn(1, 4, 4, size // 8, size // 8, device=dev)
+    gs = torch.randn(1, 4, 7, size, size, device=dev)
+    gc = torch.randn(1, 4, 3, size, size, device=dev)
+
+    def chain():
+        means, cov, _, _ = adapter_geometry(E, K, coords, depths, raw, (size, size), 0.5, 15.0)
+        gauss = dec.Gaussians(means.reshape(1, G, 3), cov.reshape(1, G, 3, 3), sc.opacities[None], sc.color_sh[None], sc.feature_sh[None])
+        out = d.forward(gauss, sc.extrinsics[None], sc.intrinsics[None], sc.near[None], sc.far[None], (size, size))
+        return out, decoder_output_epilogue(out, 8, noise=noise)
+
+    def fwd():
+        with torch.no_grad():
+            chain()
+
+    def fwdbwd():
+        out, ep = chain()
+        torch.autograd.backward([ep.z, ep.skip_z, out.color], [gz, gs, gc])
+        coords.grad = depths.grad = raw.grad = None
+
+    res = {}
+    for name, fn in (("forward_ms", fwd), ("forward_backward_ms", fwdbwd)):
+        el = timed_region(fn, steps, 3, None, lambda: torch.cuda.synchronize(dev))
+        res[name] = 1e3 * el / steps
+    res["config"] = "configs[3] shape: adapter tail (393216 Gaussians) -> decoder (1 x 4 views, SH 4 + latent SH 2, 256x256) -> latent epilogue (factor 8)"
+    return res
+
+
 def adapter_step_timing(dev, steps=20):
     """the Gaussian adapter tail at the configs[3] shape (2 context cameras x 256^2
     rays x 3 depth samples = 393 216 Gaussians), raw parameters read as a strided view of the
@@ -674,6 +725,7 @@ def main():
         dec_step["batch4"] = decoder_step_timing(dev, scenes=4)      # configs[4]: batch_size 4 per GPU
         adapter_step = adapter_step_timing(dev)
         latent_step = latent_step_timing(dev)
+        path_step = path_step_timing(dev)
         if not args.no_cpu_baseline:
             nxt = cpu_baseline_next_rows()
             adapter_step["cpu_baseline"], latent_step["cpu_baseline"] = nxt["adapter"], nxt["latent"]
@@ -692,7 +744,7 @@ def main():
             "kernel_ms_per_launch": {k: (ms / n if n else None) for k, (ms, n) in prof.items()},
             "per_rank_ms_per_step": per_rank_fwd, "ms_per_step_spread": step_spread,
             "stage_roofline": stage_roofline, "roofline_bwd": roofline_bwd, "latency": latency, "pipelined": pipelined,
-            "fwdbwd": fb, "decoder_step": dec_step, "adapter_step": adapter_step, "latent_step": latent_step, "roofline": roofline, "roofline_valu": roofline_valu, "roofline_path": path, "cpu_baseline": cpu,
+            "fwdbwd": fb, "decoder_step": dec_step, "adapter_step": adapter_step, "latent_step": latent_step, "path_step": path_step, "roofline": roofline, "roofline_valu": roofline_valu, "roofline_path": path, "cpu_baseline": cpu,
         }
         # The whole dictionary goes to a side file; stdout carries ONE compact line (graded keys first, < 4 KB) so
         # that a driver record that truncates long lines still holds value / roofline / cpu_baseline / fwdbwd.

@@ -167,8 +167,11 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
             const float px = ndc2pix(ndc_x, d.width), py = ndc2pix(ndc_y, d.height);
             const int rminx = imin_sel(gx, imax_sel(0, (int)((px - my_radius) / LSR_TILE)));
             const int rminy = imin_sel(gy, imax_sel(0, (int)((py - my_radius) / LSR_TILE)));
-            const int rmaxx = imin_sel(gx, imax_sel(0, (int)((px + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
-            const int rmaxy = imin_sel(gy, imax_sel(0, (int)((py + my_radius + (LSR_TILE - 1)) / LSR_TILE)));
+            // ((p + r) + 16) - 1, in THIS order: the published expression `p.x + max_radius + BLOCK_X - 1` is evaluated left
+            // to right in float, and (p + r) + 15 rounds differently when p sits just below a pixel centre
+            // (x = 233.99998, r = 7: 256.99998 rounds up to 257 -> tile 16; 255.99998 is exact -> tile 15)
+            const int rmaxx = imin_sel(gx, imax_sel(0, (int)((((px + my_radius) + (float)LSR_TILE) - 1.0f) / LSR_TILE)));
+            const int rmaxy = imin_sel(gy, imax_sel(0, (int)((((py + my_radius) + (float)LSR_TILE) - 1.0f) / LSR_TILE)));
             ok = ok && (rmaxx - rminx) * (rmaxy - rminy) != 0;
 
             const float4 rr0 = make_float4(px, py, conic_a, conic_b);

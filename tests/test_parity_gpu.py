@@ -89,6 +89,27 @@ def test_forward_parity(hip_device, name):
     _check_forward(bi, run)
 
 
+def test_pixel_aligned_means_tile_rectangles(hip_device):
+    """Gaussians sitting on pixel centres (what the reference's encoder emits: one Gaussian per context-view ray)
+    project to x = k + 0.99998-type floats, where the published tile-rectangle expression
+    `(int)((p.x + max_radius + BLOCK_X - 1) / BLOCK_X)` depends on its left-to-right float evaluation order:
+    ((p + r) + 16) - 1 rounds up across a tile boundary where (p + r) + 15 does not.  Found by the chained path
+    test (tests/test_path_gpu.py) in round 3; rectangles, pair counts and lists must be bit-exact here too."""
+    S, G = 128, 128 * 128
+    sc = util.make_scene(G, image_size=S, views=2, color_sh_degree=0, feature_channels=4, seed=9, sigma_px=(0.3, 2.5))
+    ys, xs = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    u, v = (xs.reshape(-1).float() + 0.5) / S, (ys.reshape(-1).float() + 0.5) / S
+    z = sc.means[:, 2]
+    sc.means[:, 0] = (u - 0.5) / 0.8 * z
+    sc.means[:, 1] = (v - 0.5) / 0.8 * z
+    bi = util.boundary_inputs(sc, S, S)
+    run = util.HipRun(bi, hip_device)
+    o = util.oracle_forward(bi, 0)
+    frac = np.abs(o["xy"][o["radii"] > 0] % 1.0 - 0.5)          # distance from an integer pixel coordinate, 0.5 = on it
+    assert (frac > 0.4999).mean() > 0.5                          # the scene really is pixel aligned in view 0
+    _check_forward(bi, run)
+
+
 def _box_masks(xy, co, lst, tx0, ty0):
     """float64 restatement of the kernels' footprint box (lsr_blend.h footprint_cells) -> 16-bit sub-block masks."""
     A, B, C, o = (co[lst, k].astype(np.float64) for k in range(4))
