@@ -452,6 +452,7 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
     }
     *num_pairs_host = (int64_t)hdr[0];
     *max_tile_pairs_host = (int32_t)hdr[1];
+    if (hdr[0] == 0xFFFFFFFFu) return LSR_EUNSUPPORTED;   // more (Gaussian, tile) pairs than the 32-bit offsets address (count saturated)
     return LSR_OK;
 }
 

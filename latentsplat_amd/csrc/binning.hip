@@ -74,10 +74,25 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
     const int per = (N + kScanThreads - 1) / kScanThreads;
     const int lo = tid * per, hi = min(N, lo + per);
     uint32_t sum = 0, mx = 0;
-    for (int i = lo; i < hi; ++i) { const uint32_t c = count[i]; sum += c; mx = max(mx, c); }
+    uint64_t sum64 = 0;
+    for (int i = lo; i < hi; ++i) { const uint32_t c = count[i]; sum += c; sum64 += c; mx = max(mx, c); }
     uint32_t total;
     uint32_t run = block_exclusive_scan(sum, s_wave, total);   // exclusive prefix of this thread's chunk
     const uint32_t maxc = block_max(mx, s_wave);
+    // Offsets are 32-bit: a call whose pair count does not fit (possible in principle: every Gaussian can touch every
+    // tile of every view) is reported as an overflow with the count saturated, never silently wrapped.
+    __shared__ uint64_t s_tot64[kScanWaves];
+    {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum64 += __shfl_xor(sum64, off);
+        if ((tid & (LSR_WAVE - 1)) == 0) s_tot64[tid / LSR_WAVE] = sum64;
+        __syncthreads();
+        sum64 = 0;
+#pragma unroll
+        for (int w = 0; w < kScanWaves; ++w) sum64 += s_tot64[w];
+    }
+    const bool wrapped = sum64 > 0xFFFFFFFFull;
+    if (wrapped) total = 0xFFFFFFFFu;
     // Offsets are clamped to the capacity of the binning workspace: with exact sizing (capacity =
     // UINT32_MAX) nothing changes; in the no-sync forward a scene that produces more pairs than the
     // caller provided for gets its last lists truncated (never an out-of-bounds write) and the
@@ -85,7 +100,7 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
     for (int i = lo; i < hi; ++i) { start[i] = min(run, capacity); run += count[i]; }
     if (tid == kScanThreads - 1) {
         start[N] = min(total, capacity); header[kHdrPairs] = total; header[kHdrMaxTile] = maxc;
-        header[kHdrOverflow] = total > capacity ? 1u : 0u;
+        header[kHdrOverflow] = (total > capacity || wrapped) ? 1u : 0u;
         // the two numbers the host is waiting for go straight into its (mapped, pinned) memory:
         // no copy command between this kernel and the stream synchronisation
         if (host_mirror) { host_mirror[0] = total; host_mirror[1] = maxc; }
@@ -218,7 +233,11 @@ k_scatter(int G, int gx, int T, int view0, const char *__restrict__ binrec,
                 if (LDS_RESERVE) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
                 else pos = ts[t] + atomicAdd(&cur[t], 1u);
                 const uint32_t code = span_code(sp, x - x0, y - y0);
-                if (!CHECK || pos < capacity) keys[pos] = key | code;   // CHECK (no-sync forward): tile_scan clamped the offsets to the workspace capacity
+                // The position is CLAMPED to the workspace (one v_min; a store under a per-lane bounds test cost 17 % of
+                // this kernel): in the no-sync forward tile_scan clamps the offsets to the capacity, in the synchronous one
+                // the capacity is the host's early pair count — if that ever came out short, the surplus pairs land
+                // on the last slot and the sort flags the overflow; never an out-of-bounds write.
+                keys[min(pos, capacity - 1u)] = key | code;
             }
     }
     LSR_STAMP(4);
@@ -242,6 +261,8 @@ constexpr int kSortThreads = 512;
 // Where k_sort_tiles puts the two half-tile render lists of a tile (BinLayout::half_list, GeomLayout::half_count).
 struct HalfOut {
     uint32_t *half_list, *half_count;
+    uint32_t *header;         // geometry-workspace header (overflow flag)
+    uint32_t capacity;        // pairs the binning workspace holds
 };
 __device__ __forceinline__ uint32_t key_index(uint32_t low_word) { return low_word >> kKeyIndexShift; }
 constexpr int kEmitTab = 130;   // uint64 words of LDS scratch emit_half_lists needs
@@ -346,6 +367,11 @@ k_sort_tiles(int T, int view0, const uint32_t *__restrict__ tile_start, const ui
     const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
     uint32_t *hcnt = ho.half_count + 2 * vt, *hdst = ho.half_list + 2 * (size_t)start;
     if (n == 0) { if (longer_than == 0 && tid < 2) hcnt[tid] = 0; return; }
+    if ((uint64_t)start + n > ho.capacity) {      // a list beyond the workspace (synchronous forward: the host's count was short): flag, render nothing
+        if (tid < 2) hcnt[tid] = 0;
+        if (tid == 0) ho.header[kHdrOverflow] = 1u;
+        return;
+    }
     if (n <= longer_than) return;   // shorter lists belong to another launch (no-sync forward: two variants)
     if (n > (uint32_t)CAP) return;  // handled by a larger variant / the global-memory path
     const uint64_t *src = keys + start;
@@ -548,6 +574,11 @@ k_sort_tiles_global(int T, int view0, uint32_t cap, const uint32_t *__restrict__
     const size_t vt = blockIdx.x + (size_t)view0 * T;   // view-major (view, tile)
     const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
     if (n <= cap) return;
+    if ((uint64_t)start + n > ho.capacity) {
+        if (threadIdx.x < 2) ho.half_count[2 * vt + threadIdx.x] = 0;
+        if (threadIdx.x == 0) ho.header[kHdrOverflow] = 1u;
+        return;
+    }
     uint64_t *src = keys + start, *dst = tmp + start;
     // width-1 runs are trivially sorted; keys are unique (index in the low word) so ranks are exact
     for (uint32_t w = 1; w < n; w <<= 1) {
@@ -585,6 +616,8 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     const uint32_t *ts = (const uint32_t *)(geom + L.tile_start);
     HalfOut ho;
     ho.half_list = (uint32_t *)(bin + B.half_list); ho.half_count = (uint32_t *)(geom + L.half_count);
+    ho.header = (uint32_t *)(geom + L.header);
+    ho.capacity = (uint32_t)(num_pairs < 0xFFFFFFFFll ? num_pairs : 0xFFFFFFFFll);
     {
         const bool lds = T <= 8192;
         // Items per thread: the launch should be ONE round of resident workgroups (8 per CU, fewer when
@@ -611,8 +644,8 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     hipLaunchKernelGGL((k_scatter<LDSR, CHK, NRW>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T, vc.view0, \
                        (const char *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, strace)
 #define LSR_SCAT(LDSR, CHK, SHM) do { if (narrow_bins(d)) LSR_SCAT2(LDSR, CHK, true, SHM); else LSR_SCAT2(LDSR, CHK, false, SHM); } while (0)
-        if (lds) { if (device_counts) LSR_SCAT(true, true, (size_t)T * 8); else LSR_SCAT(true, false, (size_t)T * 8); }
-        else { if (device_counts) LSR_SCAT(false, true, 0); else LSR_SCAT(false, false, 0); }
+        if (lds) LSR_SCAT(true, false, (size_t)T * 8);
+        else LSR_SCAT(false, false, 0);
 #undef LSR_SCAT
 #undef LSR_SCAT2
         prof_end(kStScatter, s);

@@ -242,7 +242,8 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
     // (measured: the forward went from 0.56 to 0.83 ms per step).  k_tile_scan computes the same two
     // numbers again for the device side. ----
     if (host_mirror) {
-        __shared__ uint32_t s_last, s_sum[kPreThreads / LSR_WAVE], s_max[kPreThreads / LSR_WAVE];
+        __shared__ uint32_t s_last, s_max[kPreThreads / LSR_WAVE];
+        __shared__ uint64_t s_sum[kPreThreads / LSR_WAVE];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -252,7 +253,8 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
         __syncthreads();
         if (s_last) {
             const int N = d.num_views * T;
-            uint32_t sum = 0, mx = 0;
+            uint64_t sum = 0;          // (64-bit: the total may exceed the 32-bit offsets; reported saturated)
+            uint32_t mx = 0;
             for (int t0 = threadIdx.x; t0 < N; t0 += 8 * kPreThreads) {   // eight loads in flight per thread
                 uint32_t c[8];
 #pragma unroll
@@ -266,16 +268,17 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
-                sum += (uint32_t)__shfl_xor((int)sum, off);
+                sum += __shfl_xor(sum, off);
                 mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
             }
             if ((threadIdx.x & (LSR_WAVE - 1)) == 0) { s_sum[threadIdx.x / LSR_WAVE] = sum; s_max[threadIdx.x / LSR_WAVE] = mx; }
             __syncthreads();
             if (threadIdx.x == 0) {
-                uint32_t ts = 0, tm = 0;
+                uint64_t ts = 0;
+                uint32_t tm = 0;
 #pragma unroll
                 for (int w = 0; w < kPreThreads / LSR_WAVE; ++w) { ts += s_sum[w]; tm = max(tm, s_max[w]); }
-                host_mirror[0] = ts; host_mirror[1] = tm;
+                host_mirror[0] = ts > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ts; host_mirror[1] = tm;
             }
         }
     }
