@@ -685,13 +685,21 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
                            (size_t)CAPV * 8 + (size_t)(CAPV < 2048 ? CAPV : 2048) * 4, s,        \
                            T, vc.view0, ts, (const uint64_t *)keys, plist, ho, longer_than, trace); \
     } while (0)
+        // The register-resident variants (lists <= 4096) are about twice as fast per list as the larger ones, and ONE
+        // long list used to push every tile of the call through the slow variant (decoder configs[3]: longest list
+        // ~4.5 k, all 1024 tiles in k_sort_tiles<8192>).  Lists beyond 4096 get a second launch of their own
+        // (workgroups of the other tier exit at once).
         if (max_tile_pairs <= 1024) LSR_SORT(1024);
         else if (max_tile_pairs <= 2048) LSR_SORT(2048);
-        else if (max_tile_pairs <= 4096) LSR_SORT(4096);
-        else if (max_tile_pairs <= 8192) LSR_SORT(8192);
-        else LSR_SORT(16384);
+        else LSR_SORT(4096);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
+        if (!device_counts && max_tile_pairs > 4096) {
+            longer_than = 4096u;
+            if (max_tile_pairs <= 8192) LSR_SORT(8192); else LSR_SORT(16384);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
         if (device_counts && cap < kSortLdsMax) {
             // the longest list is only a hint here: lists beyond the chosen variant take the largest
             // LDS variant (blocks with nothing to do exit at once), anything longer the merge path

@@ -14,7 +14,7 @@ def short(name):
     return name[:60]
 
 
-def write_traffic_json(root, acc, path, kernel="lsr::k_render_fwd"):
+def write_traffic_json(root, acc, path, kernel="lsr::k_render_fwd<4"):
     """profiles/traffic_render_forward.json: HBM bytes per launch of the dominant kernel, read by
     bench.py for roofline.traffic."""
     import json
