@@ -263,6 +263,12 @@ struct HalfOut {
     uint32_t *half_list, *half_count;
     uint32_t *header;         // geometry-workspace header (overflow flag)
     uint32_t capacity;        // pairs the binning workspace holds
+    // Tiles whose list is longer than a launch's variant handles are appended here by that launch ((view, tile)
+    // indices; the scatter's cursor array is free by then) and picked up by the next tier's PERSISTENT launch: a
+    // few hundred workgroups looping over the list instead of one (large-LDS, two-per-CU) workgroup per tile that
+    // finds nothing to do — the empty second-tier launch over 4096 tiles cost 93 us.
+    uint32_t *long_list[2];   // [0]: beyond the first tier, [1]: beyond the LDS sort altogether (global merge path)
+    uint32_t *long_count[2];  // header words
 };
 __device__ __forceinline__ uint32_t key_index(uint32_t low_word) { return low_word >> kKeyIndexShift; }
 constexpr int kEmitTab = 130;   // uint64 words of LDS scratch emit_half_lists needs
@@ -345,10 +351,11 @@ __device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint
 // 4096-key workgroups share a CU's 160 KB.
 constexpr uint32_t kBucketOverflow = 48;   // longest bucket the in-bucket pass may get
 
+// tier: 0 = first launch of a call (also owns the empty lists), 1 = a later tier (its tiles come from a long list)
 template <int CAP>
-__global__ void __launch_bounds__(kSortThreads)
-k_sort_tiles(int T, int view0, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
-             uint32_t *__restrict__ point_list, HalfOut ho, uint32_t longer_than, unsigned long long *trace) {
+__device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier, const uint32_t *__restrict__ tile_start,
+                                          const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
+                                          const HalfOut &ho, unsigned long long *trace) {
 #ifdef LSR_ENABLE_TRACE
 #define LSR_STAMP(k) do { if (trace && threadIdx.x == 0) trace[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
 #else
@@ -357,23 +364,26 @@ k_sort_tiles(int T, int view0, const uint32_t *__restrict__ tile_start, const ui
     LSR_STAMP(0);
     constexpr int NB = CAP < 2048 ? CAP : 2048;          // buckets
     constexpr int kWaves = kSortThreads / LSR_WAVE;
-    extern __shared__ uint64_t s_keys[];                  // [CAP] keys grouped by bucket / sorted
     uint32_t *s_cnt = (uint32_t *)(s_keys + CAP);         // [NB] histogram -> bucket offsets
     uint64_t *s_red = s_keys;                             // [2 * kWaves] range reduction  } alias the key array:
     uint32_t *s_wsum = (uint32_t *)(s_keys + 2 * kWaves); // [kWaves] scan partials        } dead before the
     uint32_t *s_flag = s_wsum + kWaves;                   // bucket overflow               } first key is placed
     const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
-    const size_t vt = blockIdx.x + (size_t)view0 * T;   // view-major (view, tile)
     const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
     uint32_t *hcnt = ho.half_count + 2 * vt, *hdst = ho.half_list + 2 * (size_t)start;
-    if (n == 0) { if (longer_than == 0 && tid < 2) hcnt[tid] = 0; return; }
+    if (n == 0) { if (tid < 2) hcnt[tid] = 0; return; }
     if ((uint64_t)start + n > ho.capacity) {      // a list beyond the workspace (synchronous forward: the host's count was short): flag, render nothing
         if (tid < 2) hcnt[tid] = 0;
         if (tid == 0) ho.header[kHdrOverflow] = 1u;
         return;
     }
-    if (n <= longer_than) return;   // shorter lists belong to another launch (no-sync forward: two variants)
-    if (n > (uint32_t)CAP) return;  // handled by a larger variant / the global-memory path
+    if (n > (uint32_t)CAP) {        // for the next tier: a larger LDS variant, or (beyond the largest) the global merge path
+        if (tid == 0) {
+            const int which = n > (uint32_t)kSortLdsMax ? 1 : 0;
+            ho.long_list[which][atomicAdd(ho.long_count[which], 1u)] = (uint32_t)vt;
+        }
+        return;
+    }
     const uint64_t *src = keys + start;
     if (n == 1) {
         if (tid == 0) {
@@ -559,6 +569,25 @@ k_sort_tiles(int T, int view0, const uint32_t *__restrict__ tile_start, const ui
 #undef LSR_STAMP
 }
 
+// PERSISTENT = false: one workgroup per (view, tile) of the launch's view chunk (first tier); true: workgroups looping
+// over the previous tier's long list.  (Two kernels rather than one with a runtime switch: with both paths in one
+// body the first-tier variant needed 112 instead of 80 VGPRs and lost a resident workgroup per CU.)
+template <int CAP, bool PERSISTENT>
+__global__ void __launch_bounds__(kSortThreads)
+k_sort_tiles(int T, int view0, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
+             uint32_t *__restrict__ point_list, HalfOut ho, unsigned long long *trace) {
+    extern __shared__ uint64_t s_keys[];                  // [CAP] keys grouped by bucket / sorted, then [NB] u32 counters
+    if (!PERSISTENT) {
+        sort_tile<CAP>(s_keys, blockIdx.x + (size_t)view0 * T, 0, tile_start, keys, point_list, ho, trace);
+    } else {
+        const uint32_t count = *ho.long_count[0];
+        for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+            sort_tile<CAP>(s_keys, ho.long_list[0][i], 1, tile_start, keys, point_list, ho, trace);
+            __syncthreads();   // the LDS arrays are reused by the next tile
+        }
+    }
+}
+
 // Global-memory path for lists longer than the LDS capacity: bottom-up merge sort by one
 // workgroup per oversized tile (rank-by-binary-search merges, ping-pong between keys and tmp).
 // Rare (needs > kSortLdsMax Gaussians over one 16x16 tile); correctness path, not tuned.
@@ -568,37 +597,34 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t 
     return lo;
 }
 __global__ void __launch_bounds__(kSortThreads)
-k_sort_tiles_global(int T, int view0, uint32_t cap, const uint32_t *__restrict__ tile_start,
-                    uint64_t *keys, uint64_t *tmp, uint32_t *point_list, HalfOut ho) {
+k_sort_tiles_global(const uint32_t *__restrict__ tile_start, uint64_t *keys, uint64_t *tmp, uint32_t *point_list, HalfOut ho) {
     __shared__ uint64_t s_tab[kEmitTab];
-    const size_t vt = blockIdx.x + (size_t)view0 * T;   // view-major (view, tile)
-    const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
-    if (n <= cap) return;
-    if ((uint64_t)start + n > ho.capacity) {
-        if (threadIdx.x < 2) ho.half_count[2 * vt + threadIdx.x] = 0;
-        if (threadIdx.x == 0) ho.header[kHdrOverflow] = 1u;
-        return;
-    }
-    uint64_t *src = keys + start, *dst = tmp + start;
-    // width-1 runs are trivially sorted; keys are unique (index in the low word) so ranks are exact
-    for (uint32_t w = 1; w < n; w <<= 1) {
-        for (uint32_t i = threadIdx.x; i < n; i += kSortThreads) {
-            const uint32_t pair = i / (2 * w), a0 = pair * 2 * w;
-            const uint32_t a1 = min(a0 + w, n), b1 = min(a0 + 2 * w, n);
-            const uint64_t x = src[i];
-            uint32_t pos;
-            if (i < a1) pos = a0 + (i - a0) + lower_bound_u64(src + a1, b1 - a1, x);
-            else pos = a0 + (i - a1) + lower_bound_u64(src + a0, a1 - a0, x);
-            dst[pos] = x;
+    const uint32_t count = *ho.long_count[1];
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {   // persistent over the tiles beyond the LDS sort
+        const size_t vt = ho.long_list[1][it];
+        const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
+        uint64_t *src = keys + start, *dst = tmp + start;
+        // width-1 runs are trivially sorted; keys are unique (index in the low word) so ranks are exact
+        for (uint32_t w = 1; w < n; w <<= 1) {
+            for (uint32_t i = threadIdx.x; i < n; i += kSortThreads) {
+                const uint32_t pair = i / (2 * w), a0 = pair * 2 * w;
+                const uint32_t a1 = min(a0 + w, n), b1 = min(a0 + 2 * w, n);
+                const uint64_t x = src[i];
+                uint32_t pos;
+                if (i < a1) pos = a0 + (i - a0) + lower_bound_u64(src + a1, b1 - a1, x);
+                else pos = a0 + (i - a1) + lower_bound_u64(src + a0, a1 - a0, x);
+                dst[pos] = x;
+            }
+            __threadfence_block();
+            __syncthreads();
+            uint64_t *t = src; src = dst; dst = t;
         }
-        __threadfence_block();
+        for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
+            point_list[start + i] = key_index((uint32_t)src[i]);
+        const uint64_t *sorted = src;
+        emit_half_lists(n, ho.half_list + 2 * (size_t)start, ho.half_count + 2 * vt, s_tab, [&](uint32_t p) { return (uint32_t)sorted[p]; });
         __syncthreads();
-        uint64_t *t = src; src = dst; dst = t;
     }
-    for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
-        point_list[start + i] = key_index((uint32_t)src[i]);
-    const uint64_t *sorted = src;
-    emit_half_lists(n, ho.half_list + 2 * (size_t)start, ho.half_count + 2 * vt, s_tab, [&](uint32_t p) { return (uint32_t)sorted[p]; });
 }
 
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
@@ -618,6 +644,14 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     ho.half_list = (uint32_t *)(bin + B.half_list); ho.half_count = (uint32_t *)(geom + L.half_count);
     ho.header = (uint32_t *)(geom + L.header);
     ho.capacity = (uint32_t)(num_pairs < 0xFFFFFFFFll ? num_pairs : 0xFFFFFFFFll);
+    // long-tile lists: the two halves of this chunk's part of the scatter cursor array (free once k_scatter is done;
+    // a list holds at most the chunk's tiles), counters in the header (cleared per forward)
+    {
+        uint32_t *cur = (uint32_t *)(geom + L.tile_cursor) + (size_t)vc.view0 * T;
+        const size_t half = ((size_t)vc.num_views * T + 1) / 2;
+        ho.long_list[0] = cur; ho.long_list[1] = cur + half;
+        ho.long_count[0] = ho.header + kHdrLongTiles + 2 * vc.index; ho.long_count[1] = ho.long_count[0] + 1;
+    }
     {
         const bool lds = T <= 8192;
         // Items per thread: the launch should be ONE round of resident workgroups (8 per CU, fewer when
@@ -671,47 +705,36 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
             (void)hipMemsetAsync(trace, 0, (size_t)grid.x * 64, s);
         }
 #endif
-        int cap;
-        uint32_t longer_than = 0;
+        // Tiers: (1) one workgroup per tile with the register-resident variant that fits the expected longest list
+        // (at most 4096: these are about twice as fast per list as the larger ones); longer lists are appended to a
+        // list by that launch and sorted by (2) a persistent launch of the largest LDS variant and (3) one of the
+        // global merge path.  Tiers 2 / 3 are launched when the host knows they are needed (synchronous forward) or
+        // cannot know (no-sync forward: a few hundred workgroups that find an empty list).
         prof_begin(kStSort, s);
-#define LSR_SORT(CAPV)                                                                           \
+#define LSR_SORT(CAPV, GRID, PERS)                                                               \
     do {                                                                                         \
-        cap = CAPV;                                                                              \
         if ((size_t)CAPV * 8 + 16384 > 65536)                                                    \
-            (void)hipFuncSetAttribute((const void *)k_sort_tiles<CAPV>,                          \
+            (void)hipFuncSetAttribute((const void *)k_sort_tiles<CAPV, PERS>,                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize,                \
                                       CAPV * 8 + (CAPV < 2048 ? CAPV : 2048) * 4);               \
-        hipLaunchKernelGGL((k_sort_tiles<CAPV>), grid, dim3(kSortThreads),                       \
+        hipLaunchKernelGGL((k_sort_tiles<CAPV, PERS>), GRID, dim3(kSortThreads),                 \
                            (size_t)CAPV * 8 + (size_t)(CAPV < 2048 ? CAPV : 2048) * 4, s,        \
-                           T, vc.view0, ts, (const uint64_t *)keys, plist, ho, longer_than, trace); \
+                           T, vc.view0, ts, (const uint64_t *)keys, plist, ho, trace);           \
     } while (0)
-        // The register-resident variants (lists <= 4096) are about twice as fast per list as the larger ones, and ONE
-        // long list used to push every tile of the call through the slow variant (decoder configs[3]: longest list
-        // ~4.5 k, all 1024 tiles in k_sort_tiles<8192>).  Lists beyond 4096 get a second launch of their own
-        // (workgroups of the other tier exit at once).
-        if (max_tile_pairs <= 1024) LSR_SORT(1024);
-        else if (max_tile_pairs <= 2048) LSR_SORT(2048);
-        else LSR_SORT(4096);
+        if (max_tile_pairs <= 1024) LSR_SORT(1024, grid, false);
+        else if (max_tile_pairs <= 2048) LSR_SORT(2048, grid, false);
+        else LSR_SORT(4096, grid, false);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        if (!device_counts && max_tile_pairs > 4096) {
-            longer_than = 4096u;
-            if (max_tile_pairs <= 8192) LSR_SORT(8192); else LSR_SORT(16384);
-            e = hipGetLastError();
-            if (e != hipSuccess) return e;
-        }
-        if (device_counts && cap < kSortLdsMax) {
-            // the longest list is only a hint here: lists beyond the chosen variant take the largest
-            // LDS variant (blocks with nothing to do exit at once), anything longer the merge path
-            longer_than = (uint32_t)cap;
-            LSR_SORT(16384);
+        const dim3 pgrid((uint32_t)device_cus());
+        if (device_counts || max_tile_pairs > 4096) {
+            LSR_SORT(16384, pgrid, true);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }
 #undef LSR_SORT
-        if (device_counts || max_tile_pairs > cap) {
-            hipLaunchKernelGGL(k_sort_tiles_global, grid, dim3(kSortThreads), 0, s, T, vc.view0, (uint32_t)cap,
-                               ts, keys, (uint64_t *)(bin + B.tmp), plist, ho);
+        if (device_counts || max_tile_pairs > kSortLdsMax) {
+            hipLaunchKernelGGL(k_sort_tiles_global, pgrid, dim3(kSortThreads), 0, s, ts, keys, (uint64_t *)(bin + B.tmp), plist, ho);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }

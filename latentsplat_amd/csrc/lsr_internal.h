@@ -169,7 +169,8 @@ inline int wave_slots(int cus) { return cus * 4 * 4; }   // (at 4 resident compo
 // Environment knobs are development aids; each is read ONCE per process (never on the launch path).
 int env_int(const char *name, int fallback);        // api.hip: latched on first use
 // header words of the geometry workspace (kHdrQueueFwd + c: work-queue head of view chunk c, c < kMaxViewChunks)
-enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrNumItems = 3, kHdrOverflow = 4, kHdrPreDone = 5, kHdrQueueFwd = 8 };
+enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrNumItems = 3, kHdrOverflow = 4, kHdrPreDone = 5, kHdrQueueFwd = 8,
+       kHdrLongTiles = 16 /* + 2 c, + 2 c + 1: tiles of view chunk c beyond the first sort tier / beyond the LDS sort */ };
 
 // ---- view chunks (pipelined forward) ----
 // A forward call over V views runs its binning + compositing as K chunks of V / K consecutive views: chunk
