@@ -42,6 +42,17 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
+// acc += splat(src.lo or src.hi) * ww as ONE packed instruction: the broadcast of one half of a register pair is the
+// instruction's op_sel modifier.  (Left to the compiler, every other broadcast of a HIGH half cost a v_mov first:
+// four per iteration of the compositing loop, 1.1e7 of 9.7e7 VALU instructions per 16-view launch.)
+// The operands are never results of the immediately preceding instruction (they come from LDS reads, selects and
+// the previous iteration), which is what the packed-result forwarding hazard of gfx940+ would need a wait state for.
+template <bool HI>
+__device__ __forceinline__ void pk_fma_splat(float2_t &acc, float2_t src, float2_t ww) {
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(src), "v"(ww));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(src), "v"(ww));
+}
+
 struct RenderFwdParams {
     int H, W, gx, T, G, C, has_color;
     int num_cus;                  // compute units
@@ -262,10 +273,12 @@ k_render_fwd(RenderFwdParams p) {
                 const float w1 = __builtin_amdgcn_inverse_ballot_w64(ok1 & room1) ? aT.y : 0.0f;
                 const float2_t ww = float2_t{w0, w1};
 #pragma unroll
-                for (int c = 0; c < NCHP; ++c)
-                    acc[c] = __builtin_elementwise_fma((c & 1) ? float2_t{pay[c / 2].y, pay[c / 2].y} : float2_t{pay[c / 2].x, pay[c / 2].x}, ww, acc[c]);
-                D2 = __builtin_elementwise_fma(float2_t{zk.x, zk.x}, ww, D2);
-                T2 = __builtin_elementwise_fma(ww, float2_t{zk.y, zk.y}, T2);
+                for (int c = 0; c < NCHP; c += 2) {
+                    pk_fma_splat<false>(acc[c], pay[c / 2], ww);
+                    pk_fma_splat<true>(acc[c + 1], pay[c / 2], ww);
+                }
+                pk_fma_splat<false>(D2, zk, ww);     // depth  += (z / 255) w'
+                pk_fma_splat<true>(T2, zk, ww);      // T      -= w' / 255
                 if (stop0 | stop1) {  // rare, wave-uniform: a pixel's transmittance ran out here
                     // 1-based list position of the stopping entry, from its staging slot
                     const uint32_t pos = base + 1u + (off - wave_off) / (uint32_t)(kEnt * 16);
