@@ -47,6 +47,21 @@ typedef float float2_t __attribute__((ext_vector_type(2)));
 // four per iteration of the compositing loop, 1.1e7 of 9.7e7 VALU instructions per 16-view launch.)
 // The operands are never results of the immediately preceding instruction (they come from LDS reads, selects and
 // the previous iteration), which is what the packed-result forwarding hazard of gfx940+ would need a wait state for.
+
+// packed multiply / multiply-add as inline asm: the compiler's hazard recognizer puts a wait state behind every
+// packed-f32 instruction whose result the next instruction reads (it keys on a modifier bit that is set by default);
+// tools/microbench/pk_hazard.hip shows the hardware needs none.
+__device__ __forceinline__ float2_t pk_mul_nw(float2_t a, float2_t b) {
+    float2_t d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// a * splat(b.hi) + c
+__device__ __forceinline__ float2_t pk_fma_bhi_nw(float2_t a, float2_t b, float2_t c) {
+    float2_t d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 template <bool HI>
 __device__ __forceinline__ void pk_fma_splat(float2_t &acc, float2_t src, float2_t ww) {
     if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(acc) : "v"(src), "v"(ww));
@@ -168,6 +183,8 @@ k_render_fwd(RenderFwdParams p) {
 #pragma unroll
         for (int c = 0; c < NCHP; ++c) acc[c] = float2_t{0.0f, 0.0f};
         uint32_t stop_pos0 = 0, stop_pos1 = 0;
+        float kmax = kAlphaMax255;
+        asm volatile("" : "+v"(kmax));   // kept in a register: as a literal it makes both v_min 64-bit encodings
         // lanes whose two pixels are both finished (only consulted between batches)
         uint64_t done0 = __ballot(!inside0), done1 = __ballot(!inside1);
 
@@ -261,12 +278,12 @@ k_render_fwd(RenderFwdParams p) {
                 const float s = __builtin_fmaf(a.w * dy, dy, b.y);
                 const float2_t p1 = __builtin_elementwise_fma(float2_t{a.z, a.z}, d2, float2_t{t, t});
                 const float2_t ex = __builtin_elementwise_fma(p1, d2, float2_t{s, s});
-                const float2_t al = float2_t{fminf(kAlphaMax255, fast_exp2(ex.x)), fminf(kAlphaMax255, fast_exp2(ex.y))};   // 255 alpha
+                const float2_t al = float2_t{fminf(kmax, fast_exp2(ex.x)), fminf(kmax, fast_exp2(ex.y))};   // 255 alpha
                 // keep <=> 0 <= e' <= l2o' (alpha >= 1/255 and power <= 0): one unsigned comparison of the float bits
                 const uint32_t lim = __float_as_uint(b.y);
                 const uint64_t ok0 = __ballot(__float_as_uint(ex.x) <= lim), ok1 = __ballot(__float_as_uint(ex.y) <= lim);
-                const float2_t aT = al * T2;                                                   // 255 alpha T
-                const float2_t tT = __builtin_elementwise_fma(aT, float2_t{b.w, b.w}, T2);    // T (1 - alpha)
+                const float2_t aT = pk_mul_nw(al, T2);                                                   // 255 alpha T
+                const float2_t tT = pk_fma_bhi_nw(aT, zk, T2);    // T (1 - alpha)
                 const uint64_t room0 = __ballot(tT.x >= LSR_T_EPS), room1 = __ballot(tT.y >= LSR_T_EPS);
                 const uint64_t stop0 = ok0 & ~room0, stop1 = ok1 & ~room1;
                 const float w0 = __builtin_amdgcn_inverse_ballot_w64(ok0 & room0) ? aT.x : 0.0f;
