@@ -263,13 +263,22 @@ struct HalfOut {
     uint32_t *half_list, *half_count;
     uint32_t *header;         // geometry-workspace header (overflow flag)
     uint32_t capacity;        // pairs the binning workspace holds
-    // Tiles whose list is longer than a launch's variant handles are appended here by that launch ((view, tile)
-    // indices; the scatter's cursor array is free by then) and picked up by the next tier's PERSISTENT launch: a
-    // few hundred workgroups looping over the list instead of one (large-LDS, two-per-CU) workgroup per tile that
+    // Tiles whose list is longer than the first launch's variant handles are appended here by that launch ((view, tile)
+    // indices; the scatter's cursor array is free by then) and picked up by PERSISTENT launches of the larger
+    // variants: a few hundred workgroups looping over a list instead of one (large-LDS) workgroup per tile that
     // finds nothing to do — the empty second-tier launch over 4096 tiles cost 93 us.
-    uint32_t *long_list[2];   // [0]: beyond the first tier, [1]: beyond the LDS sort altogether (global merge path)
+    // Two lists share the array from its two ends (a tile is in at most one, so they cannot meet):
+    //   class 0, from the front: kSortTier1 < n <= kSortTier2   -> k_sort_tiles<kSortTier2, true>
+    //   class 1, from the back :  n > kSortTier2                -> k_sort_tiles<kSortLdsMax, true>, and for
+    //                                                              n > kSortLdsMax the global merge path
+    uint32_t *long_list;
+    uint32_t long_cap;        // entries of the array (tiles of the launch's view chunk)
     uint32_t *long_count[2];  // header words
 };
+constexpr int kSortTier1 = 4096, kSortTier2 = 8192;
+__device__ __forceinline__ uint32_t long_tile(const HalfOut &ho, int cls, uint32_t i) {
+    return ho.long_list[cls ? ho.long_cap - 1u - i : i];
+}
 __device__ __forceinline__ uint32_t key_index(uint32_t low_word) { return low_word >> kKeyIndexShift; }
 constexpr int kEmitTab = 130;   // uint64 words of LDS scratch emit_half_lists needs
 
@@ -377,10 +386,11 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
         if (tid == 0) ho.header[kHdrOverflow] = 1u;
         return;
     }
-    if (n > (uint32_t)CAP) {        // for the next tier: a larger LDS variant, or (beyond the largest) the global merge path
-        if (tid == 0) {
-            const int which = n > (uint32_t)kSortLdsMax ? 1 : 0;
-            ho.long_list[which][atomicAdd(ho.long_count[which], 1u)] = (uint32_t)vt;
+    if (n > (uint32_t)CAP) {        // for a later tier: a larger LDS variant, or (beyond the largest) the global merge path
+        if (tid == 0 && tier == 0) {
+            const int cls = n > (uint32_t)kSortTier2 ? 1 : 0;
+            const uint32_t i = atomicAdd(ho.long_count[cls], 1u);
+            ho.long_list[cls ? ho.long_cap - 1u - i : i] = (uint32_t)vt;
         }
         return;
     }
@@ -399,7 +409,7 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
         return;
     }
 
-    constexpr bool REG = CAP <= 4096;
+    constexpr bool REG = true;   // every LDS variant keeps its keys in registers (the 16 384-key one: 32 keys per thread, 256 VGPRs)
     constexpr int PERK = REG ? CAP / kSortThreads : 1;
     uint64_t kreg[PERK];
     if (REG) {
@@ -573,16 +583,17 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
 // over the previous tier's long list.  (Two kernels rather than one with a runtime switch: with both paths in one
 // body the first-tier variant needed 112 instead of 80 VGPRs and lost a resident workgroup per CU.)
 template <int CAP, bool PERSISTENT>
-__global__ void __launch_bounds__(kSortThreads)
+__global__ void __launch_bounds__(kSortThreads, CAP <= 4096 ? 6 : (CAP <= 8192 ? 4 : 2))   // waves per SIMD at the workgroups per CU the LDS allows (4 / 2 / 1): the register budget follows
 k_sort_tiles(int T, int view0, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
              uint32_t *__restrict__ point_list, HalfOut ho, unsigned long long *trace) {
     extern __shared__ uint64_t s_keys[];                  // [CAP] keys grouped by bucket / sorted, then [NB] u32 counters
     if (!PERSISTENT) {
         sort_tile<CAP>(s_keys, blockIdx.x + (size_t)view0 * T, 0, tile_start, keys, point_list, ho, trace);
     } else {
-        const uint32_t count = *ho.long_count[0];
+        const int cls = view0;     // persistent launches: the class of long tiles this launch owns
+        const uint32_t count = *ho.long_count[cls];
         for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-            sort_tile<CAP>(s_keys, ho.long_list[0][i], 1, tile_start, keys, point_list, ho, trace);
+            sort_tile<CAP>(s_keys, long_tile(ho, cls, i), 1, tile_start, keys, point_list, ho, trace);
             __syncthreads();   // the LDS arrays are reused by the next tile
         }
     }
@@ -601,8 +612,9 @@ k_sort_tiles_global(const uint32_t *__restrict__ tile_start, uint64_t *keys, uin
     __shared__ uint64_t s_tab[kEmitTab];
     const uint32_t count = *ho.long_count[1];
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {   // persistent over the tiles beyond the LDS sort
-        const size_t vt = ho.long_list[1][it];
+        const size_t vt = long_tile(ho, 1, it);
         const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
+        if (n <= (uint32_t)kSortLdsMax) continue;   // the class's shorter lists belong to the largest LDS variant
         uint64_t *src = keys + start, *dst = tmp + start;
         // width-1 runs are trivially sorted; keys are unique (index in the low word) so ranks are exact
         for (uint32_t w = 1; w < n; w <<= 1) {
@@ -647,9 +659,8 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     // long-tile lists: the two halves of this chunk's part of the scatter cursor array (free once k_scatter is done;
     // a list holds at most the chunk's tiles), counters in the header (cleared per forward)
     {
-        uint32_t *cur = (uint32_t *)(geom + L.tile_cursor) + (size_t)vc.view0 * T;
-        const size_t half = ((size_t)vc.num_views * T + 1) / 2;
-        ho.long_list[0] = cur; ho.long_list[1] = cur + half;
+        ho.long_list = (uint32_t *)(geom + L.tile_cursor) + (size_t)vc.view0 * T;
+        ho.long_cap = (uint32_t)vc.num_views * (uint32_t)T;
         ho.long_count[0] = ho.header + kHdrLongTiles + 2 * vc.index; ho.long_count[1] = ho.long_count[0] + 1;
     }
     {
@@ -705,13 +716,13 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
             (void)hipMemsetAsync(trace, 0, (size_t)grid.x * 64, s);
         }
 #endif
-        // Tiers: (1) one workgroup per tile with the register-resident variant that fits the expected longest list
-        // (at most 4096: these are about twice as fast per list as the larger ones); longer lists are appended to a
-        // list by that launch and sorted by (2) a persistent launch of the largest LDS variant and (3) one of the
-        // global merge path.  Tiers 2 / 3 are launched when the host knows they are needed (synchronous forward) or
-        // cannot know (no-sync forward: a few hundred workgroups that find an empty list).
+        // Tiers: (1) one workgroup per tile with the variant that fits the expected longest list (at most 4096 keys:
+        // four workgroups per CU); longer lists are appended to one of two lists by that launch and sorted by
+        // persistent launches of (2) the 8192-key variant (two workgroups per CU), (3) the 16 384-key variant (one) and
+        // (4) the global merge path.  The later tiers are launched when the host knows they are needed (synchronous
+        // forward) or cannot know (no-sync forward: a few hundred workgroups each that find an empty list).
         prof_begin(kStSort, s);
-#define LSR_SORT(CAPV, GRID, PERS)                                                               \
+#define LSR_SORT(CAPV, GRID, PERS, ARG)                                                          \
     do {                                                                                         \
         if ((size_t)CAPV * 8 + 16384 > 65536)                                                    \
             (void)hipFuncSetAttribute((const void *)k_sort_tiles<CAPV, PERS>,                    \
@@ -719,16 +730,22 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
                                       CAPV * 8 + (CAPV < 2048 ? CAPV : 2048) * 4);               \
         hipLaunchKernelGGL((k_sort_tiles<CAPV, PERS>), GRID, dim3(kSortThreads),                 \
                            (size_t)CAPV * 8 + (size_t)(CAPV < 2048 ? CAPV : 2048) * 4, s,        \
-                           T, vc.view0, ts, (const uint64_t *)keys, plist, ho, trace);           \
+                           T, ARG, ts, (const uint64_t *)keys, plist, ho, trace);                \
     } while (0)
-        if (max_tile_pairs <= 1024) LSR_SORT(1024, grid, false);
-        else if (max_tile_pairs <= 2048) LSR_SORT(2048, grid, false);
-        else LSR_SORT(4096, grid, false);
+        if (max_tile_pairs <= 1024) LSR_SORT(1024, grid, false, vc.view0);
+        else if (max_tile_pairs <= 2048) LSR_SORT(2048, grid, false, vc.view0);
+        else LSR_SORT(kSortTier1, grid, false, vc.view0);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        const dim3 pgrid((uint32_t)device_cus());
-        if (device_counts || max_tile_pairs > 4096) {
-            LSR_SORT(16384, pgrid, true);
+        const uint32_t cus = (uint32_t)device_cus();
+        const dim3 pgrid(cus);
+        if (device_counts || max_tile_pairs > kSortTier1) {   // class 0: two 72 KB workgroups per CU
+            LSR_SORT(kSortTier2, dim3(2 * cus), true, 0);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        if (device_counts || max_tile_pairs > kSortTier2) {   // class 1 up to the LDS capacity
+            LSR_SORT(kSortLdsMax, pgrid, true, 1);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }

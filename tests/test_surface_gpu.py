@@ -167,6 +167,54 @@ def test_long_tile_lists_take_the_global_merge_path(hip_device):
     np.testing.assert_allclose(run.mask_out[0].cpu().numpy(), o["mask"], atol=1e-4)
 
 
+def test_every_sort_tier_in_one_call(hip_device):
+    """One 64x64 view (16 tiles) whose tiles hold ~1.5k, ~6k, ~12k and ~20k entries: the per-tile launch, the two
+    persistent LDS variants (lists of 4097..8192 and 8193..16384 keys, collected from both ends of one array) and
+    the global merge path all run in ONE call; sorted lists bit-exact, images on the bar — through the synchronous
+    forward (later tiers launched because the host knows the longest list) and the no-sync forward (launched always)."""
+    from latentsplat_amd.rasterizer import last_forward_status, rasterize_views
+    sizes = {0: 1500, 5: 6000, 6: 6500, 10: 12000, 15: 20000}      # tile -> Gaussians squeezed onto its centre
+    G = sum(sizes.values()) + 3000
+    gen = torch.Generator().manual_seed(9)
+    sc = util.make_scene(G, image_size=64, views=1, color_sh_degree=None, feature_channels=4, sigma_px=(0.3, 0.6), opacity_scale=0.02)
+    z = sc.means[:, 2]
+    at = 0
+    for tile, n in sizes.items():
+        cx, cy = ((tile % 4) * 16 + 8) / 64.0 - 0.5, ((tile // 4) * 16 + 8) / 64.0 - 0.5
+        sl = slice(at, at + n); at += n
+        sc.means[sl, 0] = (torch.rand(n, generator=gen) * 0.05 - 0.025 + cx) / 0.8 * z[sl]
+        sc.means[sl, 1] = (torch.rand(n, generator=gen) * 0.05 - 0.025 + cy) / 0.8 * z[sl]
+    bi = util.boundary_inputs(sc, 64, 64)
+    run = util.HipRun(bi, hip_device)
+    ts = run.tile_start()
+    lens = np.diff(ts)
+    assert lens.max() > 16384 and ((lens > 8192) & (lens <= 16384)).any() and ((lens > 4096) & (lens <= 8192)).sum() >= 2 and (lens <= 4096).any()
+    o = util.oracle_forward(bi, 0)
+    np.testing.assert_array_equal(run.point_list()[:o["P"]], o["point_list"])
+    np.testing.assert_allclose(run.feat_out[0].cpu().numpy(), o["feature"], atol=1e-4)
+    np.testing.assert_allclose(run.mask_out[0].cpu().numpy(), o["mask"], atol=1e-4)
+    # half-tile render lists of the long tiles: every half list is a subsequence of the tile's sorted list
+    hc, hl, pl = run.half_count(), run.half_list(), run.point_list()
+    for t in np.nonzero(lens > 4096)[0]:
+        full = pl[ts[t]:ts[t + 1]]
+        for h in range(2):
+            n_h = int(hc[t, h])
+            mine = hl[2 * ts[t] + h * lens[t]: 2 * ts[t] + h * lens[t] + n_h] & 0x00FFFFFF
+            pos = {int(g): i for i, g in enumerate(full)}
+            idx = np.array([pos[int(g)] for g in mine])
+            assert n_h > 0 and (np.diff(idx) > 0).all(), (t, h)
+    # the same scene through the autograd op, synchronous and no-sync: identical images
+    dev = hip_device
+    views = util.view_table(bi, dev)
+    args = (views, 64, 64, 0, bi["means"].to(dev), bi["cov6"].to(dev), bi["opac"].to(dev))
+    ref = rasterize_views(*args, features=bi["features"].to(dev))
+    st = last_forward_status()
+    out = rasterize_views(*args, features=bi["features"].to(dev), pair_capacity=st["num_pairs"] + 64, max_tile_hint=4096)
+    assert last_forward_status() == st
+    assert torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2])
+    np.testing.assert_allclose(ref[1][0].cpu().numpy(), o["feature"], atol=1e-4)
+
+
 def test_identical_depths_sort_by_index(hip_device):
     """Many Gaussians at exactly the same depth: ties must resolve by ascending index."""
     G = 3000
