@@ -199,6 +199,28 @@ def decoder_step_timing(dev, steps=10, scenes=1):
         res[name] = dict(ms_per_step=1e3 * el / steps, views_per_s=4 * scenes * steps / el)
     res["config"] = (f"configs[{3 if scenes == 1 else 4}] per-GPU shape: {scenes} scene(s) x 4 views, 393216 Gaussians each, "
                      "colour SH deg 4 + 4-ch latent SH deg 2, 256x256")
+    # per-kernel times of the same step (hipEvents inside the library), and the SH kernels against the HBM roofline:
+    # the path's only kernels that exist because of the reference's payload (degree-4 colour + latent harmonics).
+    # Algorithmic bytes per launch (all scenes): coefficients (75 + 36 floats per Gaussian) read once per scene,
+    # per (view, Gaussian) the visibility word, the position and the clamp byte; backward: the coefficients again, their
+    # gradients written once per scene, the mean gradient.  The 32-byte payload half of the records (written by the
+    # forward, its gradient read by the backward) is only touched for visible (view, Gaussian) pairs and is NOT
+    # counted: the fractions are lower bounds.
+    from latentsplat_amd import _lib
+    _lib.profile_read()
+    _lib.profile_enable(True)
+    for _ in range(5):
+        fwdbwd()
+    torch.cuda.synchronize(dev)
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+    G, V, coeff = 393_216, 4, (25 * 3 + 9 * 4) * 4
+    sh_bytes = {"sh_forward": scenes * (G * coeff + V * G * (4 + 12 + 1)),
+                "sh_backward": scenes * (2 * G * coeff + V * G * (4 + 12 + 1) + G * 12)}
+    res["kernel_ms"] = {k: round(ms / n, 4) for k, (ms, n) in prof.items() if n}
+    res["sh_roofline"] = {k: dict(ms=round(prof[k][0] / prof[k][1], 4), algorithmic_bytes=nb,
+                                  frac=round(nb / (prof[k][0] / prof[k][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                          for k, nb in sh_bytes.items() if prof.get(k, (0, 0))[1]}
     return res
 
 
@@ -776,6 +798,9 @@ def main():
             line["decoder_step"] = {"cfg3_1x4": [r4(dec_step["forward"]["ms_per_step"]), r4(dec_step["forward_backward"]["ms_per_step"])],
                                     "cfg4_4x4": [r4(dec_step["batch4"]["forward"]["ms_per_step"]), r4(dec_step["batch4"]["forward_backward"]["ms_per_step"])],
                                     "unit": "ms per step [forward, forward+backward]"}
+            shr = lambda d: {k: [v["ms"], v["frac"]] for k, v in (d.get("sh_roofline") or {}).items()}
+            line["decoder_step"]["sh_roofline"] = {"cfg3": shr(dec_step), "cfg4": shr(dec_step["batch4"]),
+                                                   "unit": "[ms per launch, lower-bound fraction of the 8 TB/s HBM peak]"}
         if path_step is not None:
             line["path_step"] = pick(path_step, ("forward_ms", "forward_backward_ms"))
         line["full"] = None if side is None else os.path.relpath(side, ROOT)
