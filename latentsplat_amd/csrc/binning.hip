@@ -52,52 +52,77 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
     total = tot;
     return base + incl - v;
 }
-__device__ __forceinline__ uint32_t block_max(uint32_t v, uint32_t *s_wave) {
-    const int lane = threadIdx.x & (LSR_WAVE - 1), wid = threadIdx.x / LSR_WAVE;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
-    if (lane == 0) s_wave[wid] = v;
-    __syncthreads();
-    uint32_t m = 0;
-#pragma unroll
-    for (int w = 0; w < kScanWaves; ++w) m = max(m, s_wave[w]);
-    __syncthreads();
-    return m;
-}
+// Per-thread chunk of the counts in registers when it is short (kScanRegs words: the headline call has 4 per
+// thread): the kernel is ONE workgroup on the critical path of every forward and used to read its counts from
+// memory four times (sum, offsets, histogram, placement).
+constexpr int kScanRegs = 8;
 
 __global__ void __launch_bounds__(kScanThreads)
 k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *header,
             uint32_t *host_mirror, uint32_t *__restrict__ order, int N, uint32_t capacity, int K) {
     __shared__ uint32_t s_wave[kScanWaves];
     __shared__ uint32_t s_cls[kScanThreads];      // counting-sort classes: histogram -> running offsets
-    const int tid = threadIdx.x;
+    __shared__ uint64_t s_tot64[kScanWaves];
+    __shared__ uint32_t s_max[kScanWaves];
+    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
     const int per = (N + kScanThreads - 1) / kScanThreads;
     const int lo = tid * per, hi = min(N, lo + per);
+    const bool in_regs = per <= kScanRegs;        // block-uniform
+    uint32_t creg[kScanRegs];
+    if (in_regs) {
+#pragma unroll
+        for (int q = 0; q < kScanRegs; ++q) {     // unconditional loads at clamped positions: all in flight together
+            const uint32_t c = count[min(lo + q, N - 1)];
+            creg[q] = (q < per && lo + q < hi) ? c : 0u;
+        }
+    }
     uint32_t sum = 0, mx = 0;
     uint64_t sum64 = 0;
-    for (int i = lo; i < hi; ++i) { const uint32_t c = count[i]; sum += c; sum64 += c; mx = max(mx, c); }
-    uint32_t total;
-    uint32_t run = block_exclusive_scan(sum, s_wave, total);   // exclusive prefix of this thread's chunk
-    const uint32_t maxc = block_max(mx, s_wave);
+    if (in_regs) {
+#pragma unroll
+        for (int q = 0; q < kScanRegs; ++q) { sum += creg[q]; mx = max(mx, creg[q]); }
+        sum64 = sum;                              // at most 8 counts of < 2^28 each per thread
+    } else {
+        for (int i = lo; i < hi; ++i) { const uint32_t c = count[i]; sum += c; sum64 += c; mx = max(mx, c); }
+    }
+    // one combined pass: exclusive scan of the chunk sums, the longest list, the 64-bit total (two barriers)
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < LSR_WAVE; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += t;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, off)); sum64 += __shfl_xor(sum64, off); }
+    if (lane == LSR_WAVE - 1) s_wave[wid] = incl;
+    if (lane == 0) { s_max[wid] = mx; s_tot64[wid] = sum64; }
+    __syncthreads();
+    uint32_t wbase = 0, total = 0, maxc = 0;
+    sum64 = 0;
+#pragma unroll
+    for (int w = 0; w < kScanWaves; ++w) {
+        const uint32_t x = s_wave[w];
+        total += x;
+        wbase += w < wid ? x : 0u;
+        maxc = max(maxc, s_max[w]);
+        sum64 += s_tot64[w];
+    }
+    __syncthreads();   // s_wave is reused below
+    uint32_t run = wbase + incl - sum;            // exclusive prefix of this thread's chunk
     // Offsets are 32-bit: a call whose pair count does not fit (possible in principle: every Gaussian can touch every
     // tile of every view) is reported as an overflow with the count saturated, never silently wrapped.
-    __shared__ uint64_t s_tot64[kScanWaves];
-    {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum64 += __shfl_xor(sum64, off);
-        if ((tid & (LSR_WAVE - 1)) == 0) s_tot64[tid / LSR_WAVE] = sum64;
-        __syncthreads();
-        sum64 = 0;
-#pragma unroll
-        for (int w = 0; w < kScanWaves; ++w) sum64 += s_tot64[w];
-    }
     const bool wrapped = sum64 > 0xFFFFFFFFull;
     if (wrapped) total = 0xFFFFFFFFu;
     // Offsets are clamped to the capacity of the binning workspace: with exact sizing (capacity =
     // UINT32_MAX) nothing changes; in the no-sync forward a scene that produces more pairs than the
     // caller provided for gets its last lists truncated (never an out-of-bounds write) and the
     // overflow word set — the caller must then discard the result and retry with more room.
-    for (int i = lo; i < hi; ++i) { start[i] = min(run, capacity); run += count[i]; }
+    if (in_regs) {
+#pragma unroll
+        for (int q = 0; q < kScanRegs; ++q) { if (lo + q < hi) start[lo + q] = min(run, capacity); run += creg[q]; }
+    } else {
+        for (int i = lo; i < hi; ++i) { start[i] = min(run, capacity); run += count[i]; }
+    }
     if (tid == kScanThreads - 1) {
         start[N] = min(total, capacity); header[kHdrPairs] = total; header[kHdrMaxTile] = maxc;
         header[kHdrOverflow] = (total > capacity || wrapped) ? 1u : 0u;
@@ -119,7 +144,12 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
         const int a = max(lo, c * per_chunk), b = min(hi, (c + 1) * per_chunk);
         s_cls[tid] = 0;
         __syncthreads();
-        for (int i = a; i < b; ++i) atomicAdd(&s_cls[cls(count[i])], 2u);
+        if (in_regs) {
+#pragma unroll
+            for (int q = 0; q < kScanRegs; ++q) if (lo + q >= a && lo + q < b) atomicAdd(&s_cls[cls(creg[q])], 2u);
+        } else {
+            for (int i = a; i < b; ++i) atomicAdd(&s_cls[cls(count[i])], 2u);
+        }
         __syncthreads();
         const uint32_t mine = s_cls[tid];
         uint32_t num_items;
@@ -127,9 +157,18 @@ k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, ui
         s_cls[tid] = first;
         __syncthreads();
         uint32_t *ord = order + 2 * (size_t)c * per_chunk;
-        for (int i = a; i < b; ++i) {
-            const uint32_t at = atomicAdd(&s_cls[cls(count[i])], 2u);
-            ord[at] = (uint32_t)i; ord[at + 1] = (uint32_t)i | (1u << kItemHalfShift);
+        if (in_regs) {
+#pragma unroll
+            for (int q = 0; q < kScanRegs; ++q)
+                if (lo + q >= a && lo + q < b) {
+                    const uint32_t at = atomicAdd(&s_cls[cls(creg[q])], 2u);
+                    ord[at] = (uint32_t)(lo + q); ord[at + 1] = (uint32_t)(lo + q) | (1u << kItemHalfShift);
+                }
+        } else {
+            for (int i = a; i < b; ++i) {
+                const uint32_t at = atomicAdd(&s_cls[cls(count[i])], 2u);
+                ord[at] = (uint32_t)i; ord[at + 1] = (uint32_t)i | (1u << kItemHalfShift);
+            }
         }
         __syncthreads();
     }
@@ -300,10 +339,13 @@ __device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint
 #pragma unroll
         for (int st = 0; st < kSteps; ++st) {
             const uint32_t p = base + (uint32_t)((st * kWaves + wid) * LSR_WAVE + lane);
-            const uint32_t w = low_word(min(p, n - 1));            // unconditional at a clamped position
-            const uint32_t m16 = p < n ? code_mask(w & 0xFFu) : 0u;
-            const uint64_t packed = (uint64_t)__builtin_popcountll(__ballot((m16 & 0x00FFu) != 0u)) |
-                                    ((uint64_t)__builtin_popcountll(__ballot((m16 & 0xFF00u) != 0u)) << 32);
+            uint64_t packed = 0;
+            if (p - lane < n) {                                        // wave-uniform: chunks beyond the list only write their zero
+                const uint32_t w = low_word(min(p, n - 1));            // unconditional at a clamped position
+                const uint32_t m16 = p < n ? code_mask(w & 0xFFu) : 0u;
+                packed = (uint64_t)__builtin_popcountll(__ballot((m16 & 0x00FFu) != 0u)) |
+                         ((uint64_t)__builtin_popcountll(__ballot((m16 & 0xFF00u) != 0u)) << 32);
+            }
             if (lane == 0) s_tab[st * kWaves + wid] = packed;
         }
         __syncthreads();
