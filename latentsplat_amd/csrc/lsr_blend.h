@@ -2,7 +2,7 @@
 // compositing kernels, so both make bit-identical alpha / skip decisions (the backward rebuilds
 // the transmittance by dividing out exactly the alphas the forward multiplied in), and the
 // footprint-span / sub-block-code helpers shared by k_preprocess (writes the span), k_scatter (per-pair
-// code in the sort key) and k_sort_tiles (turns the codes into per-quadrant render lists).
+// code in the sort key) and k_sort_tiles (turns the codes into the two half-tile render lists of a tile).
 //
 // Work decomposition (CDNA4, wave64): a 16x16 tile is two 16x8 halves, a half eight 4x4-pixel
 // SUB-BLOCKS.  One wave renders one half with TWO horizontally adjacent pixels per lane: the 8-lane

@@ -77,7 +77,7 @@ inline size_t bin_stride(const lsr_dims &d) { return narrow_bins(d) ? sizeof(Bin
 //   x0 | x1 << 8 | y0 << 16 | y1 << 24;   first / last reached cell; a last cell of 255 means "255 or
 //   beyond"; x0 > x1 (kSpanNone) = reaches no pixel at all.
 // k_scatter turns it into the 8-bit sub-block code of every (Gaussian, tile) pair, carried in the low byte of
-// the sort key (below), from which k_sort_tiles builds the per-QUADRANT render lists.
+// the sort key (below), from which k_sort_tiles builds the two half-tile render lists.
 constexpr uint32_t kSpanNone = 0x00010001u;   // x0 = 1 > x1 = 0
 constexpr uint32_t kSpanAll = 0xFF00FF00u;    // conic not trustworthy: every cell
 // Sort key of a (Gaussian, tile) pair: depth bits << 32 | index << 8 | code, code = c0 | c1 << 2 | r0 << 4 | r1 << 6:

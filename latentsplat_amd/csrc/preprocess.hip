@@ -191,7 +191,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
                     }
             }
             if (in_range) {
-                // footprint span for the per-quadrant render lists (k_scatter / k_sort_tiles); not part of the bit-exact contract
+                // footprint span for the half-tile render lists (k_scatter / k_sort_tiles); not part of the bit-exact contract
                 const uint32_t span = ok ? footprint_cells(px, py, conic_a, conic_b, conic_c, opacity, rminx, rminy) : kSpanNone;
                 radii[o] = ok ? (int32_t)my_radius : 0;
                 const float out_depth = ok ? tz : 0.0f;

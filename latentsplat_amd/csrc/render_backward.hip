@@ -46,7 +46,7 @@ typedef float float4_b __attribute__((ext_vector_type(4)));
 struct RenderBwdParams {
     int H, W, gx, T, G, C, has_color;
     int num_cus;                  // workgroups of 4*WPS waves (one per compute unit)
-    const uint32_t *items;        // work items of the forward (view*T + tile | quadrant << 28), costliest first
+    const uint32_t *items;        // work items of the forward (view*T + tile | half << 28), costliest first
     const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t chunks, per_chunk;   // the forward's view chunks: the item list is `chunks` costliest-first lists of `per_chunk` items
     uint32_t *queue;              // work-queue head (zeroed with the gradient workspace)

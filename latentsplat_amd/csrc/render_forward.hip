@@ -73,7 +73,7 @@ struct RenderFwdParams {
     int num_cus;                  // compute units
     int waves_per_cu;             // resident compositing waves per CU the launch provides
     const uint32_t *items;        // work items, costliest first
-    uint32_t num_items;           // items of this launch (4 per tile of the launch's view chunk)
+    uint32_t num_items;           // items of this launch (2 per tile of the launch's view chunk)
     uint32_t *queue;              // work-queue head (zeroed per forward)
     unsigned long long *trace;    // debug builds (LSR_ENABLE_TRACE): per item {start clk, end clk, hw id, iterations << 32 | entries}
     const float *views;
