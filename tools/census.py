@@ -115,6 +115,45 @@ def main():
                 half_iters[t, h] += c
     print(f"half-tile lists: {it_half / P:.3f} 8-wide iterations per pair ({batches_half} batches, {ent_half / P:.3f} entries per pair); "
           f"ideal {sum(bin(v).count('1') for v in m16) / 8.0 / P:.3f}")
+    # (d) how much of the gap to the ideal is the batch boundary?  Same lists with other batch sizes, with ONE batch of
+    # look-ahead (a lane group that has finished its part of batch b continues in batch b+1 while the slowest group
+    # finishes b), and the bound no batching scheme can beat (the longest of the half's eight sub-block lists).
+    def half_lists():
+        for t in range(T):
+            s0, s1 = ranges[t]
+            m = m16[s0:s1]
+            for h in range(2):
+                mh = (m >> (8 * h)) & 0xFF
+                yield mh[mh != 0]
+    per_batch = {bn: 0 for bn in (32, 64, 128, 256)}
+    look = 0
+    bound = 0
+    for mh in half_lists():
+        if not len(mh):
+            continue
+        hits = np.stack([(mh >> sb) & 1 for sb in range(8)], 1)            # (entries, 8)
+        bound += int(hits.sum(0).max())
+        for bn in per_batch:
+            for b0 in range(0, len(mh), bn):
+                per_batch[bn] += int(hits[b0:b0 + bn].sum(0).max())
+        # one batch of look-ahead, batches of 64: backlog[g] = entries of already staged batches group g still has to do
+        backlog = np.zeros(8, np.int64)
+        nb = (len(mh) + Bn - 1) // Bn
+        for bi_ in range(nb + 1):
+            new = hits[bi_ * Bn:(bi_ + 1) * Bn].sum(0) if bi_ < nb else np.zeros(8, np.int64)
+            # the round that retires batch bi_-1 runs until every group has finished ITS share of it; groups that are
+            # done early work on batch bi_ (already staged) meanwhile
+            if bi_ == 0:
+                prev = new.copy(); backlog = np.zeros(8, np.int64); ahead = np.zeros(8, np.int64)
+                continue
+            rounds = int((prev - ahead).max()) if (prev - ahead).max() > 0 else 0
+            look += rounds
+            spare = rounds - (prev - ahead)                                  # iterations each group had left over
+            ahead = np.minimum(np.maximum(spare, 0), new)                    # spent on the next batch
+            prev = new
+    print("half-tile lists, lock-step iterations per pair by staging scheme: " +
+          ", ".join(f"batch {bn}: {v / P:.3f}" for bn, v in per_batch.items()) +
+          f"; batch {Bn} with one batch of look-ahead: {look / P:.3f}; longest sub-block list (bound): {bound / P:.3f}")
     ideal = sum(bin(v).count("1") for v in m16) / 4.0
     print(f"lock-step iterations per pair: current {it_cur / P:.3f} ({batches_cur} batches), "
           f"quadrant lists {it_quad / P:.3f} ({batches_quad} batches, {quad_len.sum() / P:.3f} entries per pair), ideal {ideal / P:.3f}")
