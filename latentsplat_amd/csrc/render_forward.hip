@@ -92,7 +92,7 @@ struct RenderFwdParams {
 // so every SIMD starts with nearly the same total; everything beyond the first item per wave comes from
 // the queue.
 template <int NCHP, int WPB>
-__global__ void __launch_bounds__(LSR_WAVE * WPB)
+__global__ void __launch_bounds__(LSR_WAVE * WPB, WPB == 14 ? 7 : 1)   // (the 2 x 14-wave variant needs 72 registers: seven waves per SIMD)
 k_render_fwd(RenderFwdParams p) {
     // Staged entries, one record per list entry: (x, y, a2, c2) (b2, log2(255 o), z / 255, -1 / 255) payload / 255 ...
     // (lsr_blend.h: the loop works in units of 255 alpha).  The odd float4 stride keeps the per-lane staging
@@ -392,7 +392,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
         hipLaunchKernelGGL((k_render_fwd<N, WPB>), dim3(p.num_cus * ((WPC) / (WPB))), dim3(LSR_WAVE * WPB), 0, s, p); \
     } while (0)
     const int variant = env_int("LSR_FWD_VARIANT", 0);
-    if (nchp == 4) { if (variant == 2) LSR_RF(4, 16, 16); else LSR_RF(4, 12, 24); }   // 2 x 12 waves per CU: 0.245 vs 0.281 ms per 16 views with 16
+    if (nchp == 4) { if (variant == 2) LSR_RF(4, 16, 16); else if (variant == 3) LSR_RF(4, 14, 28); else LSR_RF(4, 12, 24); }   // 2 x 12 waves per CU: 0.245 vs 0.281 ms per 16 views with 16
     else if (nchp == 8) LSR_RF(8, 16, 16);
     else if (nchp == 12) LSR_RF(12, 12, 12);
     else LSR_RF(36, 4, 8);
