@@ -426,11 +426,7 @@ k_render_bwd(RenderBwdParams p) {
                     const bool mine = !kPackRow || l16 < 6 || (l16 >= 8 && l16 < 8 + NCHP);   // slots without a column in a packed row
                     const float val = mine ? s_acc[e][16 * gi + fcol] : 0.0f;
                     if (mine) s_acc[e][16 * gi + fcol] = 0.0f;
-#ifdef LSR_ABL_NOFLUSH     // ablation builds: what do the global record-adds cost?
-                    if (hit && val == 123.456f) {
-#else
                     if (hit && val != 0.0f) {
-#endif
                         const size_t at = (vG + g) * (size_t)RF + 16 * gi + l16;
                         if (p.rec_fixed)   // order-independent integer sum (LSR_DETERMINISTIC)
                             atomicAdd((unsigned long long *)p.rec_fixed + at, (unsigned long long)__double2ll_rn((double)val * kFixedPointScale));
