@@ -7,6 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err || tail -3 $OUT/bench.err
+cp gpurun_out/bench_full.json $OUT/bench_full.json 2>/dev/null   # the side file of THIS run (later bench invocations overwrite it)
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python bench.py --no-cpu-baseline --no-latency > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err || tail -3 $OUT/rocprof.err
 bash tools/pmc_profile.sh $TAG --steps 3 --warmup 1 --no-cpu-baseline --no-latency > /dev/null 2>&1
 python tools/rocpd_summary.py $OUT/stats/bench_results.db "$TAG: python bench.py (16 views x 300k Gaussians, 256x256; fwd then fwd+bwd)" > $OUT/kernel_stats.md
