@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LSR_ABI_VERSION 6
+#define LSR_ABI_VERSION 7
 #define LSR_TILE 16            /* tile edge in pixels (16x16 = the published algorithm's tile) */
 #define LSR_MAX_FEAT_CHANNELS 32
 #define LSR_MAX_SH_DEGREE 4
@@ -202,8 +202,10 @@ int lsr_pack_view(const float *viewmatrix, const float *projmatrix, const float 
 
 /* ---- forward, phase 1: per-Gaussian preprocess + per-tile counting + tile offset scan.
  * Writes radii.  Waits once for the device to return the pair count and the longest tile list through
- * the two host pointers (both required): on an event recorded right behind the preprocess kernel, whose
- * last workgroup totals the tile counts — the offset scan is still running when the call returns.
+ * the two host pointers (both required): the last workgroup of the preprocess kernel scans the tile counts
+ * (ABI v7: no separate scan kernel for calls of up to 4096 (view, tile) pairs) and writes the two numbers plus the
+ * call's sequence number into mapped host memory as soon as it has them; the host polls that word (an event behind
+ * the kernel is the fallback) — the rest of the scan is still running when the call returns.
  * Also starts the view-dependent payload pass (colour / latent features from SH), which only depends on
  * the preprocess: it runs on a library-owned side stream (one per device, forked from `stream` with an
  * event) while the host fetches the pair count and the binning of phase 2 runs; phase 2 joins it
@@ -215,9 +217,7 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
                         lsr_stream_t stream);
 
 /* ---- forward, phase 2: binning, per-tile depth sort, front-to-back compositing. Async.  Must follow
- * the lsr_forward_prepare of the same geom_ws on the same device (it waits for that call's SH pass).
- * With enough views the work runs as chunks of views: the binning of chunk c + 1 on the library's side
- * stream beside the compositing of chunk c (forked and joined with events inside this call). */
+ * the lsr_forward_prepare of the same geom_ws on the same device (it waits for that call's SH pass). */
 int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, void *bin_ws,
                        void *img_ws, int64_t num_pairs, int32_t max_tile_pairs,
                        const lsr_outputs *out, lsr_stream_t stream);
@@ -274,6 +274,19 @@ int lsr_profile_enable(int on);
 int lsr_profile_num_stages(void);
 const char *lsr_profile_stage_name(int stage);
 int lsr_profile_read(double *ms_out, int64_t *launches_out);
+
+/* ---- development aid (kernel A/B experiments, tools/): overrides one of the library's LSR_* environment knobs
+ * (launch-shape variants, LSR_SH_PLACEMENT, LSR_FOLD_SCAN, ...) for the rest of the process.  Knobs select between
+ * implementations that produce identical results; nothing in the product path calls this. */
+int lsr_debug_set_knob(const char *name, int value);
+
+/* ---- arithmetic convention of the projection stage (ABI v7).  0 (default): every float operation of the published
+ * preprocess is a separate IEEE operation (what the oracle and the bit-exact index tests assume); 1: products feeding
+ * sums are contracted into fused multiply-adds the way a compiler with contraction on (nvcc's default -fmad=true)
+ * would build the published source — tools/contraction_census.py quantifies how many radii / tile rectangles / list
+ * positions differ between the two.  Process-wide; takes effect at the next forward. */
+int lsr_set_projection_contraction(int on);
+int lsr_get_projection_contraction(void);
 
 #ifdef __cplusplus
 }

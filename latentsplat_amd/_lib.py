@@ -120,6 +120,7 @@ EXPORTS = (
     "lsr_get_layout", "lsr_build_views", "lsr_pack_view", "lsr_forward_prepare", "lsr_forward_render", "lsr_forward_nosync",
     "lsr_forward_status", "lsr_forward_abandon", "lsr_backward",
     "lsr_profile_enable", "lsr_profile_num_stages", "lsr_profile_stage_name", "lsr_profile_read",
+    "lsr_debug_set_knob", "lsr_set_projection_contraction", "lsr_get_projection_contraction",
     "lsr_adapter_forward", "lsr_adapter_backward", "lsr_latent_forward", "lsr_latent_backward",
     "lsr_ply_pack", "lsr_ply_write_host",
 )
@@ -189,6 +190,11 @@ def load():
     lib.lsr_profile_stage_name.restype = C.c_char_p
     lib.lsr_profile_stage_name.argtypes = [C.c_int]
     lib.lsr_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(I64)]
+    lib.lsr_debug_set_knob.restype = C.c_int
+    lib.lsr_debug_set_knob.argtypes = [C.c_char_p, C.c_int]
+    lib.lsr_set_projection_contraction.restype = C.c_int
+    lib.lsr_set_projection_contraction.argtypes = [C.c_int]
+    lib.lsr_get_projection_contraction.restype = C.c_int
     lib.lsr_adapter_forward.restype = C.c_int
     lib.lsr_adapter_forward.argtypes = [C.POINTER(AdapterDims), C.POINTER(AdapterInputs),
                                         C.POINTER(AdapterOutputs), P]
@@ -205,10 +211,15 @@ def load():
     lib.lsr_ply_pack.argtypes = [I64, I32, C.POINTER(PlyInputs), P, P]
     lib.lsr_ply_write_host.restype = C.c_int
     lib.lsr_ply_write_host.argtypes = [C.c_char_p, P, I64]
-    if lib.lsr_abi_version() != 6:
+    if lib.lsr_abi_version() != 7:
         raise LsrError("liblsr_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
+
+
+def set_knob(name: str, value: int) -> None:
+    """Override one LSR_* development knob of the library for the rest of the process (A/B experiments only)."""
+    check(load().lsr_debug_set_knob(name.encode(), int(value)), "lsr_debug_set_knob")
 
 
 def profile_enable(on, only: tuple = ()) -> None:

@@ -72,19 +72,36 @@ int lsr::device_cus() {
 
 bool lsr::deterministic_backward() { return env_int("LSR_DETERMINISTIC", 0) != 0; }
 
-// Development knobs (LSR_FWD_VARIANT, LSR_SH_SIDE_STREAM, ...): read from the environment once per
-// process and knob, then served from a table — no getenv on the launch path.
+// -1: not set yet (the environment default LSR_PROJECTION_CONTRACTION, 0 unless given, applies)
+static int g_projection_contraction = -1;
+bool lsr::projection_contraction() {
+    const int v = __atomic_load_n(&g_projection_contraction, __ATOMIC_RELAXED);
+    return (v < 0 ? env_int("LSR_PROJECTION_CONTRACTION", 0) : v) != 0;
+}
+
+// Development knobs (LSR_FWD_VARIANT, LSR_SH_PLACEMENT, ...): read from the environment once per process and knob,
+// then served from a table — no getenv on the launch path.  lsr_debug_set_knob overrides a table entry at run time
+// (kernel A/B experiments in one process; not part of the product surface).
+namespace {
+struct Knob { char name[32]; int value; };
+Knob g_knobs[32];
+int g_n_knobs = 0;
+std::mutex g_knob_mu;
+Knob *find_knob(const char *name) {
+    for (int i = 0; i < g_n_knobs; ++i)
+        if (!strcmp(g_knobs[i].name, name)) return &g_knobs[i];
+    return nullptr;
+}
+}  // namespace
 int lsr::env_int(const char *name, int fallback) {
-    struct Knob { const char *name; int value; };
-    static Knob knobs[16];
-    static int n_knobs = 0;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    for (int i = 0; i < n_knobs; ++i)
-        if (!strcmp(knobs[i].name, name)) return knobs[i].value;
+    std::lock_guard<std::mutex> lock(g_knob_mu);
+    if (Knob *k = find_knob(name)) return k->value;
     const char *e = getenv(name);
     const int v = e ? atoi(e) : fallback;
-    if (n_knobs < 16) knobs[n_knobs++] = {name, v};
+    if (g_n_knobs < 32 && strlen(name) < sizeof(g_knobs[0].name)) {
+        strcpy(g_knobs[g_n_knobs].name, name);
+        g_knobs[g_n_knobs++].value = v;
+    }
     return v;
 }
 
@@ -161,22 +178,27 @@ static int check_dims(const lsr_dims *d) {
 //   * the SH payload pass (sh.hip) depends on k_preprocess only and touches nothing that tile_scan / scatter /
 //     sort read or write: forked after the preprocess launch, joined before the first compositing launch
 //     (in the synchronous forward this also fills the host's round trip for the pair count);
-//   * the binning of view chunk c + 1 runs beside the compositing of chunk c (view chunks, lsr_internal.h);
 //   * the backward's per-scene geometry / SH kernels of odd scenes.
 // Every cross-stream edge is an event record + a stream wait.  The events are shared too, so a record and the
 // wait that consumes it are issued under the context's mutex (a wait binds to the record that precedes it):
 // another host thread re-recording the same event can then only make a LATER wait cover more work, never less
 // — the side stream executes in order, so a wait on the latest record covers every earlier one.
-// LSR_SH_SIDE_STREAM=0 keeps everything on the caller's stream (and view chunks off).
+// LSR_SH_PLACEMENT (development knob): 0 = side stream (default), 1 = on the caller's stream right behind k_preprocess,
+// 2 = on the caller's stream behind the binning (in front of the compositing launch).  LSR_SH_SIDE_STREAM=0 is the
+// older spelling of 1.
 struct SideCtx {
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;            // caller -> side, side -> caller
-    hipEvent_t chunk[kMaxViewChunks] = {};                // side -> caller: binning of view chunk c is done
     std::mutex mu;
     bool tried = false;
 };
+static int sh_placement() {
+    if (!env_int("LSR_SH_SIDE_STREAM", 1)) return 1;
+    const int p = env_int("LSR_SH_PLACEMENT", 0);
+    return p < 0 || p > 2 ? 0 : p;
+}
 static SideCtx *side_ctx() {
-    if (!env_int("LSR_SH_SIDE_STREAM", 1)) return nullptr;
+    if (sh_placement() != 0) return nullptr;
     static SideCtx ctx[64];
     static std::mutex mu;
     int dev = 0;
@@ -188,7 +210,6 @@ static SideCtx *side_ctx() {
         bool ok = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) == hipSuccess &&
                   hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) == hipSuccess &&
                   hipEventCreateWithFlags(&c.join, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; ok && i < kMaxViewChunks; ++i) ok = hipEventCreateWithFlags(&c.chunk[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
             c.side = nullptr;
@@ -204,28 +225,13 @@ static hipError_t cross_edge(SideCtx *c, hipEvent_t ev, hipStream_t from, hipStr
     return hipStreamWaitEvent(to, ev, 0);
 }
 
-// View chunks of the pipelined forward (lsr_internal.h).  LSR_PIPE_CHUNKS (development knob, read once):
-// unset / 0 / 1 = one chunk (the default), n = n chunks whenever the views divide evenly.
-// Measured on MI355X (16 views x 300 k Gaussians): 2 chunks 0.567 vs 0.577 ms per step with 32
-// compositing waves per CU, 0.626 vs 0.566 with 16 — beside a compositing kernel the next chunk's scatter / sort
-// run two to three times longer and slow the compositing down by as much as they hide; the mechanism stays
-// (tested for bitwise equal results) but is off by default.
-int lsr::view_chunks(const lsr_dims &d) {
-    if (!env_int("LSR_SH_SIDE_STREAM", 1)) return 1;
-    int K = env_int("LSR_PIPE_CHUNKS", 1);
-    if (K < 1) K = 1;
-    if (K > kMaxViewChunks) K = kMaxViewChunks;
-    while (K > 1 && d.num_views % K != 0) --K;
-    return K;
-}
-
 static bool has_sh_payload(const lsr_dims &d) {
     return d.num_gaussians > 0 && (d.color_mode == LSR_COLOR_SH || (d.feat_channels > 0 && d.feat_mode == LSR_FEAT_SH));
 }
 // SH forward of all view groups: on the side stream (forked from what is queued on `s` so far; the caller
 // joins with sh_forward_join before the compositing launch), or in line on `s`.
 static int sh_forward_fork(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s) {
-    if (!has_sh_payload(d)) return LSR_OK;
+    if (!has_sh_payload(d) || sh_placement() == 2) return LSR_OK;
     SideCtx *c = side_ctx();
     hipStream_t q = s;
     if (c) {
@@ -241,8 +247,12 @@ static int sh_forward_fork(const lsr_dims &d, const lsr_inputs &in, char *geom, 
 }
 // The caller's stream waits for the SH pass (the latest record of the join event: this call's, or a later one
 // of another host thread, which the in-order side stream completes after this call's).
-static int sh_forward_join(const lsr_dims &d, hipStream_t s) {
+static int sh_forward_join(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s) {
     if (!has_sh_payload(d)) return LSR_OK;
+    if (sh_placement() == 2) {   // in line, behind the binning
+        LSR_STAGE("sh_forward", s, launch_sh_forward(d, in, geom, s));
+        return LSR_OK;
+    }
     if (SideCtx *c = side_ctx()) {
         std::lock_guard<std::mutex> lock(c->mu);
         LSR_HIP(hipStreamWaitEvent(s, c->join, 0));
@@ -250,39 +260,16 @@ static int sh_forward_join(const lsr_dims &d, hipStream_t s) {
     return LSR_OK;
 }
 
-// Binning + forward compositing of all view chunks.  One chunk: everything on `s`.  K chunks:
-//   s    : scatter_0 sort_0 | render_0 | render_1 | ...          (render_c waits for chunk c's binning)
-//   side :                 | scatter_1 sort_1 | scatter_2 ...    (starts when chunk 0's binning is done)
-// so the binning of the later chunks runs beside the compositing of the earlier ones.
-static int forward_chunks(const lsr_dims &d, const lsr_inputs &in, char *geom, char *bin, char *img, int64_t num_pairs,
-                          int32_t max_tile_pairs, const lsr_outputs &out, hipStream_t s, bool device_counts) {
-    const int K = view_chunks(d);
-    SideCtx *c = K > 1 ? side_ctx() : nullptr;
-    if (!c) {   // (K is 1 whenever the side stream is switched off; a failed stream creation falls back to in-order chunks)
-        for (int k = 0; k < K; ++k)
-            LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts, view_chunk(d, K, k)));
-        int rc = sh_forward_join(d, s);
-        if (rc) return rc;
-        for (int k = 0; k < K; ++k)
-            LSR_STAGE("render_forward", s, launch_render_forward(d, in, geom, bin, num_pairs, img, out, s, view_chunk(d, K, k)));
-        return LSR_OK;
-    }
-    LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts, view_chunk(d, K, 0)));
-    LSR_HIP(cross_edge(c, c->fork, s, c->side));            // the side stream starts behind chunk 0's binning (and behind the SH pass it may carry)
-    for (int k = 1; k < K; ++k) {
-        LSR_STAGE("binning", c->side, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, c->side, device_counts, view_chunk(d, K, k)));
-        std::lock_guard<std::mutex> lock(c->mu);
-        LSR_HIP(hipEventRecord(c->chunk[k], c->side));
-    }
-    int rc = sh_forward_join(d, s);   // (the join event was recorded behind the SH pass, before this call's chunk work: only the SH pass is waited for)
+// Binning + forward compositing on `s`; the compositing launch waits for the SH payload pass on the side stream.
+// (Round 3 also carried an in-call pipeline that ran the binning of one half of the views beside the compositing of
+// the other half on the side stream: bit-identical, never faster — both halves are issue-bound — and deleted in
+// round 4.  Callers with independent batches overlap whole calls on two streams instead: INTEGRATION.md.)
+static int forward_tail(const lsr_dims &d, const lsr_inputs &in, char *geom, char *bin, char *img, int64_t num_pairs,
+                        int32_t max_tile_pairs, const lsr_outputs &out, hipStream_t s, bool device_counts) {
+    LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts));
+    int rc = sh_forward_join(d, in, geom, s);
     if (rc) return rc;
-    for (int k = 0; k < K; ++k) {
-        if (k > 0) {
-            std::lock_guard<std::mutex> lock(c->mu);
-            LSR_HIP(hipStreamWaitEvent(s, c->chunk[k], 0));
-        }
-        LSR_STAGE("render_forward", s, launch_render_forward(d, in, geom, bin, num_pairs, img, out, s, view_chunk(d, K, k)));
-    }
+    LSR_STAGE("render_forward", s, launch_render_forward(d, in, geom, bin, num_pairs, img, out, s));
     return LSR_OK;
 }
 
@@ -334,6 +321,22 @@ int lsr_profile_read(double *ms_out, int64_t *launches_out) {
     return LSR_OK;
 }
 int lsr_last_hip_error(void) { return g_last_hip_error; }
+
+int lsr_set_projection_contraction(int on) {
+    __atomic_store_n(&g_projection_contraction, on ? 1 : 0, __ATOMIC_RELAXED);
+    return LSR_OK;
+}
+int lsr_get_projection_contraction(void) { return lsr::projection_contraction() ? 1 : 0; }
+
+int lsr_debug_set_knob(const char *name, int value) {
+    if (!name || strlen(name) >= sizeof(g_knobs[0].name)) return LSR_EINVAL;
+    std::lock_guard<std::mutex> lock(g_knob_mu);
+    if (Knob *k = find_knob(name)) { k->value = value; return LSR_OK; }
+    if (g_n_knobs >= 32) return LSR_EINVAL;
+    strcpy(g_knobs[g_n_knobs].name, name);
+    g_knobs[g_n_knobs++].value = value;
+    return LSR_OK;
+}
 
 const char *lsr_error_string(int code) {
     switch (code) {
@@ -391,6 +394,35 @@ int lsr_pack_view(const float *viewmatrix, const float *projmatrix, const float 
     return LSR_OK;
 }
 
+// The host side of the synchronous forward's only wait: the pair count and the longest list arrive in three mapped,
+// pinned host words (pair count, longest list, sequence number of the call) that the scanning workgroup writes as soon
+// as it has the totals — before it goes on to the tile offsets and the work items (lsr_tile_scan.h).  The host polls
+// the sequence word (a cache line of its own memory until the device's write lands) instead of sleeping on an event:
+// the wake-up through the runtime cost more than the scan it was hiding.  The event recorded behind the kernel is
+// the safety net: queried every few microseconds, and once it has completed without the sequence word showing up
+// (cannot happen unless the launch failed) the header is read back with a copy.  LSR_HOST_POLL=0: wait on the event.
+static int wait_pair_count(volatile uint32_t *h, uint32_t seq, hipEvent_t ev, bool &have) {
+    have = false;
+    if (!env_int("LSR_HOST_POLL", 1)) {
+        LSR_HIP(hipEventSynchronize(ev));
+        have = __atomic_load_n(&h[2], __ATOMIC_ACQUIRE) == seq;
+        return LSR_OK;
+    }
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n(&h[2], __ATOMIC_ACQUIRE) == seq) { have = true; return LSR_OK; }
+        __builtin_ia32_pause();
+        if ((spins & 0x3FFu) == 0u) {
+            const hipError_t q = hipEventQuery(ev);
+            if (q == hipSuccess) {
+                have = __atomic_load_n(&h[2], __ATOMIC_ACQUIRE) == seq;
+                return LSR_OK;
+            }
+            if (q != hipErrorNotReady) return fail_hip(q);
+            (void)hipGetLastError();   // hipErrorNotReady is sticky in the last-error slot
+        }
+    }
+}
+
 int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii,
                         int64_t *num_pairs_host, int32_t *max_tile_pairs_host, lsr_stream_t stream) {
     g_last_hip_error = 0;
@@ -403,12 +435,10 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
     hipStream_t s = (hipStream_t)stream;
     char *geom = (char *)geom_ws;
     // Pair count and longest list come back through a 64-byte pinned, device-mapped host buffer (one per host
-    // thread, allocated on first use; the library's only allocation and it is host memory).  The LAST
-    // workgroup of k_preprocess writes them, and the host waits on an event recorded right behind that
-    // kernel: k_tile_scan and the SH pass run while the host wakes up, sizes the binning workspace and
-    // launches phase 2 (the device used to idle through that round trip).  Without mapped memory: a
-    // device-to-host copy of the header after k_tile_scan.
+    // thread, allocated on first use; the library's only allocation and it is host memory): wait_pair_count above.
+    // Without mapped memory: a device-to-host copy of the header behind the scan.
     static thread_local uint32_t *h_hdr = nullptr, *h_hdr_dev = nullptr;
+    static thread_local uint32_t h_seq = 0;
     static thread_local hipEvent_t h_events[64] = {};     // one per device this thread has used (events belong to a device)
     static thread_local bool h_tried = false;
     if (!h_tried) {
@@ -417,6 +447,7 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
         if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
             hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
             h_hdr = (uint32_t *)hp; h_hdr_dev = (uint32_t *)dp;
+            memset(hp, 0, 64);
         } else {
             (void)hipGetLastError();
         }
@@ -432,21 +463,28 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
             h_event = h_events[dev];
         }
     }
-    // (one workgroup adds the counts up: beyond 64 k tiles the scan kernel's own totals are the faster way)
-    const bool early = h_event != nullptr && d->num_gaussians > 0 && (int64_t)d->num_views * num_tiles(*d) <= 65536;
-    LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, early ? h_hdr_dev : nullptr, s));
-    if (early) LSR_HIP(hipEventRecord(h_event, s));
-    rc = sh_forward_fork(*d, *in, geom, s);   // view-dependent payload: next to tile_scan, the host round trip and the binning
+    const bool mapped = h_event != nullptr;
+    if (++h_seq == 0u) h_seq = 1u;                        // 0 is what a fresh buffer holds
+    const bool fold = fold_tile_scan(*d);
+    FoldedScan fs{};
+    fs.enabled = fold ? 1 : 0;
+    fs.host_words = mapped ? h_hdr_dev : nullptr; fs.host_seq = h_seq; fs.capacity = 0xFFFFFFFFu;
+    LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, fs, s));
+    if (fold && mapped) LSR_HIP(hipEventRecord(h_event, s));
+    rc = sh_forward_fork(*d, *in, geom, s);   // view-dependent payload: beside the host round trip and the binning
     if (rc) return rc;
-    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, early ? nullptr : h_hdr_dev, 0xFFFFFFFFu, s));
+    if (!fold) {
+        LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, mapped ? h_hdr_dev : nullptr, h_seq, 0xFFFFFFFFu, s));
+        if (mapped) LSR_HIP(hipEventRecord(h_event, s));
+    }
     uint32_t hdr[2] = {0, 0};
-    if (early) {
-        LSR_HIP(hipEventSynchronize(h_event));
-        hdr[0] = h_hdr[0]; hdr[1] = h_hdr[1];
-    } else if (h_hdr) {      // k_tile_scan wrote the mapped words itself
-        LSR_HIP(hipStreamSynchronize(s));
-        hdr[0] = h_hdr[0]; hdr[1] = h_hdr[1];
-    } else {
+    bool have = false;
+    if (mapped) {
+        rc = wait_pair_count(h_hdr, h_seq, h_event, have);
+        if (rc) return rc;
+        if (have) { hdr[0] = h_hdr[0]; hdr[1] = h_hdr[1]; }
+    }
+    if (!have) {
         LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));
         LSR_HIP(hipStreamSynchronize(s));
     }
@@ -470,8 +508,8 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
     if (num_pairs < 0 || max_tile_pairs < 0) return LSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    // binning + compositing per view chunk; waits for the SH payload pass lsr_forward_prepare launched
-    return forward_chunks(*d, *in, (char *)geom_ws, (char *)bin_ws, (char *)img_ws, num_pairs, max_tile_pairs, *out, s, false);
+    // binning + compositing; waits for the SH payload pass lsr_forward_prepare launched
+    return forward_tail(*d, *in, (char *)geom_ws, (char *)bin_ws, (char *)img_ws, num_pairs, max_tile_pairs, *out, s, false);
 }
 
 int lsr_forward_abandon(lsr_stream_t stream) {
@@ -495,11 +533,15 @@ int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     hipStream_t s = (hipStream_t)stream;
     char *geom = (char *)geom_ws;
     // the same stage sequence as prepare + render; nothing between the launches waits for the device
-    LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, nullptr, s));
+    const bool fold = fold_tile_scan(*d);
+    FoldedScan fs{};
+    fs.enabled = fold ? 1 : 0;
+    fs.capacity = (uint32_t)pair_capacity;
+    LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, fs, s));
     rc = sh_forward_fork(*d, *in, geom, s);
     if (rc) return rc;
-    LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, (uint32_t)pair_capacity, s));
-    return forward_chunks(*d, *in, geom, (char *)bin_ws, (char *)img_ws, pair_capacity, max_tile_hint, *out, s, true);
+    if (!fold) LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, 0u, (uint32_t)pair_capacity, s));
+    return forward_tail(*d, *in, geom, (char *)bin_ws, (char *)img_ws, pair_capacity, max_tile_hint, *out, s, true);
 }
 
 int lsr_forward_status(const lsr_dims *d, const void *geom_ws, int64_t *num_pairs_host, int32_t *max_tile_pairs_host,

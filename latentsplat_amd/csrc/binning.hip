@@ -6,7 +6,9 @@
 //                 total pair count and the longest list (header[0], header[1]); also emits the
 //                 compositing work items — two (view, tile, half) items per tile — ordered
 //                 longest-list-first (counting sort): the work queue order of both compositing
-//                 kernels (longest-processing-time-first balancing).
+//                 kernels (longest-processing-time-first balancing).  Since round 4 this work is done by the
+//                 last workgroup of k_preprocess (lsr_tile_scan.h); the kernel here remains for calls whose
+//                 V*T counts do not fit that workgroup's registers.
 //   k_scatter   : every visible Gaussian writes (depth_bits<<32 | index) into each tile segment
 //                 it overlaps.  Slots come from a two-level reservation: LDS counters per block,
 //                 then ONE global atomic per (block, tile).
@@ -15,7 +17,9 @@
 //                 == the published stable sort by depth with ties in emission (= index) order,
 //                 so lists are bit-exact whatever order the scatter produced.
 #include "lsr_blend.h"
+#include "lsr_tile_scan.h"
 #include <algorithm>
+#include <mutex>
 #ifdef LSR_ENABLE_TRACE
 #include <cstdio>
 #include <cstdlib>
@@ -26,161 +30,23 @@ namespace lsr {
 
 // ------------------------------------------------------------------------------------------
 constexpr int kScanThreads = 1024;
-constexpr int kScanWaves = kScanThreads / LSR_WAVE;
 
-// Block-wide exclusive prefix sum of one value per thread: wave-level scans in registers (6 shuffles),
-// one LDS hop for the 16 wave totals — two barriers instead of the 20 of a Hillis-Steele ladder over
-// 1024 LDS slots (the kernel is a single workgroup on the critical path of every forward).
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
-    const int lane = threadIdx.x & (LSR_WAVE - 1), wid = threadIdx.x / LSR_WAVE;
-    uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < LSR_WAVE; off <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
-        if (lane >= off) incl += t;
-    }
-    if (lane == LSR_WAVE - 1) s_wave[wid] = incl;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < kScanWaves; ++w) {
-        const uint32_t x = s_wave[w];
-        tot += x;
-        base += w < wid ? x : 0u;
-    }
-    __syncthreads();   // s_wave may be reused
-    total = tot;
-    return base + incl - v;
-}
-// Per-thread chunk of the counts in registers when it is short (kScanRegs words: the headline call has 4 per
-// thread): the kernel is ONE workgroup on the critical path of every forward and used to read its counts from
-// memory four times (sum, offsets, histogram, placement).
-constexpr int kScanRegs = 8;
+constexpr int kScanRegs = 8;   // counts per thread kept in registers (4 at 1024 threads x 4096 tiles)
 
 __global__ void __launch_bounds__(kScanThreads)
 k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *header,
-            uint32_t *host_mirror, uint32_t *__restrict__ order, int N, uint32_t capacity, int K) {
-    __shared__ uint32_t s_wave[kScanWaves];
-    __shared__ uint32_t s_cls[kScanThreads];      // counting-sort classes: histogram -> running offsets
-    __shared__ uint64_t s_tot64[kScanWaves];
-    __shared__ uint32_t s_max[kScanWaves];
-    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
-    const int per = (N + kScanThreads - 1) / kScanThreads;
-    const int lo = tid * per, hi = min(N, lo + per);
-    const bool in_regs = per <= kScanRegs;        // block-uniform
-    uint32_t creg[kScanRegs];
-    if (in_regs) {
-#pragma unroll
-        for (int q = 0; q < kScanRegs; ++q) {     // unconditional loads at clamped positions: all in flight together
-            const uint32_t c = count[min(lo + q, N - 1)];
-            creg[q] = (q < per && lo + q < hi) ? c : 0u;
-        }
-    }
-    uint32_t sum = 0, mx = 0;
-    uint64_t sum64 = 0;
-    if (in_regs) {
-#pragma unroll
-        for (int q = 0; q < kScanRegs; ++q) { sum += creg[q]; mx = max(mx, creg[q]); }
-        sum64 = sum;                              // at most 8 counts of < 2^28 each per thread
-    } else {
-        for (int i = lo; i < hi; ++i) { const uint32_t c = count[i]; sum += c; sum64 += c; mx = max(mx, c); }
-    }
-    // one combined pass: exclusive scan of the chunk sums, the longest list, the 64-bit total (two barriers)
-    uint32_t incl = sum;
-#pragma unroll
-    for (int off = 1; off < LSR_WAVE; off <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, off);
-        if (lane >= off) incl += t;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, off)); sum64 += __shfl_xor(sum64, off); }
-    if (lane == LSR_WAVE - 1) s_wave[wid] = incl;
-    if (lane == 0) { s_max[wid] = mx; s_tot64[wid] = sum64; }
-    __syncthreads();
-    uint32_t wbase = 0, total = 0, maxc = 0;
-    sum64 = 0;
-#pragma unroll
-    for (int w = 0; w < kScanWaves; ++w) {
-        const uint32_t x = s_wave[w];
-        total += x;
-        wbase += w < wid ? x : 0u;
-        maxc = max(maxc, s_max[w]);
-        sum64 += s_tot64[w];
-    }
-    __syncthreads();   // s_wave is reused below
-    uint32_t run = wbase + incl - sum;            // exclusive prefix of this thread's chunk
-    // Offsets are 32-bit: a call whose pair count does not fit (possible in principle: every Gaussian can touch every
-    // tile of every view) is reported as an overflow with the count saturated, never silently wrapped.
-    const bool wrapped = sum64 > 0xFFFFFFFFull;
-    if (wrapped) total = 0xFFFFFFFFu;
-    // Offsets are clamped to the capacity of the binning workspace: with exact sizing (capacity =
-    // UINT32_MAX) nothing changes; in the no-sync forward a scene that produces more pairs than the
-    // caller provided for gets its last lists truncated (never an out-of-bounds write) and the
-    // overflow word set — the caller must then discard the result and retry with more room.
-    if (in_regs) {
-#pragma unroll
-        for (int q = 0; q < kScanRegs; ++q) { if (lo + q < hi) start[lo + q] = min(run, capacity); run += creg[q]; }
-    } else {
-        for (int i = lo; i < hi; ++i) { start[i] = min(run, capacity); run += count[i]; }
-    }
-    if (tid == kScanThreads - 1) {
-        start[N] = min(total, capacity); header[kHdrPairs] = total; header[kHdrMaxTile] = maxc;
-        header[kHdrOverflow] = (total > capacity || wrapped) ? 1u : 0u;
-        // the two numbers the host is waiting for go straight into its (mapped, pinned) memory:
-        // no copy command between this kernel and the stream synchronisation
-        if (host_mirror) { host_mirror[0] = total; host_mirror[1] = maxc; }
-    }
-    // ---- work items, costliest first: counting sort on kScanThreads classes of the per-tile cost
-    // (= canonical list length; the two half-tile items of a tile stay together).  The exact half list
-    // lengths only exist after k_sort_tiles; the order is a scheduling hint (longest-processing-time
-    // first for the compositing kernels' work queue), never a correctness matter. ----
-    // With K view chunks (lsr_internal.h) every chunk gets its own costliest-first list: chunk c's items are
-    // order[2 c N/K, 2 (c+1) N/K).
-    const uint64_t scale = (uint64_t)maxc + 1u;
-    auto cls = [&](uint32_t w) -> uint32_t { return kScanThreads - 1 - (uint32_t)(((uint64_t)w * kScanThreads) / scale); };
-    if (tid == 0) header[kHdrNumItems] = 2u * (uint32_t)N;
-    const int per_chunk = N / K;
-    for (int c = 0; c < K; ++c) {
-        const int a = max(lo, c * per_chunk), b = min(hi, (c + 1) * per_chunk);
-        s_cls[tid] = 0;
-        __syncthreads();
-        if (in_regs) {
-#pragma unroll
-            for (int q = 0; q < kScanRegs; ++q) if (lo + q >= a && lo + q < b) atomicAdd(&s_cls[cls(creg[q])], 2u);
-        } else {
-            for (int i = a; i < b; ++i) atomicAdd(&s_cls[cls(count[i])], 2u);
-        }
-        __syncthreads();
-        const uint32_t mine = s_cls[tid];
-        uint32_t num_items;
-        const uint32_t first = block_exclusive_scan(mine, s_wave, num_items);   // exclusive start of class tid
-        s_cls[tid] = first;
-        __syncthreads();
-        uint32_t *ord = order + 2 * (size_t)c * per_chunk;
-        if (in_regs) {
-#pragma unroll
-            for (int q = 0; q < kScanRegs; ++q)
-                if (lo + q >= a && lo + q < b) {
-                    const uint32_t at = atomicAdd(&s_cls[cls(creg[q])], 2u);
-                    ord[at] = (uint32_t)(lo + q); ord[at + 1] = (uint32_t)(lo + q) | (1u << kItemHalfShift);
-                }
-        } else {
-            for (int i = a; i < b; ++i) {
-                const uint32_t at = atomicAdd(&s_cls[cls(count[i])], 2u);
-                ord[at] = (uint32_t)i; ord[at + 1] = (uint32_t)i | (1u << kItemHalfShift);
-            }
-        }
-        __syncthreads();
-    }
+            uint32_t *host_words, uint32_t host_seq, uint32_t *__restrict__ order, int N, uint32_t capacity) {
+    __shared__ TileScanShared<kScanThreads> s_scan;
+    tile_scan_block<kScanThreads, kScanRegs, false>(count, start, header, HostMirror{host_words, host_seq}, order, N, capacity, s_scan);
 }
 
-hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror, uint32_t pair_capacity, hipStream_t s) {
+hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_words, uint32_t host_seq, uint32_t pair_capacity, hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const int N = d.num_views * (int)num_tiles(d);
     prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
                        (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
-                       (uint32_t *)(geom + L.header), host_mirror, (uint32_t *)(geom + L.tile_order), N, pair_capacity, view_chunks(d));
+                       (uint32_t *)(geom + L.header), host_words, host_seq, (uint32_t *)(geom + L.tile_order), N, pair_capacity);
     prof_end(kStTileScan, s);
     return hipGetLastError();
 }
@@ -189,9 +55,9 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror
 constexpr int kScatThreads = 256;
 constexpr int kScatItems = 12;   // most (view, Gaussian) items of one thread; the launcher picks the count
 
-template <bool LDS_RESERVE, bool CHECK, bool NARROW>
+template <bool LDS_RESERVE, bool NARROW>
 __global__ void __launch_bounds__(kScatThreads, 8)
-k_scatter(int G, int gx, int T, int view0, const char *__restrict__ binrec,
+k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
           const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ tile_cursor,
           uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, unsigned long long *trace) {
 #ifdef LSR_ENABLE_TRACE
@@ -203,7 +69,7 @@ k_scatter(int G, int gx, int T, int view0, const char *__restrict__ binrec,
     extern __shared__ uint32_t s_mem[];  // [T] counts, [T] bases
     uint32_t *s_cnt = s_mem, *s_base = s_mem + T;
     const uint32_t unit = blockIdx.x;   // view-major (view, chunk)
-    const int v = view0 + (int)(unit / chunks);
+    const int v = (int)(unit / chunks);
     const size_t vo = (size_t)v * G;
     const uint32_t *ts = tile_start + (size_t)v * T;
     uint32_t *cur = tile_cursor + (size_t)v * T;
@@ -295,7 +161,7 @@ k_scatter(int G, int gx, int T, int view0, const char *__restrict__ binrec,
 }
 
 // ------------------------------------------------------------------------------------------
-constexpr int kSortThreads = 512;
+constexpr int kSortThreads = 512;      // workgroup of the later tiers and of the global merge path
 
 // Where k_sort_tiles puts the two half-tile render lists of a tile (BinLayout::half_list, GeomLayout::half_count).
 struct HalfOut {
@@ -307,38 +173,37 @@ struct HalfOut {
     // variants: a few hundred workgroups looping over a list instead of one (large-LDS) workgroup per tile that
     // finds nothing to do — the empty second-tier launch over 4096 tiles cost 93 us.
     // Two lists share the array from its two ends (a tile is in at most one, so they cannot meet):
-    //   class 0, from the front: kSortTier1 < n <= kSortTier2   -> k_sort_tiles<kSortTier2, true>
-    //   class 1, from the back :  n > kSortTier2                -> k_sort_tiles<kSortLdsMax, true>, and for
-    //                                                              n > kSortLdsMax the global merge path
+    //   class 0, from the front: first-tier capacity < n <= kSortTier2   -> k_sort_tiles<kSortTier2, 512, true>
+    //   class 1, from the back :  n > kSortTier2                         -> k_sort_tiles<kSortLdsMax, 512, true>, and for
+    //                                                                       n > kSortLdsMax the global merge path
     uint32_t *long_list;
-    uint32_t long_cap;        // entries of the array (tiles of the launch's view chunk)
+    uint32_t long_cap;        // entries of the array (tiles of the call)
     uint32_t *long_count[2];  // header words
 };
-constexpr int kSortTier1 = 4096, kSortTier2 = 8192;
+constexpr int kSortTier2 = 8192;
 __device__ __forceinline__ uint32_t long_tile(const HalfOut &ho, int cls, uint32_t i) {
     return ho.long_list[cls ? ho.long_cap - 1u - i : i];
 }
 __device__ __forceinline__ uint32_t key_index(uint32_t low_word) { return low_word >> kKeyIndexShift; }
 constexpr int kEmitTab = 130;   // uint64 words of LDS scratch emit_half_lists needs
 
-// Block-wide (kSortThreads threads): walks the tile's depth-sorted list in order and appends every entry to
+// Block-wide (THREADS threads): walks the tile's depth-sorted list in order and appends every entry to
 // the list of each half of the tile (pixel rows 0-7 / 8-15) its footprint can reach (order preserved), as
 // `index | 8 sub-block bits << 24`; the sub-block mask comes from the code in the low key byte.
 // low_word(p) = low key word of sorted position p.  A pass covers 64 wave-chunks of 64 positions: per chunk
 // and half a ballot count (two 32-bit fields of one u64), one wave scans the 64 chunk totals, then every
 // entry's place is chunk offset + lanes below it in the ballot.
 // hdst = half_list + 2 * tile_start: the list of half h starts at hdst + h * n.
-template <class LowWord>
+template <int THREADS, class LowWord>
 __device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint32_t *hcnt, uint64_t *s_tab, LowWord low_word) {
     const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
-    constexpr int kWaves = kSortThreads / LSR_WAVE, kSteps = LSR_WAVE / kWaves;
+    constexpr int kWaves = THREADS / LSR_WAVE;
     uint32_t run0 = 0u, run1 = 0u;
     for (uint32_t base = 0; base < n; base += LSR_WAVE * LSR_WAVE) {
         // (nothing but the running lengths lives across the barriers: the second phase reads the words again — the
         // kernel's register budget decides how many of its workgroups share a CU)
-#pragma unroll
-        for (int st = 0; st < kSteps; ++st) {
-            const uint32_t p = base + (uint32_t)((st * kWaves + wid) * LSR_WAVE + lane);
+        for (int c = wid; c < LSR_WAVE; c += kWaves) {                  // chunk c: positions base + 64 c .. + 63
+            const uint32_t p = base + (uint32_t)(c * LSR_WAVE + lane);
             uint64_t packed = 0;
             if (p - lane < n) {                                        // wave-uniform: chunks beyond the list only write their zero
                 const uint32_t w = low_word(min(p, n - 1));            // unconditional at a clamped position
@@ -346,7 +211,7 @@ __device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint
                 packed = (uint64_t)__builtin_popcountll(__ballot((m16 & 0x00FFu) != 0u)) |
                          ((uint64_t)__builtin_popcountll(__ballot((m16 & 0xFF00u) != 0u)) << 32);
             }
-            if (lane == 0) s_tab[st * kWaves + wid] = packed;
+            if (lane == 0) s_tab[c] = packed;
         }
         __syncthreads();
         if (wid == 0) {
@@ -359,13 +224,12 @@ __device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint
         }
         __syncthreads();
         const uint64_t tot = s_tab[2 * LSR_WAVE];
-#pragma unroll
-        for (int st = 0; st < kSteps; ++st) {
-            const uint32_t p = base + (uint32_t)((st * kWaves + wid) * LSR_WAVE + lane);
-            if (base + (uint32_t)((st * kWaves + wid) * LSR_WAVE) >= n) break;   // wave-uniform
+        for (int c = wid; c < LSR_WAVE; c += kWaves) {
+            const uint32_t p = base + (uint32_t)(c * LSR_WAVE + lane);
+            if (p - lane >= n) break;                                  // wave-uniform
             const uint32_t w = low_word(min(p, n - 1));
             const uint32_t idx = key_index(w), m16 = p < n ? code_mask(w & 0xFFu) : 0u;
-            const uint64_t off = s_tab[LSR_WAVE + st * kWaves + wid];
+            const uint64_t off = s_tab[LSR_WAVE + c];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const uint32_t bits = half_bits(m16, h);
@@ -382,7 +246,8 @@ __device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint
     if (tid < 2) hcnt[tid] = tid == 0 ? run0 : run1;
 }
 
-// One workgroup per (tile, view); list length n <= CAP, keys sorted inside LDS.
+// One workgroup of THREADS threads per (tile, view); list length n <= CAP = 8 * THREADS for the first tier (the keys of a
+// list live in registers, eight per thread), keys sorted inside LDS.
 //
 // Order-preserving bucket sort: bucket = (key - min) >> shift is monotone in the key, so a histogram +
 // scan puts every key into its final neighbourhood; inside a bucket (about one key on average) a
@@ -392,18 +257,22 @@ __device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint
 // Both paths produce the same total order of distinct 64-bit keys, i.e. the bit-exact published
 // ordering.
 //
-// Lists up to 4096 keys (REG): the list is read from memory once into registers; the returning
-// histogram atomic is the key's arrival rank in its bucket, so after the scan every key is placed
-// with a plain LDS write, and its final position is found by EVERY KEY IN PARALLEL (count the smaller
-// members of its bucket, four per step).  The round-1 version finished buckets with a serial
-// insertion sort, four buckets per thread: a chain of dependent LDS round trips that was half of
-// the kernel (phase trace: 5.1 of 10.2 us per workgroup).  All LDS scratch lives in the dynamic
-// allocation (the reduction scratch aliases the key array before keys are placed) so that four
-// 4096-key workgroups share a CU's 160 KB.
+// The list is read from memory once into registers; the returning histogram atomic is the key's arrival rank
+// in its bucket, so after the scan every key is placed with a plain LDS write, and its final position is found
+// by EVERY KEY IN PARALLEL (count the smaller members of its bucket, four per step).  The round-1 version
+// finished buckets with a serial insertion sort, four buckets per thread: a chain of dependent LDS round trips
+// that was half of the kernel (phase trace: 5.1 of 10.2 us per workgroup).  All LDS scratch lives in the dynamic
+// allocation (the reduction scratch aliases the key array before keys are placed).
+//
+// Round 4: the first tier's workgroup size follows the longest list of the call — 128 / 256 / 384 / 512 threads for
+// lists up to 1024 / 2048 / 3072 / 4096 keys, always eight keys per thread and ~76 VGPRs — because the kernel is a
+// chain of a dozen barrier-separated, latency-bound phases: what it needs is TILES IN FLIGHT per compute unit (24
+// resident waves = 12 / 6 / 4 / 3 tiles), not threads per tile.  Round 3 ran every call whose longest list exceeded
+// 2048 keys on the 512-thread variant (the bench scene: lists of 1 920 +- 50 keys, longest 2 130 -> 3 tiles per CU).
 constexpr uint32_t kBucketOverflow = 48;   // longest bucket the in-bucket pass may get
 
 // tier: 0 = first launch of a call (also owns the empty lists), 1 = a later tier (its tiles come from a long list)
-template <int CAP>
+template <int CAP, int THREADS>
 __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier, const uint32_t *__restrict__ tile_start,
                                           const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list,
                                           const HalfOut &ho, unsigned long long *trace) {
@@ -413,8 +282,9 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
 #define LSR_STAMP(k) do { } while (0)
 #endif
     LSR_STAMP(0);
+    static_assert(CAP % THREADS == 0, "whole keys per thread");
     constexpr int NB = CAP < 2048 ? CAP : 2048;          // buckets
-    constexpr int kWaves = kSortThreads / LSR_WAVE;
+    constexpr int kWaves = THREADS / LSR_WAVE;
     uint32_t *s_cnt = (uint32_t *)(s_keys + CAP);         // [NB] histogram -> bucket offsets
     uint64_t *s_red = s_keys;                             // [2 * kWaves] range reduction  } alias the key array:
     uint32_t *s_wsum = (uint32_t *)(s_keys + 2 * kWaves); // [kWaves] scan partials        } dead before the
@@ -451,28 +321,21 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
         return;
     }
 
-    constexpr bool REG = true;   // every LDS variant keeps its keys in registers (the 16 384-key one: 32 keys per thread, 256 VGPRs)
-    constexpr int PERK = REG ? CAP / kSortThreads : 1;
+    constexpr int PERK = CAP / THREADS;   // keys per thread, register-resident (the 16 384-key variant: 32 keys, 256 VGPRs)
     uint64_t kreg[PERK];
-    if (REG) {
 #pragma unroll
-        for (int q = 0; q < PERK; ++q) {
-            const uint32_t i = tid + q * kSortThreads;
-            const uint64_t k = src[min(i, n - 1)];   // unconditional (clamped) so that all loads are in flight together
-            kreg[q] = i < n ? k : ~0ull;
-        }
+    for (int q = 0; q < PERK; ++q) {
+        const uint32_t i = tid + q * THREADS;
+        const uint64_t k = src[min(i, n - 1)];   // unconditional (clamped) so that all loads are in flight together
+        kreg[q] = i < n ? k : ~0ull;
     }
     // ---- key range ----
     uint64_t kmin = ~0ull, kmax = 0ull;
-    if (REG) {
 #pragma unroll
-        for (int q = 0; q < PERK; ++q) {
-            const uint64_t k = kreg[q];
-            kmin = k < kmin ? k : kmin;
-            if (tid + q * kSortThreads < n) kmax = k > kmax ? k : kmax;
-        }
-    } else {
-        for (uint32_t i = tid; i < n; i += kSortThreads) { const uint64_t k = src[i]; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+    for (int q = 0; q < PERK; ++q) {
+        const uint64_t k = kreg[q];
+        kmin = k < kmin ? k : kmin;
+        if (tid + q * THREADS < n) kmax = k > kmax ? k : kmax;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -480,7 +343,7 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
         kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
     }
     if (lane == 0) { s_red[2 * wid] = kmin; s_red[2 * wid + 1] = kmax; }
-    for (int b = tid; b < NB; b += kSortThreads) s_cnt[b] = 0;
+    for (int b = tid; b < NB; b += THREADS) s_cnt[b] = 0;
     if (tid == 0) *s_flag = 0;
     __syncthreads();
 #pragma unroll
@@ -494,21 +357,20 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
     constexpr int LOGNB = NB == 4096 ? 12 : (NB == 2048 ? 11 : 10);
     const int shift = bits > LOGNB ? bits - LOGNB : 0;
 
-    // ---- histogram (REG: the returning atomic is the key's rank inside its bucket), scan ----
+    // ---- histogram (the returning atomic is the key's rank inside its bucket), scan ----
     uint32_t rnk[PERK];
-    if (REG) {
 #pragma unroll
-        for (int q = 0; q < PERK; ++q)   // (under the validity test: padding lanes on one dummy word serialise — measured 0.048 -> 0.077 ms)
-            if (tid + q * kSortThreads < n) rnk[q] = atomicAdd(&s_cnt[(uint32_t)((kreg[q] - kmin) >> shift)], 1u);
-    } else {
-        for (uint32_t i = tid; i < n; i += kSortThreads) atomicAdd(&s_cnt[(uint32_t)((src[i] - kmin) >> shift)], 1u);
-    }
+    for (int q = 0; q < PERK; ++q)   // (under the validity test: padding lanes on one dummy word serialise — measured 0.048 -> 0.077 ms)
+        if (tid + q * THREADS < n) rnk[q] = atomicAdd(&s_cnt[(uint32_t)((kreg[q] - kmin) >> shift)], 1u);
     __syncthreads();
     LSR_STAMP(2);
-    constexpr int PER = NB / kSortThreads;
+    constexpr int PER = (NB + THREADS - 1) / THREADS;   // buckets per thread of the scan (the last threads may own fewer)
     uint32_t loc[PER], sum = 0, mx = 0;
 #pragma unroll
-    for (int q = 0; q < PER; ++q) { loc[q] = s_cnt[tid * PER + q]; sum += loc[q]; mx = loc[q] > mx ? loc[q] : mx; }
+    for (int q = 0; q < PER; ++q) {
+        loc[q] = (NB % THREADS == 0 || tid * PER + q < NB) ? s_cnt[min(tid * PER + q, NB - 1)] : 0u;
+        sum += loc[q]; mx = loc[q] > mx ? loc[q] : mx;
+    }
     uint32_t incl = sum;
 #pragma unroll
     for (int off = 1; off < LSR_WAVE; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
@@ -521,82 +383,65 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
     const bool overflow = *s_flag != 0;
     if (!overflow) {
 #pragma unroll
-        for (int q = 0; q < PER; ++q) { s_cnt[tid * PER + q] = run; run += loc[q]; }   // exclusive starts
+        for (int q = 0; q < PER; ++q) { if (NB % THREADS == 0 || tid * PER + q < NB) s_cnt[tid * PER + q] = run; run += loc[q]; }   // exclusive starts
         __syncthreads();   // also: every thread is done with the aliased scratch
         LSR_STAMP(3);
-        if (REG) {
-            // ---- place: start of the bucket + arrival rank ----
+        // ---- place: start of the bucket + arrival rank ----
 #pragma unroll
-            for (int q = 0; q < PERK; ++q)
-                if (tid + q * kSortThreads < n) s_keys[s_cnt[(uint32_t)((kreg[q] - kmin) >> shift)] + rnk[q]] = kreg[q];
-            __syncthreads();
-            LSR_STAMP(4);
-            // ---- final position of every key: bucket start + number of smaller members ----
-            uint32_t dst[PERK];
+        for (int q = 0; q < PERK; ++q)
+            if (tid + q * THREADS < n) s_keys[s_cnt[(uint32_t)((kreg[q] - kmin) >> shift)] + rnk[q]] = kreg[q];
+        __syncthreads();
+        LSR_STAMP(4);
+        // ---- final position of every key: bucket start + number of smaller members ----
+        uint32_t dst[PERK];
 #pragma unroll
-            for (int q = 0; q < PERK; ++q) {
-                dst[q] = 0;
-                if (tid + q * kSortThreads < n) {
-                    const uint64_t key = kreg[q];
-                    const uint32_t b = (uint32_t)((key - kmin) >> shift);
-                    const uint32_t lo = s_cnt[b], hi = b + 1 < (uint32_t)NB ? s_cnt[b + 1] : n;
-                    uint32_t below = 0;
-                    for (uint32_t j = lo; j < hi; j += 4) {
-                        const uint32_t last = hi - 1;
-                        const uint64_t m0 = s_keys[j], m1 = s_keys[min(j + 1, last)], m2 = s_keys[min(j + 2, last)], m3 = s_keys[min(j + 3, last)];
-                        below += (m0 < key) + (j + 1 < hi && m1 < key) + (j + 2 < hi && m2 < key) + (j + 3 < hi && m3 < key);
-                    }
-                    dst[q] = lo + below;
+        for (int q = 0; q < PERK; ++q) {
+            dst[q] = 0;
+            if (tid + q * THREADS < n) {
+                const uint64_t key = kreg[q];
+                const uint32_t b = (uint32_t)((key - kmin) >> shift);
+                const uint32_t lo = s_cnt[b], hi = b + 1 < (uint32_t)NB ? s_cnt[b + 1] : n;
+                uint32_t below = 0;
+                for (uint32_t j = lo; j < hi; j += 4) {
+                    const uint32_t last = hi - 1;
+                    const uint64_t m0 = s_keys[j], m1 = s_keys[min(j + 1, last)], m2 = s_keys[min(j + 2, last)], m3 = s_keys[min(j + 3, last)];
+                    below += (m0 < key) + (j + 1 < hi && m1 < key) + (j + 2 < hi && m2 < key) + (j + 3 < hi && m3 < key);
                 }
+                dst[q] = lo + below;
             }
-            __syncthreads();   // all reads of the key array done: its storage becomes the sorted list of low key words
-            uint32_t *s_out = (uint32_t *)s_keys;
-#pragma unroll
-            for (int q = 0; q < PERK; ++q)
-                if (tid + q * kSortThreads < n) s_out[dst[q]] = (uint32_t)kreg[q];
-            __syncthreads();
-            LSR_STAMP(5);
-            for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = key_index(s_out[i]);
-            // half-tile render lists (the bucket offsets in s_cnt are dead: scratch of the emitter)
-            emit_half_lists(n, hdst, hcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return s_out[p]; });
-            LSR_STAMP(6);
-        } else {
-            // ---- lists beyond the register budget: scatter with a second atomic (s_cnt[b] ends up as the
-            // END of bucket b), then a short insertion sort per bucket ----
-            for (uint32_t i = tid; i < n; i += kSortThreads) {
-                const uint64_t k = src[i];
-                s_keys[atomicAdd(&s_cnt[(uint32_t)((k - kmin) >> shift)], 1u)] = k;
-            }
-            __syncthreads();
-            for (int b = tid; b < NB; b += kSortThreads) {
-                const uint32_t lo = b ? s_cnt[b - 1] : 0u, hi = s_cnt[b];
-                for (uint32_t i = lo + 1; i < hi; ++i) {
-                    const uint64_t k = s_keys[i];
-                    uint32_t j = i;
-                    while (j > lo && s_keys[j - 1] > k) { s_keys[j] = s_keys[j - 1]; --j; }
-                    s_keys[j] = k;
-                }
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = key_index((uint32_t)s_keys[i]);
-            emit_half_lists(n, hdst, hcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return (uint32_t)s_keys[p]; });
         }
+        __syncthreads();   // all reads of the key array done: its storage becomes the sorted list of low key words
+        uint32_t *s_out = (uint32_t *)s_keys;
+#pragma unroll
+        for (int q = 0; q < PERK; ++q)
+            if (tid + q * THREADS < n) s_out[dst[q]] = (uint32_t)kreg[q];
+        __syncthreads();
+        LSR_STAMP(5);
+        for (uint32_t i = tid; i < n; i += THREADS) point_list[start + i] = key_index(s_out[i]);
+        // half-tile render lists (the bucket offsets in s_cnt are dead: scratch of the emitter)
+        emit_half_lists<THREADS>(n, hdst, hcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return s_out[p]; });
+        LSR_STAMP(6);
     } else {
         // ---- bitonic network over the padded list ----
         uint32_t npad = 2;
         while (npad < n) npad <<= 1;
         __syncthreads();
-        if (REG) {
+        if (npad <= (uint32_t)CAP) {
 #pragma unroll
             for (int q = 0; q < PERK; ++q)
-                if (tid + q * kSortThreads < npad) s_keys[tid + q * kSortThreads] = kreg[q];   // padding = ~0
+                if (tid + q * THREADS < npad) s_keys[tid + q * THREADS] = kreg[q];   // padding = ~0
         } else {
-            for (uint32_t i = tid; i < npad; i += kSortThreads) s_keys[i] = i < n ? src[i] : ~0ull;
+            // (CAP = 3072: a list of 2049 .. 3072 keys pads to 4096 > CAP; the key array and the bucket counters behind it
+            // hold 3072 + 1024 keys' worth of bytes — exactly the padded list)
+            static_assert(CAP * 8 + NB * 4 >= (CAP <= 2048 ? CAP : (CAP <= 4096 ? 4096 : CAP)) * 8, "bitonic padding fits the allocation");
+#pragma unroll
+            for (int q = 0; q < PERK; ++q) s_keys[tid + q * THREADS] = kreg[q];
+            for (uint32_t i = CAP + tid; i < npad; i += THREADS) s_keys[i] = ~0ull;
         }
         __syncthreads();
         for (uint32_t k = 2; k <= npad; k <<= 1) {
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t t = tid; t < (npad >> 1); t += kSortThreads) {
+                for (uint32_t t = tid; t < (npad >> 1); t += THREADS) {
                     // t-th compare-exchange of this stage: partner indices differ in bit j
                     const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                     const uint32_t hi = lo | j;
@@ -607,8 +452,9 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
                 __syncthreads();
             }
         }
-        for (uint32_t i = tid; i < n; i += kSortThreads) point_list[start + i] = key_index((uint32_t)s_keys[i]);
-        emit_half_lists(n, hdst, hcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return (uint32_t)s_keys[p]; });
+        // (the emitter's scratch, the counter array, only overlaps padding keys: it reads positions < n <= CAP)
+        for (uint32_t i = tid; i < n; i += THREADS) point_list[start + i] = key_index((uint32_t)s_keys[i]);
+        emit_half_lists<THREADS>(n, hdst, hcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return (uint32_t)s_keys[p]; });
     }
 #ifdef LSR_ENABLE_TRACE
     if (trace && tid == 0) {
@@ -621,21 +467,23 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
 #undef LSR_STAMP
 }
 
-// PERSISTENT = false: one workgroup per (view, tile) of the launch's view chunk (first tier); true: workgroups looping
-// over the previous tier's long list.  (Two kernels rather than one with a runtime switch: with both paths in one
-// body the first-tier variant needed 112 instead of 80 VGPRs and lost a resident workgroup per CU.)
-template <int CAP, bool PERSISTENT>
-__global__ void __launch_bounds__(kSortThreads, CAP <= 4096 ? 6 : (CAP <= 8192 ? 4 : 2))   // waves per SIMD at the workgroups per CU the LDS allows (4 / 2 / 1): the register budget follows
-k_sort_tiles(int T, int view0, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
+// PERSISTENT = false: one workgroup per (view, tile) (first tier), in the costliest-first order of the work items when
+// `order` is given (longest-processing-time first: the launch runs several rounds of resident workgroups and should
+// not end on its longest lists); true: workgroups looping over the previous tier's long list.  (Two kernels rather
+// than one with a runtime switch: with both paths in one body the first-tier variant needed 112 instead of 80 VGPRs
+// and lost a resident workgroup per CU.)
+template <int CAP, int THREADS, bool PERSISTENT>
+__global__ void __launch_bounds__(THREADS, CAP <= 4096 ? 6 : (CAP <= 8192 ? 4 : 2))   // waves per SIMD: the register budget follows
+k_sort_tiles(int cls, const uint32_t *__restrict__ order, const uint32_t *__restrict__ tile_start, const uint64_t *__restrict__ keys,
              uint32_t *__restrict__ point_list, HalfOut ho, unsigned long long *trace) {
     extern __shared__ uint64_t s_keys[];                  // [CAP] keys grouped by bucket / sorted, then [NB] u32 counters
     if (!PERSISTENT) {
-        sort_tile<CAP>(s_keys, blockIdx.x + (size_t)view0 * T, 0, tile_start, keys, point_list, ho, trace);
+        const size_t vt = order ? (size_t)(order[2 * (size_t)blockIdx.x] & kItemTileMask) : (size_t)blockIdx.x;
+        sort_tile<CAP, THREADS>(s_keys, vt, 0, tile_start, keys, point_list, ho, trace);
     } else {
-        const int cls = view0;     // persistent launches: the class of long tiles this launch owns
-        const uint32_t count = *ho.long_count[cls];
+        const uint32_t count = *ho.long_count[cls];       // persistent launches: the class of long tiles this launch owns
         for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-            sort_tile<CAP>(s_keys, long_tile(ho, cls, i), 1, tile_start, keys, point_list, ho, trace);
+            sort_tile<CAP, THREADS>(s_keys, long_tile(ho, cls, i), 1, tile_start, keys, point_list, ho, trace);
             __syncthreads();   // the LDS arrays are reused by the next tile
         }
     }
@@ -676,17 +524,37 @@ k_sort_tiles_global(const uint32_t *__restrict__ tile_start, uint64_t *keys, uin
         for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
             point_list[start + i] = key_index((uint32_t)src[i]);
         const uint64_t *sorted = src;
-        emit_half_lists(n, ho.half_list + 2 * (size_t)start, ho.half_count + 2 * vt, s_tab, [&](uint32_t p) { return (uint32_t)sorted[p]; });
+        emit_half_lists<kSortThreads>(n, ho.half_list + 2 * (size_t)start, ho.half_count + 2 * vt, s_tab, [&](uint32_t p) { return (uint32_t)sorted[p]; });
         __syncthreads();
     }
 }
 
+// Dynamic LDS of a sort variant, and (once per process, device and variant) the function attribute the larger ones need.
+template <int CAP>
+constexpr size_t sort_lds_bytes() { return (size_t)CAP * 8 + (size_t)(CAP < 2048 ? CAP : 2048) * 4; }
+template <int CAP, int THREADS, bool PERS>
+static void sort_launch(dim3 grid, hipStream_t s, int cls, const uint32_t *order, const uint32_t *ts, const uint64_t *keys,
+                        uint32_t *plist, const HalfOut &ho, unsigned long long *trace) {
+    constexpr size_t lds = sort_lds_bytes<CAP>();
+    if (lds > 48 * 1024) {
+        static uint64_t done = 0;     // one bit per device id
+        static std::mutex mu;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev < 0 || dev >= 64 || !((done >> dev) & 1ull)) {
+            (void)hipFuncSetAttribute((const void *)k_sort_tiles<CAP, THREADS, PERS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (dev >= 0 && dev < 64) done |= 1ull << dev;
+        }
+    }
+    hipLaunchKernelGGL((k_sort_tiles<CAP, THREADS, PERS>), grid, dim3(THREADS), lds, s, cls, order, ts, keys, plist, ho, trace);
+}
+
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
-                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts, ViewChunk vc) {
+                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts) {
     (void)radii;
     const GeomLayout L = geom_layout(d);
     if (num_pairs <= 0 || d.num_gaussians == 0)   // nothing to sort: every half-tile render list is empty
-        // (the whole array, whatever the chunk: no pairs in the call means no chunk sorts anything)
         return launch_clear(geom + L.half_count, align_up((size_t)d.num_views * (size_t)num_tiles(d) * 8, 16), s);
     // no-sync forward: the merge scratch is always part of the layout (the longest list is unknown)
     const BinLayout B = bin_layout(d, num_pairs, device_counts ? kSortLdsMax + 1 : max_tile_pairs);
@@ -698,25 +566,23 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     ho.half_list = (uint32_t *)(bin + B.half_list); ho.half_count = (uint32_t *)(geom + L.half_count);
     ho.header = (uint32_t *)(geom + L.header);
     ho.capacity = (uint32_t)(num_pairs < 0xFFFFFFFFll ? num_pairs : 0xFFFFFFFFll);
-    // long-tile lists: the two halves of this chunk's part of the scatter cursor array (free once k_scatter is done;
-    // a list holds at most the chunk's tiles), counters in the header (cleared per forward)
-    {
-        ho.long_list = (uint32_t *)(geom + L.tile_cursor) + (size_t)vc.view0 * T;
-        ho.long_cap = (uint32_t)vc.num_views * (uint32_t)T;
-        ho.long_count[0] = ho.header + kHdrLongTiles + 2 * vc.index; ho.long_count[1] = ho.long_count[0] + 1;
-    }
+    // long-tile lists: the two ends of the scatter cursor array (free once k_scatter is done; a list holds at most
+    // the call's tiles), counters in the header (cleared per forward)
+    ho.long_list = (uint32_t *)(geom + L.tile_cursor);
+    ho.long_cap = (uint32_t)d.num_views * (uint32_t)T;
+    ho.long_count[0] = ho.header + kHdrLongTiles; ho.long_count[1] = ho.long_count[0] + 1;
     {
         const bool lds = T <= 8192;
         // Items per thread: the launch should be ONE round of resident workgroups (8 per CU, fewer when
         // the per-tile counters of a large image take the LDS) — with a fixed 2048 Gaussians per block the
         // 16-view headline needed 9.2 blocks per CU and ran a second, 15 %-full round (phase trace).
         const int64_t resident = (int64_t)device_cus() * (lds ? std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / ((int64_t)T * 8 + 64))) : 8);
-        const int64_t work = (int64_t)vc.num_views * d.num_gaussians;
+        const int64_t work = (int64_t)d.num_views * d.num_gaussians;
         const int64_t rounds = (work + resident * kScatThreads * kScatItems - 1) / (resident * kScatThreads * kScatItems);
         int items = (int)((work + resident * kScatThreads * rounds - 1) / (resident * kScatThreads * rounds));
         items = std::max(1, std::min(kScatItems, items));
         const uint32_t chunks = (uint32_t)((d.num_gaussians + kScatThreads * items - 1) / (kScatThreads * items));
-        dim3 grid(chunks * (uint32_t)vc.num_views);
+        dim3 grid(chunks * (uint32_t)d.num_views);
         unsigned long long *strace = nullptr;
 #ifdef LSR_ENABLE_TRACE
         const char *strace_path = getenv("LSR_TRACE_SCATTER");
@@ -727,12 +593,12 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
 #endif
         prof_begin(kStScatter, s);
         const uint32_t capacity = (uint32_t)(num_pairs < 0xFFFFFFFFll ? num_pairs : 0xFFFFFFFFll);
-#define LSR_SCAT2(LDSR, CHK, NRW, SHM)                                                                         \
-    hipLaunchKernelGGL((k_scatter<LDSR, CHK, NRW>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T, vc.view0, \
+#define LSR_SCAT2(LDSR, NRW, SHM)                                                                         \
+    hipLaunchKernelGGL((k_scatter<LDSR, NRW>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T, \
                        (const char *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, strace)
-#define LSR_SCAT(LDSR, CHK, SHM) do { if (narrow_bins(d)) LSR_SCAT2(LDSR, CHK, true, SHM); else LSR_SCAT2(LDSR, CHK, false, SHM); } while (0)
-        if (lds) LSR_SCAT(true, false, (size_t)T * 8);
-        else LSR_SCAT(false, false, 0);
+#define LSR_SCAT(LDSR, SHM) do { if (narrow_bins(d)) LSR_SCAT2(LDSR, true, SHM); else LSR_SCAT2(LDSR, false, SHM); } while (0)
+        if (lds) LSR_SCAT(true, (size_t)T * 8);
+        else LSR_SCAT(false, 0);
 #undef LSR_SCAT
 #undef LSR_SCAT2
         prof_end(kStScatter, s);
@@ -749,7 +615,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         if (e != hipSuccess) return e;
     }
     {
-        dim3 grid((uint32_t)T * (uint32_t)vc.num_views);
+        dim3 grid((uint32_t)T * (uint32_t)d.num_views);
         unsigned long long *trace = nullptr;
 #ifdef LSR_ENABLE_TRACE
         const char *trace_path = getenv("LSR_TRACE_SORT");
@@ -758,40 +624,42 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
             (void)hipMemsetAsync(trace, 0, (size_t)grid.x * 64, s);
         }
 #endif
-        // Tiers: (1) one workgroup per tile with the variant that fits the expected longest list (at most 4096 keys:
-        // four workgroups per CU); longer lists are appended to one of two lists by that launch and sorted by
-        // persistent launches of (2) the 8192-key variant (two workgroups per CU), (3) the 16 384-key variant (one) and
-        // (4) the global merge path.  The later tiers are launched when the host knows they are needed (synchronous
-        // forward) or cannot know (no-sync forward: a few hundred workgroups each that find an empty list).
+        // Tiers: (1) one workgroup per tile, the variant whose capacity (8 keys per thread) covers the longest list the
+        // host knows of — 128 / 256 / 384 / 512 threads for up to 1024 / 2048 / 3072 / 4096 keys; longer lists are
+        // appended to one of two lists by that launch and sorted by persistent launches of (2) the 8192-key variant (two
+        // workgroups per CU), (3) the 16 384-key variant (one) and (4) the global merge path.  The later tiers are
+        // launched when the host knows they are needed (synchronous forward) or cannot know (no-sync forward: a few
+        // hundred workgroups each that find an empty list; its first tier is always the 4096-key variant, whatever the
+        // caller's hint says, so that only lists beyond 4096 keys take the later tiers).
         prof_begin(kStSort, s);
-#define LSR_SORT(CAPV, GRID, PERS, ARG)                                                          \
-    do {                                                                                         \
-        if ((size_t)CAPV * 8 + 16384 > 65536)                                                    \
-            (void)hipFuncSetAttribute((const void *)k_sort_tiles<CAPV, PERS>,                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize,                \
-                                      CAPV * 8 + (CAPV < 2048 ? CAPV : 2048) * 4);               \
-        hipLaunchKernelGGL((k_sort_tiles<CAPV, PERS>), GRID, dim3(kSortThreads),                 \
-                           (size_t)CAPV * 8 + (size_t)(CAPV < 2048 ? CAPV : 2048) * 4, s,        \
-                           T, ARG, ts, (const uint64_t *)keys, plist, ho, trace);                \
-    } while (0)
-        if (max_tile_pairs <= 1024) LSR_SORT(1024, grid, false, vc.view0);
-        else if (max_tile_pairs <= 2048) LSR_SORT(2048, grid, false, vc.view0);
-        else LSR_SORT(kSortTier1, grid, false, vc.view0);
+        const uint32_t *order = env_int("LSR_SORT_LPT", 1) ? (const uint32_t *)(geom + L.tile_order) : nullptr;
+        const int legacy = env_int("LSR_SORT_VARIANT", 0);    // 1: round 3's choice (512 threads whatever the list length)
+        const int32_t longest = device_counts ? std::max<int32_t>(max_tile_pairs, 4096) : max_tile_pairs;
+        int32_t tier1;     // capacity of the first tier
+        if (legacy == 1) {
+            if (longest <= 1024) { tier1 = 1024; sort_launch<1024, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
+            else if (longest <= 2048) { tier1 = 2048; sort_launch<2048, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
+            else { tier1 = 4096; sort_launch<4096, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
+        } else {
+            if (longest <= 1024) { tier1 = 1024; sort_launch<1024, 128, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
+            else if (longest <= 2048) { tier1 = 2048; sort_launch<2048, 256, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
+            else if (longest <= 3072) { tier1 = 3072; sort_launch<3072, 384, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
+            else { tier1 = 4096; sort_launch<4096, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         const uint32_t cus = (uint32_t)device_cus();
         const dim3 pgrid(cus);
-        if (device_counts || max_tile_pairs > kSortTier1) {   // class 0: two 72 KB workgroups per CU
-            LSR_SORT(kSortTier2, dim3(2 * cus), true, 0);
+        if (device_counts || max_tile_pairs > tier1) {   // class 0: two 72 KB workgroups per CU
+            sort_launch<kSortTier2, 512, true>(dim3(2 * cus), s, 0, nullptr, ts, keys, plist, ho, trace);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }
         if (device_counts || max_tile_pairs > kSortTier2) {   // class 1 up to the LDS capacity
-            LSR_SORT(kSortLdsMax, pgrid, true, 1);
+            sort_launch<kSortLdsMax, 512, true>(pgrid, s, 1, nullptr, ts, keys, plist, ho, trace);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }
-#undef LSR_SORT
         if (device_counts || max_tile_pairs > kSortLdsMax) {
             hipLaunchKernelGGL(k_sort_tiles_global, pgrid, dim3(kSortThreads), 0, s, ts, keys, (uint64_t *)(bin + B.tmp), plist, ho);
             e = hipGetLastError();

@@ -134,6 +134,7 @@ inline int grad_rec_floats(const lsr_dims &d) { return rec_floats(d); }
 // sums go through 64-bit FIXED-POINT integer atomics (order independent => bitwise reproducible
 // gradients) in a second record array behind the float records, converted back by one extra kernel.
 bool deterministic_backward();
+bool projection_contraction();                      // lsr_set_projection_contraction (api.hip): fused multiply-adds in k_preprocess
 constexpr double kFixedPointScale = 1073741824.0;   // 2^30: 9.3e-10 resolution, +-8.6e9 range per record slot
 inline GradLayout grad_layout(const lsr_dims &d) {
     GradLayout L;
@@ -168,21 +169,9 @@ int device_cus();                                   // multiProcessorCount of th
 inline int wave_slots(int cus) { return cus * 4 * 4; }   // (at 4 resident compositing waves per SIMD)
 // Environment knobs are development aids; each is read ONCE per process (never on the launch path).
 int env_int(const char *name, int fallback);        // api.hip: latched on first use
-// header words of the geometry workspace (kHdrQueueFwd + c: work-queue head of view chunk c, c < kMaxViewChunks)
+// header words of the geometry workspace (kHdrQueueFwd: work-queue head of the forward compositing kernel)
 enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrNumItems = 3, kHdrOverflow = 4, kHdrPreDone = 5, kHdrQueueFwd = 8,
-       kHdrLongTiles = 16 /* + 2 c, + 2 c + 1: tiles of view chunk c beyond the first sort tier / beyond the LDS sort */ };
-
-// ---- view chunks (pipelined forward) ----
-// A forward call over V views runs its binning + compositing as K chunks of V / K consecutive views: chunk
-// c + 1's scatter and per-tile sort (short, memory / latency bound, on the library's side stream) run beside
-// chunk c's compositing kernel (VALU bound, persistent waves that leave half of every CU's wave slots free) and
-// fill its load-imbalance tail.  K is a pure function of the dims (and of LSR_PIPE_CHUNKS, read once), because
-// k_tile_scan (work items ordered per chunk), the forward and the backward must agree on it.
-constexpr int kMaxViewChunks = 8;
-int view_chunks(const lsr_dims &d);                 // api.hip
-struct ViewChunk { int view0, num_views, index; };
-inline ViewChunk view_chunk(const lsr_dims &d, int K, int c) { const int n = d.num_views / K; return ViewChunk{c * n, n, c}; }
-inline ViewChunk all_views(const lsr_dims &d) { return ViewChunk{0, d.num_views, 0}; }
+       kHdrLongTiles = 16 /* + 0, + 1: number of tiles beyond the first sort tier / beyond the second */ };
 
 // ---- optional per-stage hipEvent timing (api.hip); no-ops unless lsr_profile_enable(1) ----
 enum Stage { kStPreprocess = 0, kStTileScan, kStScatter, kStSort, kStRenderFwd, kStRenderBwd, kStPreprocessBwd, kStShFwd, kStShBwd, kStAdapterFwd, kStAdapterBwd, kStLatentFwd, kStLatentBwd, kNumStages };
@@ -195,13 +184,24 @@ void note_hip_error(int hip_error);   // what lsr_last_hip_error() returns for t
 hipError_t launch_clear(void *ptr, size_t bytes, hipStream_t s);
 
 // ---- stage launchers (defined one per .hip file) ----
-// host_mirror (optional, device pointer to two mapped host words): the LAST workgroup of k_preprocess to
-// finish sums the tile counts and writes (pair count, longest list) there, so the synchronous forward can
-// hand them to the host while k_tile_scan is still running.
-hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, uint32_t *host_mirror,
+// The tile scan (tile offsets, header, compositing work items, the host's two numbers: lsr_tile_scan.h) runs in the
+// LAST workgroup of k_preprocess whenever the V*T counts fit its LDS staging array (fold_tile_scan: up to kFoldTiles);
+// larger calls launch k_tile_scan behind it.
+//   host_words: device pointer to three mapped host words (pair count, longest list, sequence number) or nullptr;
+//   capacity  : pairs the binning workspace can hold (UINT32_MAX = exact sizing after the host read-back).
+constexpr int kPreThreadsScan = 256, kFoldTiles = 4096;   // workgroup of k_preprocess; most (view, tile) counts its last workgroup scans
+struct FoldedScan {
+    int enabled;
+    uint32_t *host_words; uint32_t host_seq;
+    uint32_t capacity;
+    uint32_t *tile_start, *tile_order;     // filled in by launch_preprocess
+};
+inline bool fold_tile_scan(const lsr_dims &d) {
+    return d.num_gaussians > 0 && (int64_t)d.num_views * num_tiles(d) <= kFoldTiles && env_int("LSR_FOLD_SCAN", 1) != 0;
+}
+hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, const FoldedScan &fs,
                              hipStream_t s);
-// pair_capacity: pairs the binning workspace can hold (UINT32_MAX = exact sizing after a host read-back)
-hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_mirror, uint32_t pair_capacity, hipStream_t s);
+hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_words, uint32_t host_seq, uint32_t pair_capacity, hipStream_t s);
 hipError_t launch_pack_view(const float *viewmatrix, const float *projmatrix, const float *campos, const float *bg,
                             float tanfovx, float tanfovy, const float *tanfovx_dev, const float *tanfovy_dev, float *out,
                             hipStream_t s);
@@ -240,12 +240,11 @@ hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const cha
                               const lsr_in_grads &gin, hipStream_t s);
 // device_counts: the pair count / longest list are NOT known on the host (no-sync forward):
 // `num_pairs` is then the workspace capacity and `max_tile_pairs` only a hint for the sort variant
-// (binning and forward compositing take the view chunk they work on)
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
-                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts, ViewChunk vc);
+                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts);
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                  const char *bin, int64_t num_pairs, char *img, const lsr_outputs &out,
-                                 hipStream_t s, ViewChunk vc);
+                                 hipStream_t s);
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                   const char *bin, int64_t num_pairs, const char *img,
                                   const lsr_outputs &fwd, const lsr_out_grads &gout, char *grad,

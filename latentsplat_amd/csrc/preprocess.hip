@@ -7,6 +7,7 @@
 // tile lists, so every float operation must be the single IEEE operation written here (the CPU
 // oracle performs the identical sequence).  Spec: SURVEY.md Appendix A.1-A.3.
 #include "lsr_blend.h"
+#include "lsr_tile_scan.h"
 
 namespace lsr {
 
@@ -14,13 +15,32 @@ __device__ __forceinline__ float fmin_sel(float a, float b) { return a < b ? a :
 __device__ __forceinline__ float fmax_sel(float a, float b) { return a > b ? a : b; }
 __device__ __forceinline__ int imin_sel(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax_sel(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ float ndc2pix(float v, int S) {
-    return (float)(((v + 1.0) * S - 1.0) * 0.5);
+// ---- arithmetic convention of the projection (lsr_set_projection_contraction) ----
+// FMA = false: the published source with every float operation a separate IEEE operation (this file is compiled with
+// -ffp-contract=off) — the convention of the oracle and of the bit-exact index tests.
+// FMA = true : the same source as a compiler with contraction ON builds it (nvcc's default -fmad=true): a product
+// that feeds a sum is fused into it.  The rule applied is LLVM's default combine on the published expression trees
+// (glm's mat3 products of computeCov2D INCLUDING their terms with a literal zero factor, which decide which product
+// of a sum stays rounded):  x*y + z -> fma(x, y, z);  z + x*y -> fma(x, y, z);  x*y - z -> fma(x, y, -z);  sums
+// associate left to right, so  p1 + p2 + p3 -> fma(a3, b3, fma(a1, b1, a2*b2)).
+// What nvcc / ptxas really emit for the fork cannot be known here; the switch exists to measure how much of the
+// "bit-exact" index contract depends on the answer, and to flip the default in one commit once fork vectors say so.
+template <bool FMA> __device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+    return FMA ? __builtin_fmaf(a2, b2, __builtin_fmaf(a0, b0, a1 * b1)) : a0 * b0 + a1 * b1 + a2 * b2;
+}
+// glm's  w0*j0 + w1*0 + w2*j2  (a column of J with one zero): contracted, the zero term swallows the fusion of the
+// first product (fma(w0, j0, w1*0) = round(w0*j0)) and the LAST product is the fused one
+template <bool FMA> __device__ __forceinline__ float dot2z(float j0, float w0, float j2, float w2) {
+    return FMA ? __builtin_fmaf(w2, j2, w0 * j0) : j0 * w0 + j2 * w2;
+}
+template <bool FMA> __device__ __forceinline__ float ndc2pix(float v, int S) {
+    return FMA ? (float)(__builtin_fma(v + 1.0, (double)S, -1.0) * 0.5) : (float)(((v + 1.0) * S - 1.0) * 0.5);
 }
 
 typedef const float __attribute__((address_space(4))) *kfloat_ptr;   // constant address space: uniform loads become s_load
 
 constexpr int kPreThreads = 256;
+static_assert(kPreThreads == kPreThreadsScan, "the folded tile scan is sized for this workgroup");
 constexpr int kPreItems = 8;  // (Gaussian, view) items per thread: 2048 per block, one histogram flush each
 
 // VB = views per block.  Views that read the same input slice (a shared scene, or the views of one
@@ -28,10 +48,10 @@ constexpr int kPreItems = 8;  // (Gaussian, view) items per thread: 2048 per blo
 // views, so a shared scene is read V / VB times instead of V times (269 of the kernel's
 // 578 MB were per-view re-reads of the scene from L2/MALL).  Items per thread shrink by the same
 // factor, so the grid keeps its size.
-template <int COLOR_MODE, bool LDS_HIST, int VB>
+template <int COLOR_MODE, bool LDS_HIST, int VB, bool FMA>
 __global__ void __launch_bounds__(kPreThreads)
 k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *__restrict__ binrec, int narrow,
-             int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count, uint32_t *header, uint32_t *host_mirror) {
+             int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count, uint32_t *header, FoldedScan fs) {
     extern __shared__ uint32_t s_hist[];   // [VB][T] pair counts
     // 64-byte records are staged here and stored by the whole block as one contiguous run
     // (lane-contiguous 16-byte stores) instead of 4 strided partial-line stores per thread.
@@ -40,6 +60,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
     // record) are both bank-conflict free.
     constexpr int kRecRow = kPreThreads + 4;
     __shared__ float4 s_rec[kRecRow * 4];
+    static_assert(sizeof(float4) * kRecRow * 4 >= sizeof(uint32_t) * kFoldTiles, "the folded tile scan stages its counts here");
     const bool staged = RF == 16;
     const int v0 = blockIdx.y * VB;
     const int G = d.num_gaussians;
@@ -123,13 +144,13 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
             // ONE visibility predicate instead of nested early exits (each exit level made the compiler
             // re-materialise the zeroed outputs): culled lanes run the arithmetic on whatever they hold
             // (IEEE special values are harmless here) and are masked where results leave the thread.
-            const float t0 = vm[0] * p0 + vm[4] * p1 + vm[8] * p2 + vm[12];
-            const float t1 = vm[1] * p0 + vm[5] * p1 + vm[9] * p2 + vm[13];
-            const float t2 = vm[2] * p0 + vm[6] * p1 + vm[10] * p2 + vm[14];
+            const float t0 = dot3<FMA>(vm[0], p0, vm[4], p1, vm[8], p2) + vm[12];
+            const float t1 = dot3<FMA>(vm[1], p0, vm[5], p1, vm[9], p2) + vm[13];
+            const float t2 = dot3<FMA>(vm[2], p0, vm[6], p1, vm[10], p2) + vm[14];
             bool ok = in_range && !(t2 <= LSR_NEAR_CULL);
-            const float h0 = pm[0] * p0 + pm[4] * p1 + pm[8] * p2 + pm[12];
-            const float h1 = pm[1] * p0 + pm[5] * p1 + pm[9] * p2 + pm[13];
-            const float h3 = pm[3] * p0 + pm[7] * p1 + pm[11] * p2 + pm[15];
+            const float h0 = dot3<FMA>(pm[0], p0, pm[4], p1, pm[8], p2) + pm[12];
+            const float h1 = dot3<FMA>(pm[1], p0, pm[5], p1, pm[9], p2) + pm[13];
+            const float h3 = dot3<FMA>(pm[3], p0, pm[7], p1, pm[11], p2) + pm[15];
             const float p_w = 1.0f / (h3 + 0.0000001f);
             const float ndc_x = h0 * p_w, ndc_y = h1 * p_w;
 
@@ -139,32 +160,32 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
             const float tz = t2;
             const float j00 = focal_x / tz, j02 = -(focal_x * tx) / (tz * tz);
             const float j11 = focal_y / tz, j12 = -(focal_y * ty) / (tz * tz);
-            const float m00 = j00 * vm[0] + j02 * vm[2];
-            const float m01 = j00 * vm[4] + j02 * vm[6];
-            const float m02 = j00 * vm[8] + j02 * vm[10];
-            const float m10 = j11 * vm[1] + j12 * vm[2];
-            const float m11 = j11 * vm[5] + j12 * vm[6];
-            const float m12 = j11 * vm[9] + j12 * vm[10];
+            const float m00 = dot2z<FMA>(j00, vm[0], j02, vm[2]);
+            const float m01 = dot2z<FMA>(j00, vm[4], j02, vm[6]);
+            const float m02 = dot2z<FMA>(j00, vm[8], j02, vm[10]);
+            const float m10 = dot2z<FMA>(j11, vm[1], j12, vm[2]);
+            const float m11 = dot2z<FMA>(j11, vm[5], j12, vm[6]);
+            const float m12 = dot2z<FMA>(j11, vm[9], j12, vm[10]);
             const float s0 = r0 * scale2, s1 = r1 * scale2, s2 = r2 * scale2;
             const float s3 = r3 * scale2, s4 = r4 * scale2, s5 = r5 * scale2;
-            const float v00 = s0 * m00 + s1 * m01 + s2 * m02;
-            const float v01 = s1 * m00 + s3 * m01 + s4 * m02;
-            const float v02 = s2 * m00 + s4 * m01 + s5 * m02;
-            const float v10 = s0 * m10 + s1 * m11 + s2 * m12;
-            const float v11 = s1 * m10 + s3 * m11 + s4 * m12;
-            const float v12 = s2 * m10 + s4 * m11 + s5 * m12;
-            const float ca = (m00 * v00 + m01 * v01 + m02 * v02) + LSR_LOWPASS;
-            const float cb = m00 * v10 + m01 * v11 + m02 * v12;
-            const float cc = (m10 * v10 + m11 * v11 + m12 * v12) + LSR_LOWPASS;
-            const float det = ca * cc - cb * cb;
+            const float v00 = dot3<FMA>(s0, m00, s1, m01, s2, m02);
+            const float v01 = dot3<FMA>(s1, m00, s3, m01, s4, m02);
+            const float v02 = dot3<FMA>(s2, m00, s4, m01, s5, m02);
+            const float v10 = dot3<FMA>(s0, m10, s1, m11, s2, m12);
+            const float v11 = dot3<FMA>(s1, m10, s3, m11, s4, m12);
+            const float v12 = dot3<FMA>(s2, m10, s4, m11, s5, m12);
+            const float ca = dot3<FMA>(m00, v00, m01, v01, m02, v02) + LSR_LOWPASS;
+            const float cb = dot3<FMA>(m00, v10, m01, v11, m02, v12);
+            const float cc = dot3<FMA>(m10, v10, m11, v11, m12, v12) + LSR_LOWPASS;
+            const float det = FMA ? __builtin_fmaf(ca, cc, -(cb * cb)) : ca * cc - cb * cb;
             ok = ok && !(det == 0.0f);
             const float det_inv = 1.0f / det;
             const float conic_a = cc * det_inv, conic_b = -cb * det_inv, conic_c = ca * det_inv;
             const float mid = 0.5f * (ca + cc);
-            const float disc = sqrtf(fmax_sel(0.1f, mid * mid - det));
+            const float disc = sqrtf(fmax_sel(0.1f, FMA ? __builtin_fmaf(mid, mid, -det) : mid * mid - det));
             const float lambda1 = mid + disc, lambda2 = mid - disc;
             const float my_radius = ceilf(3.0f * sqrtf(fmax_sel(lambda1, lambda2)));
-            const float px = ndc2pix(ndc_x, d.width), py = ndc2pix(ndc_y, d.height);
+            const float px = ndc2pix<FMA>(ndc_x, d.width), py = ndc2pix<FMA>(ndc_y, d.height);
             const int rminx = imin_sel(gx, imax_sel(0, (int)((px - my_radius) / LSR_TILE)));
             const int rminy = imin_sel(gy, imax_sel(0, (int)((py - my_radius) / LSR_TILE)));
             // ((p + r) + 16) - 1, in THIS order: the published expression `p.x + max_radius + BLOCK_X - 1` is evaluated left
@@ -234,16 +255,17 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
             if (c && v < d.num_views) atomicAdd(&tile_count[(size_t)v * T + (t % T)], c);
         }
     }
-    // ---- totals for the host (synchronous forward only): the last workgroup to arrive adds up the tile
-    // counts.  The counts are only ever touched by agent-scope atomics, which are performed past the (mutually
-    // incoherent) per-XCD L2s: a block waits until its own count updates have been acknowledged (vmcnt) and
-    // only then arrives at the counter, and the last block reads the counts with agent-scope atomic loads.
-    // No release fence: that would write back every record line the block has just left dirty in L2
-    // (measured: the forward went from 0.56 to 0.83 ms per step).  k_tile_scan computes the same two
-    // numbers again for the device side. ----
-    if (host_mirror) {
-        __shared__ uint32_t s_last, s_max[kPreThreads / LSR_WAVE];
-        __shared__ uint64_t s_sum[kPreThreads / LSR_WAVE];
+    // ---- the tile scan, folded in (round 4; it used to be a kernel of its own between this one and k_scatter): the LAST
+    // workgroup to arrive scans the tile counts, writes the tile offsets, the header, the compositing work items and
+    // the two numbers the synchronous forward's host is waiting for (lsr_tile_scan.h).
+    // The counts are only ever touched by agent-scope atomics, which are performed past the (mutually incoherent)
+    // per-XCD L2s: a block waits until its own count updates have been acknowledged (vmcnt) and only then arrives at the
+    // counter, and the last block reads the counts with agent-scope atomic loads.  No release fence: that would write
+    // back every record line the block has just left dirty in L2 (measured in round 2: the forward went from 0.56 to
+    // 0.83 ms per step). ----
+    if (fs.enabled) {
+        __shared__ uint32_t s_last;
+        __shared__ TileScanShared<kPreThreads> s_scan;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -252,34 +274,15 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
         }
         __syncthreads();
         if (s_last) {
+            // the counts go through LDS (the record staging array is free by now): sixteen of them per thread in
+            // registers cost the whole kernel a wave per SIMD (85 instead of 77 VGPRs)
+            uint32_t *s_counts = (uint32_t *)s_rec;
             const int N = d.num_views * T;
-            uint64_t sum = 0;          // (64-bit: the total may exceed the 32-bit offsets; reported saturated)
-            uint32_t mx = 0;
-            for (int t0 = threadIdx.x; t0 < N; t0 += 8 * kPreThreads) {   // eight loads in flight per thread
-                uint32_t c[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    c[j] = __hip_atomic_load(&tile_count[min(t0 + j * kPreThreads, N - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t cj = t0 + j * kPreThreads < N ? c[j] : 0u;
-                    sum += cj; mx = max(mx, cj);
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                sum += __shfl_xor(sum, off);
-                mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
-            }
-            if ((threadIdx.x & (LSR_WAVE - 1)) == 0) { s_sum[threadIdx.x / LSR_WAVE] = sum; s_max[threadIdx.x / LSR_WAVE] = mx; }
+            for (int i = threadIdx.x; i < N; i += kPreThreads)
+                s_counts[i] = __hip_atomic_load(&tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
-            if (threadIdx.x == 0) {
-                uint64_t ts = 0;
-                uint32_t tm = 0;
-#pragma unroll
-                for (int w = 0; w < kPreThreads / LSR_WAVE; ++w) { ts += s_sum[w]; tm = max(tm, s_max[w]); }
-                host_mirror[0] = ts > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ts; host_mirror[1] = tm;
-            }
+            tile_scan_block<kPreThreads, 0, false>(s_counts, fs.tile_start, header, HostMirror{fs.host_words, fs.host_seq},
+                                                   fs.tile_order, N, fs.capacity, s_scan);
         }
     }
 }
@@ -296,7 +299,7 @@ hipError_t launch_clear(void *ptr, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, uint32_t *host_mirror,
+hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, const FoldedScan &fs_in,
                              hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const int T = (int)num_tiles(d);
@@ -320,9 +323,13 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     const int narrow = narrow_bins(d) ? 1 : 0;
     const int RF = L.rec_floats;
     uint32_t *tc = (uint32_t *)(geom + L.tile_count);
+    FoldedScan fs = fs_in;
+    fs.tile_start = (uint32_t *)(geom + L.tile_start); fs.tile_order = (uint32_t *)(geom + L.tile_order);
     const bool lds = (size_t)T * vb <= 4096;
     const size_t shm = lds ? (size_t)T * vb * 4 : 0;
-#define LSR_PRE2(CM, LH, VBV) hipLaunchKernelGGL((k_preprocess<CM, LH, VBV>), grid, dim3(kPreThreads), shm, s, d, in, rec, RF, binrec, narrow, radii, tc, (uint32_t *)(geom + L.header), host_mirror)
+    const bool fma = projection_contraction();
+#define LSR_PRE3(CM, LH, VBV, FM) hipLaunchKernelGGL((k_preprocess<CM, LH, VBV, FM>), grid, dim3(kPreThreads), shm, s, d, in, rec, RF, binrec, narrow, radii, tc, (uint32_t *)(geom + L.header), fs)
+#define LSR_PRE2(CM, LH, VBV) do { if (fma) LSR_PRE3(CM, LH, VBV, true); else LSR_PRE3(CM, LH, VBV, false); } while (0)
 #define LSR_PRE(CM)                                                                              \
     do {                                                                                         \
         if (lds) { if (vb == 4) LSR_PRE2(CM, true, 4); else if (vb == 2) LSR_PRE2(CM, true, 2); else LSR_PRE2(CM, true, 1); } \
@@ -334,6 +341,7 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     else LSR_PRE(LSR_COLOR_NONE);
 #undef LSR_PRE
 #undef LSR_PRE2
+#undef LSR_PRE3
     prof_end(kStPreprocess, s);
     return hipGetLastError();
 }

@@ -48,7 +48,6 @@ struct RenderBwdParams {
     int num_cus;                  // workgroups of 4*WPS waves (one per compute unit)
     const uint32_t *items;        // work items of the forward (view*T + tile | half << 28), costliest first
     const uint32_t *header;       // geometry-workspace header (item count)
-    uint32_t chunks, per_chunk;   // the forward's view chunks: the item list is `chunks` costliest-first lists of `per_chunk` items
     uint32_t *queue;              // work-queue head (zeroed with the gradient workspace)
     const float *views;
     const float4 *geo;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
@@ -180,8 +179,7 @@ k_render_bwd(RenderBwdParams p) {
             if (qi >= num_items) break;
         }
         qi = __builtin_amdgcn_readfirstlane(qi);
-        // the chunk lists interleaved: one costliest-first order over the whole call
-        const uint32_t item = p.items[(qi % p.chunks) * p.per_chunk + qi / p.chunks];
+        const uint32_t item = p.items[qi];
         const uint32_t vt = item & kItemTileMask, half = item >> kItemHalfShift;
         const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
         const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)half;
@@ -463,8 +461,6 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     p.num_cus = device_cus();
     p.items = (const uint32_t *)(geom + L.tile_order);
     p.header = (const uint32_t *)(geom + L.header);
-    p.chunks = (uint32_t)view_chunks(d);
-    p.per_chunk = 2u * (uint32_t)p.T * (uint32_t)d.num_views / p.chunks;
     p.views = in.views;
     p.geo = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
     p.tile_start = (const uint32_t *)(geom + L.tile_start);

@@ -73,7 +73,7 @@ struct RenderFwdParams {
     int num_cus;                  // compute units
     int waves_per_cu;             // resident compositing waves per CU the launch provides
     const uint32_t *items;        // work items, costliest first
-    uint32_t num_items;           // items of this launch (2 per tile of the launch's view chunk)
+    uint32_t num_items;           // items of this launch (2 per (view, tile))
     uint32_t *queue;              // work-queue head (zeroed per forward)
     unsigned long long *trace;    // debug builds (LSR_ENABLE_TRACE): per item {start clk, end clk, hw id, iterations << 32 | entries}
     const float *views;
@@ -352,7 +352,7 @@ k_render_fwd(RenderFwdParams p) {
 
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                  const char *bin, int64_t num_pairs, char *img, const lsr_outputs &out,
-                                 hipStream_t s, ViewChunk vc) {
+                                 hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const ImgLayout I = img_layout(d);
     const BinLayout B = bin_layout(d, num_pairs, 0);
@@ -360,10 +360,10 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.H = d.height; p.W = d.width; p.gx = tiles_x(d); p.T = (int)num_tiles(d); p.G = d.num_gaussians;
     p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE;
     p.num_cus = device_cus();
-    // the chunk's own costliest-first item list (k_tile_scan) and queue word
-    p.items = (const uint32_t *)(geom + L.tile_order) + 2 * (size_t)vc.view0 * (size_t)p.T;
-    p.num_items = 2u * (uint32_t)vc.num_views * (uint32_t)p.T;
-    p.queue = (uint32_t *)(geom + L.header) + kHdrQueueFwd + vc.index;
+    // the costliest-first item list (written with the tile offsets) and the queue word
+    p.items = (const uint32_t *)(geom + L.tile_order);
+    p.num_items = 2u * (uint32_t)d.num_views * (uint32_t)p.T;
+    p.queue = (uint32_t *)(geom + L.header) + kHdrQueueFwd;
     p.views = in.views;
     p.rec = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
     p.tile_start = (const uint32_t *)(geom + L.tile_start);
@@ -376,7 +376,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
 
     p.trace = nullptr;
 #ifdef LSR_ENABLE_TRACE
-    const int64_t max_items = 2 * (int64_t)p.T * vc.num_views;
+    const int64_t max_items = 2 * (int64_t)p.T * d.num_views;
     const char *trace_path = getenv("LSR_TRACE");
     if (trace_path) {
         (void)hipMalloc((void **)&p.trace, (size_t)max_items * 32);

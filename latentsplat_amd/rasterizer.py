@@ -231,22 +231,34 @@ class _RasterizeViews(torch.autograd.Function):
                                                   npairs.value, maxtile.value, C.byref(outs), stream),
                            "lsr_forward_nosync")
             else:
-                _lib.check(lib.lsr_forward_prepare(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii),
-                                                   C.byref(npairs), C.byref(maxtile), stream),
-                           "lsr_forward_prepare")
                 try:
+                    # prepare() forks the SH payload pass onto the library's side stream before its own later failure
+                    # points (the wait for the pair count, the unsupported-size return): it sits inside the try as well
+                    _lib.check(lib.lsr_forward_prepare(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii),
+                                                       C.byref(npairs), C.byref(maxtile), stream),
+                               "lsr_forward_prepare")
                     # the largest pair-count dependent allocation (the likeliest out-of-memory site of a forward)
                     binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), npairs.value, maxtile.value), **u8)
                     _lib.check(lib.lsr_forward_render(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img),
                                                       npairs.value, maxtile.value, C.byref(outs), stream),
                                "lsr_forward_render")
                 except BaseException:
-                    # prepare() left the SH payload pass on the library's side stream, still writing `geom`: the
-                    # current stream has to wait for it before the caching allocator may hand these blocks out again
+                    # the SH payload pass may still be writing `geom` on the side stream: the current stream has to
+                    # wait for it before the caching allocator may hand these blocks out again
                     lib.lsr_forward_abandon(stream)
                     raise
             if debug:
                 torch.cuda.synchronize(dev)
+                if pair_capacity <= 0:
+                    # debug mode of the reference API (settings.debug): the synchronous forward sizes its binning
+                    # workspace with the host's pair count; the device flags a list that did not fit (it cannot
+                    # happen unless the two counts disagree) — surface it instead of rendering a tile short
+                    n, mt, ov = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+                    _lib.check(lib.lsr_forward_status(C.byref(d), _ptr(geom), C.byref(n), C.byref(mt), C.byref(ov), stream),
+                               "lsr_forward_status")
+                    if ov.value or n.value != npairs.value:
+                        raise LsrError(f"synchronous forward: device pair count {n.value} / overflow {ov.value} disagrees "
+                                       f"with the host's {npairs.value}")
         plan = _Plan()
         plan.dims, plan.geom, plan.bin, plan.img = d, geom, binws, img
         plan.num_pairs, plan.radii = npairs.value, radii

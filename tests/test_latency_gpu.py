@@ -173,13 +173,14 @@ print("HASH", h.hexdigest())
     assert digests["1"].startswith("HASH ") and digests["1"] == digests["0"], digests
 
 
-def test_view_chunk_pipeline_does_not_change_results(hip_device):
-    """A forward over V views runs its binning + compositing as K chunks of views, the binning of chunk c + 1
-    on the library's side stream beside the compositing of chunk c (lsr_internal.h view chunks).  K only
-    changes WHEN kernels run: images, the per-pixel workspaces the backward reads and the gradients must be
-    bitwise identical for K = 1, 2, 4 (LSR_PIPE_CHUNKS is read once per process, hence subprocesses), in the
-    synchronous and the no-sync forward, under back-to-back calls (forks / joins of successive calls interleave
-    on the side stream) and inside a captured hipGraph."""
+def test_launch_structure_knobs_do_not_change_results(hip_device):
+    """Where the tile scan runs (folded into the last workgroup of k_preprocess or as a kernel of its own:
+    LSR_FOLD_SCAN), how the host waits for the pair count (polling the mapped words or sleeping on the event:
+    LSR_HOST_POLL), where the SH payload pass runs (side stream, behind the preprocess, behind the binning:
+    LSR_SH_PLACEMENT), the order in which the per-tile sort visits the tiles (LSR_SORT_LPT) and its workgroup size
+    (LSR_SORT_VARIANT) only change WHEN and WHERE kernels run: images, the per-pixel workspaces the backward reads and
+    the gradients must be bitwise identical (knobs are read once per process, hence subprocesses), in the synchronous
+    and the no-sync forward, under back-to-back calls and inside a captured hipGraph."""
     import os
     import subprocess
     import sys
@@ -221,19 +222,25 @@ with torch.no_grad():
 print("HASH", h.hexdigest())
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = {}
-    for chunks in ("1", "2", "4"):
-        env = dict(os.environ, LSR_PIPE_CHUNKS=chunks)
+    variants = {"default": {}, "scan_kernel": dict(LSR_FOLD_SCAN="0"), "event_wait": dict(LSR_HOST_POLL="0"),
+                "scan_kernel_event_wait": dict(LSR_FOLD_SCAN="0", LSR_HOST_POLL="0"),
+                "sh_after_preprocess": dict(LSR_SH_PLACEMENT="1"), "sh_after_binning": dict(LSR_SH_PLACEMENT="2"),
+                "sort_natural_order": dict(LSR_SORT_LPT="0"), "sort_512_threads": dict(LSR_SORT_VARIANT="1")}
+    for name, extra in variants.items():
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        digests[chunks] = r.stdout.strip().splitlines()[-1]
-    assert digests["1"].startswith("HASH ") and digests["1"] == digests["2"] == digests["4"], digests
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        digests[name] = r.stdout.strip().splitlines()[-1]
+    assert digests["default"].startswith("HASH ") and len(set(digests.values())) == 1, digests
 
 
 def test_early_pair_count_equals_the_device_header(hip_device):
-    """The synchronous forward hands the pair count to the host from the LAST workgroup of k_preprocess
-    (while k_tile_scan is still running); the authoritative numbers are the ones k_tile_scan leaves in the
+    """The synchronous forward's host reads the pair count from mapped host words the scanning workgroup (the last
+    one of k_preprocess, or k_tile_scan for calls with more than 4096 (view, tile) counts: the 1040-pixel shape
+    below) writes BEFORE it finishes the offsets; the authoritative numbers are the ones the scan leaves in the
     workspace header.  They must agree on every call — a smaller host count would under-size the binning
-    workspace.  Repeated over shapes that use the LDS-privatised and the global tile histograms."""
+    workspace — and a stale sequence word must never be mistaken for this call's.  Repeated over shapes that use the
+    LDS-privatised and the global tile histograms."""
     import ctypes as C
     from latentsplat_amd import _lib
     lib = _lib.load()
