@@ -1,0 +1,113 @@
+#!/usr/bin/env python
+"""A/B of the library's development knobs in ONE process (lsr_debug_set_knob): per-kernel times (hipEvents inside the
+library) and wall-clock step times of the bench workloads for each knob set, alternating, several rounds.
+
+    python tools/ab_knobs.py [--rounds 2] [--workloads raster16,cfg3,cfg4] '{"LSR_FOLD_SCAN":0}' '{"LSR_SORT_VARIANT":1}' ...
+
+The first (implicit) set is the default configuration {}.  A knob set stays in force until the next one resets it: every
+knob named anywhere on the command line is reset to its default (given as NAME=default in --defaults, else 0) first."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from latentsplat_amd import _lib  # noqa: E402
+from latentsplat_amd.rasterizer import rasterize_views  # noqa: E402
+
+DEFAULTS = {"LSR_FOLD_SCAN": 1, "LSR_HOST_POLL": 1, "LSR_SORT_LPT": 1, "LSR_SORT_VARIANT": 0, "LSR_SH_PLACEMENT": 0,
+            "LSR_FWD8_VARIANT": 0, "LSR_FWD_VARIANT": 0, "LSR_BWD_VARIANT": 0, "LSR_SCATTER_VARIANT": 0, "LSR_SORT_EMIT": 0}
+
+
+def timed(fn, steps, dev):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def kernels(fn, steps, dev):
+    _lib.profile_read(); _lib.profile_enable(True)
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    _lib.profile_enable(False)
+    return {k: round(ms / n, 4) for k, (ms, n) in _lib.profile_read().items() if n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--workloads", default="raster16,cfg3,cfg4")
+    ap.add_argument("sets", nargs="*")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    _lib.load()
+    sets = [{}] + [json.loads(s) for s in args.sets]
+    names = sorted({k for s in sets for k in s})
+    wl = {}
+    want = args.workloads.split(",")
+    if "raster16" in want:
+        inp = bench.build_inputs(300_000, 16, 256, dev, 1234)
+        gf = torch.randn((16, 4, 256, 256), device=dev)
+
+        def r_fwd():
+            with torch.no_grad():
+                rasterize_views(inp["views"], 256, 256, 0, inp["means"], inp["cov"], inp["opac"], features=inp["features"])
+
+        def r_fb():
+            m, c, o, f = (t.detach().requires_grad_(True) for t in (inp["means"], inp["cov"], inp["opac"], inp["features"]))
+            rasterize_views(inp["views"], 256, 256, 0, m, c, o, features=f)[1].backward(gf)
+        wl["raster16"] = (r_fwd, r_fb)
+    for name, scenes in (("cfg3", 1), ("cfg4", 4)):
+        if name not in want:
+            continue
+        from latentsplat_amd import decoder as dec
+        from latentsplat_amd.synthetic import make_scene
+        scs = [make_scene(393_216, image_size=256, views=4, color_sh_degree=4, feature_channels=4, feature_sh_degree=2,
+                          seed=4321 + i).to(dev) for i in range(scenes)]
+        st = lambda n: torch.stack([getattr(sc, n) for sc in scs])
+        leaf = lambda n: st(n).contiguous().requires_grad_(True)
+        gauss = dec.Gaussians(leaf("means"), leaf("covariances"), leaf("opacities"), leaf("color_sh"), leaf("feature_sh"))
+        d = dec.get_decoder(dec.DecoderSplattingCUDACfg(name="splatting_cuda"), [0.0, 0.0, 0.0]).to(dev)
+        a = (gauss, st("extrinsics"), st("intrinsics"), st("near"), st("far"), (256, 256))
+        gc = torch.randn((scenes, 4, 3, 256, 256), device=dev)
+        gl = torch.randn((scenes, 4, 4, 256, 256), device=dev)
+        leaves = (gauss.means, gauss.covariances, gauss.opacities, gauss.color_harmonics, gauss.feature_harmonics)
+
+        def d_fwd(d=d, a=a):
+            with torch.no_grad():
+                d.forward(*a)
+
+        def d_fb(d=d, a=a, gc=gc, gl=gl, leaves=leaves):
+            o = d.forward(*a)
+            torch.autograd.backward([o.color, o.feature_posterior.mean], [gc, gl])
+            for t in leaves:
+                t.grad = None
+        wl[name] = (d_fwd, d_fb)
+    for rnd in range(args.rounds):
+        for s in sets:
+            for n in names:
+                _lib.set_knob(n, DEFAULTS.get(n, 0))
+            for k, v in s.items():
+                _lib.set_knob(k, int(v))
+            for name, (f, fb) in wl.items():
+                res = {"round": rnd, "knobs": s, "workload": name, "fwd_ms": round(timed(f, args.steps, dev), 4),
+                       "fwdbwd_ms": round(timed(fb, args.steps, dev), 4)}
+                res["kernels_fwd"] = kernels(f, 10, dev)
+                res["kernels_fwdbwd"] = kernels(fb, 10, dev)
+                print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
