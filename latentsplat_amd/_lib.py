@@ -190,11 +190,12 @@ def load():
     lib.lsr_profile_stage_name.restype = C.c_char_p
     lib.lsr_profile_stage_name.argtypes = [C.c_int]
     lib.lsr_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(I64)]
-    lib.lsr_debug_set_knob.restype = C.c_int
-    lib.lsr_debug_set_knob.argtypes = [C.c_char_p, C.c_int]
-    lib.lsr_set_projection_contraction.restype = C.c_int
-    lib.lsr_set_projection_contraction.argtypes = [C.c_int]
-    lib.lsr_get_projection_contraction.restype = C.c_int
+    if hasattr(lib, "lsr_debug_set_knob"):    # (absent from a previous round's build selected with LSR_LIB for an A/B)
+        lib.lsr_debug_set_knob.restype = C.c_int
+        lib.lsr_debug_set_knob.argtypes = [C.c_char_p, C.c_int]
+        lib.lsr_set_projection_contraction.restype = C.c_int
+        lib.lsr_set_projection_contraction.argtypes = [C.c_int]
+        lib.lsr_get_projection_contraction.restype = C.c_int
     lib.lsr_adapter_forward.restype = C.c_int
     lib.lsr_adapter_forward.argtypes = [C.POINTER(AdapterDims), C.POINTER(AdapterInputs),
                                         C.POINTER(AdapterOutputs), P]
@@ -211,7 +212,7 @@ def load():
     lib.lsr_ply_pack.argtypes = [I64, I32, C.POINTER(PlyInputs), P, P]
     lib.lsr_ply_write_host.restype = C.c_int
     lib.lsr_ply_write_host.argtypes = [C.c_char_p, P, I64]
-    if lib.lsr_abi_version() != 7:
+    if lib.lsr_abi_version() != 7 and not os.environ.get("LSR_LIB"):
         raise LsrError("liblsr_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -71,6 +71,9 @@ __device__ __forceinline__ void tile_scan_block(const uint32_t *count, uint32_t 
     const int per = (N + THREADS - 1) / THREADS;
     const int lo = tid * per, hi = min(N, lo + per);
     const bool in_regs = REGS > 0 && per <= REGS; // block-uniform
+    // chunks of whole, aligned 16-byte groups (the folded instance: 4096 counts in LDS, 16 per thread): every pass reads
+    // four counts per instruction and the reads of a pass are independent of each other
+    const bool vec4 = !ATOMIC && !in_regs && (per & 3) == 0 && per <= 16 && (N % per) == 0 && ((size_t)count & 15) == 0;
     uint32_t creg[REGS > 0 ? REGS : 1];
     if (in_regs) {
         // unconditional loads, all in flight together, from ONE base address with immediate offsets (sixteen clamped
@@ -90,6 +93,12 @@ __device__ __forceinline__ void tile_scan_block(const uint32_t *count, uint32_t 
 #pragma unroll
         for (int q = 0; q < REGS; ++q) { sum += creg[q]; mx = max(mx, creg[q]); }
         sum64 = sum;                              // at most REGS counts of < 2^28 each per thread
+    } else if (vec4) {
+        for (int i = lo; i < hi; i += 4) {
+            const uint4 c = *(const uint4 *)(count + i);
+            sum += c.x + c.y + c.z + c.w; mx = max(max(mx, c.x), max(max(c.y, c.z), c.w));
+        }
+        sum64 = sum;                              // a chunk of < 2^4 counts of < 2^28 each
     } else {
         for (int i = lo; i < hi; ++i) { const uint32_t c = scan_load<ATOMIC>(&count[i]); sum += c; sum64 += c; mx = max(mx, c); }
     }
@@ -134,6 +143,14 @@ __device__ __forceinline__ void tile_scan_block(const uint32_t *count, uint32_t 
     if (in_regs) {
 #pragma unroll
         for (int q = 0; q < REGS; ++q) { if (lo + q < hi) start[lo + q] = min(run, capacity); run += creg[q]; }
+    } else if (vec4) {
+        for (int i = lo; i < hi; i += 4) {
+            const uint4 c = *(const uint4 *)(count + i);
+            uint4 o;
+            o.x = min(run, capacity); run += c.x; o.y = min(run, capacity); run += c.y;
+            o.z = min(run, capacity); run += c.z; o.w = min(run, capacity); run += c.w;
+            *(uint4 *)(start + i) = o;
+        }
     } else {
         for (int i = lo; i < hi; ++i) { start[i] = min(run, capacity); run += scan_load<ATOMIC>(&count[i]); }
     }
@@ -145,14 +162,21 @@ __device__ __forceinline__ void tile_scan_block(const uint32_t *count, uint32_t 
     // length; the two half-tile items of a tile stay together).  The exact half list lengths only exist after
     // k_sort_tiles; the order is a scheduling hint (longest-processing-time first for the work queues), never a
     // correctness matter. ----
-    const uint64_t scale = (uint64_t)maxc + 1u;
-    auto cls = [&](uint32_t w) -> uint32_t { return THREADS - 1 - (uint32_t)(((uint64_t)w * THREADS) / scale); };
+    // class = THREADS - 1 - floor(w THREADS / (maxc + 1)), in float (a software 64-bit division per count was a third of
+    // this stage; the classes only steer scheduling, and both passes below evaluate the same expression)
+    const float cls_scale = (float)THREADS / ((float)maxc + 1.0f);
+    auto cls = [&](uint32_t w) -> uint32_t { return THREADS - 1 - min((uint32_t)((float)w * cls_scale), (uint32_t)(THREADS - 1)); };
     if (tid == 0) header[kHdrNumItems] = 2u * (uint32_t)N;
     sh.cls[tid] = 0;
     __syncthreads();
     if (in_regs) {
 #pragma unroll
         for (int q = 0; q < REGS; ++q) if (lo + q < hi) atomicAdd(&sh.cls[cls(creg[q])], 2u);
+    } else if (vec4) {
+        for (int i = lo; i < hi; i += 4) {
+            const uint4 c = *(const uint4 *)(count + i);
+            atomicAdd(&sh.cls[cls(c.x)], 2u); atomicAdd(&sh.cls[cls(c.y)], 2u); atomicAdd(&sh.cls[cls(c.z)], 2u); atomicAdd(&sh.cls[cls(c.w)], 2u);
+        }
     } else {
         for (int i = lo; i < hi; ++i) atomicAdd(&sh.cls[cls(scan_load<ATOMIC>(&count[i]))], 2u);
     }
@@ -169,6 +193,16 @@ __device__ __forceinline__ void tile_scan_block(const uint32_t *count, uint32_t 
                 const uint32_t at = atomicAdd(&sh.cls[cls(creg[q])], 2u);
                 *(uint2 *)(order + at) = make_uint2((uint32_t)(lo + q), (uint32_t)(lo + q) | (1u << kItemHalfShift));
             }
+    } else if (vec4) {
+        for (int i = lo; i < hi; i += 4) {
+            const uint4 c = *(const uint4 *)(count + i);
+            const uint32_t cc[4] = {c.x, c.y, c.z, c.w};
+            uint32_t at[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) at[k] = atomicAdd(&sh.cls[cls(cc[k])], 2u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *(uint2 *)(order + at[k]) = make_uint2((uint32_t)(i + k), (uint32_t)(i + k) | (1u << kItemHalfShift));
+        }
     } else {
         for (int i = lo; i < hi; ++i) {
             const uint32_t at = atomicAdd(&sh.cls[cls(scan_load<ATOMIC>(&count[i]))], 2u);

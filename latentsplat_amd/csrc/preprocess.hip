@@ -278,8 +278,15 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
             // registers cost the whole kernel a wave per SIMD (85 instead of 77 VGPRs)
             uint32_t *s_counts = (uint32_t *)s_rec;
             const int N = d.num_views * T;
-            for (int i = threadIdx.x; i < N; i += kPreThreads)
-                s_counts[i] = __hip_atomic_load(&tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i0 = threadIdx.x; i0 < N; i0 += 4 * kPreThreads) {     // four coalesced loads in flight per thread
+                uint32_t c[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    c[k] = __hip_atomic_load(&tile_count[min(i0 + k * kPreThreads, N - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (i0 + k * kPreThreads < N) s_counts[i0 + k * kPreThreads] = c[k];
+            }
             __syncthreads();
             tile_scan_block<kPreThreads, 0, false>(s_counts, fs.tile_start, header, HostMirror{fs.host_words, fs.host_seq},
                                                    fs.tile_order, N, fs.capacity, s_scan);

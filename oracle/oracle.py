@@ -44,6 +44,17 @@ def set_sh_convention(name: str) -> None:
     lib().oracle_set_sh_convention(ctypes.c_int({"3dgs": 0, "reference": 1}[name]))
 
 
+def set_fma_contraction(on: bool) -> None:
+    """Arithmetic convention of the oracle's projection stage: False (default) = every float operation separate (what
+    the bit-exact index tests assume); True = products fused into the sums they feed, the way a compiler with
+    contraction on would build the published source (raster_oracle.c, oracle_set_fma_contraction)."""
+    lib().oracle_set_fma_contraction(ctypes.c_int(1 if on else 0))
+
+
+def get_fma_contraction() -> bool:
+    return bool(lib().oracle_get_fma_contraction())
+
+
 def _p(a: Optional[np.ndarray]):
     if a is None:
         return ctypes.c_void_p(0)

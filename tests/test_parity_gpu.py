@@ -89,6 +89,37 @@ def test_forward_parity(hip_device, name):
     _check_forward(bi, run)
 
 
+@pytest.mark.parametrize("name", ["cfg1_rgb_deg0", "rgb_deg4_feat4_deg2_v3", "ragged_image", "big_splats"])
+def test_forward_parity_contracted_projection(hip_device, name):
+    """The OTHER arithmetic convention of the projection stage: products fused into the sums they feed, as a
+    compiler with contraction on (nvcc's default -fmad=true, which the real fork was built with) may build the published
+    source.  The kernel's switch (lsr_set_projection_contraction) against the oracle's (oracle_set_fma_contraction): radii,
+    rectangles, depth bits, pixel means, conics, tile offsets and sorted lists bit for bit, images at the usual bar —
+    so that the default can be flipped in one commit the day vectors of the real fork say which convention it follows
+    (tools/contraction_census.py counts what flips between the two: profiles/r04_contraction_census.json)."""
+    from latentsplat_amd import _lib
+    from oracle import oracle as orc
+    lib = _lib.load()
+    sc, H, W = _scene(CASES[name])
+    bi = util.boundary_inputs(sc, H, W, bg=(0.2, 0.4, 0.6))
+    try:
+        lib.lsr_set_projection_contraction(1)
+        orc.set_fma_contraction(True)
+        assert lib.lsr_get_projection_contraction() == 1
+        run = util.HipRun(bi, hip_device)
+        _check_forward(bi, run)
+        o_fused = util.oracle_forward(bi, bi["V"] - 1)
+    finally:
+        lib.lsr_set_projection_contraction(0)
+        orc.set_fma_contraction(False)
+    # and the two conventions really are different arithmetic: some depth bits move (1-2 ulp) — except in view 0 of the
+    # synthetic scenes, whose camera looks down the z axis (its products are exact)
+    o_plain = util.oracle_forward(bi, bi["V"] - 1)
+    vis = (o_plain["radii"] > 0) & (o_fused["radii"] > 0)
+    if bi["V"] > 1:
+        assert (o_plain["gdepth"][vis].view(np.uint32) != o_fused["gdepth"][vis].view(np.uint32)).any()
+
+
 def test_pixel_aligned_means_tile_rectangles(hip_device):
     """Gaussians sitting on pixel centres (what the reference's encoder emits: one Gaussian per context-view ray)
     project to x = k + 0.99998-type floats, where the published tile-rectangle expression

@@ -113,8 +113,33 @@ def main():
                "wall_clock_khz": khz, "rocm_smi": box.get("smi")}
         print(json.dumps(res), flush=True)
 
-    for mode in ("fwd_tight", "fwdbwd", "fwd_all_events", "fwd_idle_1ms", "fwd_idle_5ms", "fwd_then_clear", "fwd_tight", "fwdbwd"):
-        run(mode)
+    def cold_start(idle_s, steps=23):
+        """What bench.py's headline region looked like in rounds 1-3: an idle device, then 3 + 20 forward steps (10 ms)."""
+        torch.cuda.synchronize(dev)
+        time.sleep(idle_s)
+        buf.zero_()
+        _lib.profile_read()
+        _lib.profile_enable(True, only=("render_forward",))
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fwd()
+            probe.clock_probe_launch(C.c_void_p(buf.data_ptr()), i, 100, C.c_void_p(side.cuda_stream))
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        _lib.profile_enable(False)
+        prof = _lib.profile_read()
+        b = buf.cpu().numpy().reshape(-1, 2)[:steps]
+        mhz = [round(float(c / w * khz / 1e3), 0) if w > 0 else None for c, w in b]
+        print(json.dumps({"mode": f"cold_start_after_{idle_s}s_idle", "steps": steps, "ms_per_step_wall": round(1e3 * el / steps, 4),
+                          "kernel_ms": {k: round(ms / c, 4) for k, (ms, c) in prof.items() if c}, "sclk_mhz_per_step": mhz}), flush=True)
+
+    if "--cold-only" not in sys.argv:
+        for mode in ("fwd_tight", "fwdbwd", "fwd_all_events", "fwd_idle_1ms", "fwd_idle_5ms", "fwd_then_clear", "fwd_tight", "fwdbwd"):
+            run(mode)
+    for idle in (2.0, 0.5, 2.0):
+        cold_start(idle)
+    run("fwd_tight", 1.0)
+    run("fwdbwd", 1.0)
 
 
 if __name__ == "__main__":

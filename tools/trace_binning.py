@@ -54,7 +54,6 @@ def main():
     from latentsplat_amd.rasterizer import rasterize_views
     V = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     dev = torch.device("cuda", 0)
-    khz = torch.cuda.get_device_properties(0).__dict__.get("wall_clock_rate", None)
     inp = bench.build_inputs(300_000, V, 256, dev, 1234)
     with torch.no_grad():
         for _ in range(3):
