@@ -54,6 +54,7 @@ struct ShParams {
     uint32_t mdiv[2];         // ceil(2^22 / ks): x / ks == (x * mdiv) >> 22 for x < 8192
     uint32_t mdivK, mdivKf;   // same for K (coefficients per colour channel) and Kf
     GroupStrides gs;          // view groups: blockIdx.y = group, every pointer above advances by the group's slices
+    int full_line;            // forward, 64-byte records: re-read the geometry half and store the WHOLE line (LSR_SH_FULL_LINE)
 };
 // the launch's parameters as seen by view group blockIdx.y (uniform: scalar arithmetic)
 __device__ __forceinline__ ShParams group_params(const ShParams &pk) {
@@ -181,6 +182,12 @@ k_sh_fwd(ShParams pk) {
         if (!(active && f.visf > 0.0f)) return;
         const ShDir dir = sh_direction(p, v, f.pos);
         float *R = p.rec + o * (size_t)p.RF + 8;
+        // Whole-line store (LSR_SH_FULL_LINE, 64-byte records): k_preprocess wrote this record's line as a whole; a
+        // 32-byte store into it is a PARTIAL line write, which the memory system turns into a read-modify-write once the
+        // line has left the Infinity Cache (16 views x 393 216 records = 403 MB at configs[4]).  Re-reading the geometry
+        // half and storing all 64 bytes keeps every write a full line.
+        float4 geo0 = make_float4(0, 0, 0, 0), geo1 = geo0;
+        if (p.full_line) { geo0 = *(const float4 *)(R - 8); geo1 = *(const float4 *)(R - 4); }
         float basF[9];
         // features use the reference's axis naming: B^ref(x,y,z) = B(z,x,y) up to degree 2
         if (hasF) sh_basis<2>(degF, dir.dz, dir.dx, dir.dy, basF);
@@ -232,6 +239,7 @@ k_sh_fwd(ShParams pk) {
             for (int c = c_next; c < pad; c += 4)
                 *(float4 *)(R + COFF + c) = make_float4(feat(c), feat(c + 1), feat(c + 2), feat(c + 3));
         }
+        if (p.full_line) { *(float4 *)(R - 8) = geo0; *(float4 *)(R - 4) = geo1; }
     };
 
     if (sh_shared_scene(p)) {
@@ -491,6 +499,8 @@ static ShParams make_params(const lsr_dims &d, const lsr_inputs &in, const GeomL
     p.rec = (float *)const_cast<char *>(geom + L.rec);
     p.clamp = (uint8_t *)const_cast<char *>(geom + L.sh_clamp);
     p.grec = nullptr; p.RF = L.rec_floats; p.g = lsr_in_grads{};
+    // (only when the payload half is written completely: colour + features filling slots 8..15, or features alone)
+    p.full_line = 0;
     p.has[0] = group_enabled(d, 0); p.has[1] = group_enabled(d, 1);
     p.ks[0] = p.has[0] ? d.sh_coeffs * 3 : 0;
     p.ks[1] = p.has[1] ? d.feat_sh_coeffs * d.feat_channels : 0;
@@ -516,8 +526,9 @@ hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom
     if (d.num_gaussians == 0) return hipSuccess;
     if (!group_enabled(d, 0) && !group_enabled(d, 1)) return hipSuccess;
     const GeomLayout L = geom_layout(d);
-    const ShParams p = make_params(d, in, L, geom);
+    ShParams p = make_params(d, in, L, geom);
     const int degc = p.has[0] ? d.sh_degree : -1, coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
+    p.full_line = L.rec_floats == 16 && p.has[1] && (coff == 0 || p.has[0]) && coff + d.feat_channels > 4 && env_int("LSR_SH_FULL_LINE", 0) != 0;
     const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE, num_view_groups(d)), block(kShThreads);
     const size_t shm = ((size_t)p.offF + (size_t)LSR_WAVE * p.ks[1]) * 4;
     prof_begin(kStShFwd, s);

@@ -21,7 +21,7 @@ from latentsplat_amd import _lib  # noqa: E402
 from latentsplat_amd.rasterizer import rasterize_views  # noqa: E402
 
 DEFAULTS = {"LSR_FOLD_SCAN": 1, "LSR_HOST_POLL": 1, "LSR_SORT_LPT": 1, "LSR_SORT_VARIANT": 0, "LSR_SH_PLACEMENT": 0,
-            "LSR_FWD8_VARIANT": 0, "LSR_FWD_VARIANT": 0, "LSR_BWD_VARIANT": 0, "LSR_SCATTER_VARIANT": 0, "LSR_SORT_EMIT": 0}
+            "LSR_FWD8_VARIANT": 0, "LSR_FWD_VARIANT": 0, "LSR_BWD_VARIANT": 0, "LSR_SCATTER_VARIANT": 0, "LSR_SORT_PERSIST": 1, "LSR_SORT_TIER1": 0, "LSR_SH_FULL_LINE": 0}
 
 
 def timed(fn, steps, dev):
