@@ -183,9 +183,11 @@ static int check_dims(const lsr_dims *d) {
 // wait that consumes it are issued under the context's mutex (a wait binds to the record that precedes it):
 // another host thread re-recording the same event can then only make a LATER wait cover more work, never less
 // — the side stream executes in order, so a wait on the latest record covers every earlier one.
-// LSR_SH_PLACEMENT (development knob): 0 = side stream (default), 1 = on the caller's stream right behind k_preprocess,
-// 2 = on the caller's stream behind the binning (in front of the compositing launch).  LSR_SH_SIDE_STREAM=0 is the
-// older spelling of 1.
+// LSR_SH_PLACEMENT (development knob): 0 = side stream, 1 (default since round 4) = on the caller's stream right behind
+// k_preprocess, 2 = on the caller's stream behind the binning (in front of the compositing launch).  Measured on MI355X
+// (tools/ab_knobs.py): beside the binning chain the SH pass and the per-tile sort slow each other down by
+// more than the overlap hides — configs[3] forward 0.325 (side) / 0.313 (1) / 0.321 ms (2), configs[4] 0.926 / 0.912 /
+// 0.921 ms.  LSR_SH_SIDE_STREAM=0 is the older spelling of 1.
 struct SideCtx {
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;            // caller -> side, side -> caller
@@ -194,7 +196,7 @@ struct SideCtx {
 };
 static int sh_placement() {
     if (!env_int("LSR_SH_SIDE_STREAM", 1)) return 1;
-    const int p = env_int("LSR_SH_PLACEMENT", 0);
+    const int p = env_int("LSR_SH_PLACEMENT", 1);
     return p < 0 || p > 2 ? 0 : p;
 }
 static SideCtx *side_ctx() {
@@ -225,8 +227,10 @@ static hipError_t cross_edge(SideCtx *c, hipEvent_t ev, hipStream_t from, hipStr
     return hipStreamWaitEvent(to, ev, 0);
 }
 
+// a separate SH payload pass behind k_preprocess (not when the fused projection + SH kernel handles the call)
 static bool has_sh_payload(const lsr_dims &d) {
-    return d.num_gaussians > 0 && (d.color_mode == LSR_COLOR_SH || (d.feat_channels > 0 && d.feat_mode == LSR_FEAT_SH));
+    return d.num_gaussians > 0 && (d.color_mode == LSR_COLOR_SH || (d.feat_channels > 0 && d.feat_mode == LSR_FEAT_SH)) &&
+           !fused_preprocess_sh(d);
 }
 // SH forward of all view groups: on the side stream (forked from what is queued on `s` so far; the caller
 // joins with sh_forward_join before the compositing launch), or in line on `s`.
@@ -469,7 +473,8 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
     FoldedScan fs{};
     fs.enabled = fold ? 1 : 0;
     fs.host_words = mapped ? h_hdr_dev : nullptr; fs.host_seq = h_seq; fs.capacity = 0xFFFFFFFFu;
-    LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, fs, s));
+    if (fused_preprocess_sh(*d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(*d, *in, geom, radii, fs, s));
+    else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, fs, s));
     if (fold && mapped) LSR_HIP(hipEventRecord(h_event, s));
     rc = sh_forward_fork(*d, *in, geom, s);   // view-dependent payload: beside the host round trip and the binning
     if (rc) return rc;
@@ -537,7 +542,8 @@ int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     FoldedScan fs{};
     fs.enabled = fold ? 1 : 0;
     fs.capacity = (uint32_t)pair_capacity;
-    LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, fs, s));
+    if (fused_preprocess_sh(*d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(*d, *in, geom, out->radii, fs, s));
+    else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, fs, s));
     rc = sh_forward_fork(*d, *in, geom, s);
     if (rc) return rc;
     if (!fold) LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, 0u, (uint32_t)pair_capacity, s));

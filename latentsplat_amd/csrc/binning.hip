@@ -489,249 +489,6 @@ k_sort_tiles(int cls, const uint32_t *__restrict__ order, const uint32_t *__rest
     }
 }
 
-// ---- first tier, round 4: PERSISTENT workgroups with the next list's keys in flight, half lists placed from counts
-// taken while the sorted words are written ----
-// The phase trace of the one-workgroup-per-tile launch (tools/trace_binning.py, bench scene: 10.9 us per tile) shows
-// 3.0 us of every tile spent waiting for its keys, 2.3 us ranking, 3.1 us writing point_list and the half lists.
-// Here a workgroup walks the costliest-first tile list with a stride of the grid and
-//   * requests the NEXT tile's keys as soon as the current keys are dead (after the sorted low words are in LDS): the
-//     loads fly while the current tile's lists are written, the registers are the same ones;
-//   * counts, per 64 sorted positions and half, the entries of the half lists WHILE it writes the sorted words (one
-//     LDS atomic per entry and half on 2 x 64 counters), so that the emitter needs no counting pass and no barrier of
-//     its own: every wave scans the 64 counts in registers and places its chunks.
-// Same arithmetic, same total order, same lists as sort_tile / emit_half_lists above (the later tiers still use those).
-template <int CAP, int THREADS, int MINW>   // MINW: waves per SIMD the register allocation must leave room for (6: 80 VGPRs with a few spills, 5: 96)
-__global__ void __launch_bounds__(THREADS, MINW)
-k_sort_tiles_p(const uint32_t *__restrict__ order, uint32_t num_tiles, const uint32_t *__restrict__ tile_start,
-               const uint64_t *__restrict__ keys, uint32_t *__restrict__ point_list, HalfOut ho) {
-    static_assert(CAP % THREADS == 0 && CAP <= 4096, "first tier: whole keys per thread, one emitter pass");
-    extern __shared__ uint64_t s_keys[];                  // [CAP] keys, [NB] u32 counters, [2][64] u32 chunk counts
-    constexpr int NB = CAP < 2048 ? CAP : 2048;
-    constexpr int kWaves = THREADS / LSR_WAVE;
-    constexpr int PERK = CAP / THREADS;
-    constexpr int LOGNB = NB == 2048 ? 11 : 10;
-    constexpr int PER = (NB + THREADS - 1) / THREADS;
-    uint32_t *s_cnt = (uint32_t *)(s_keys + CAP);
-    uint32_t *s_chunk = s_cnt + NB;
-    uint64_t *s_red = s_keys;
-    uint32_t *s_wsum = (uint32_t *)(s_keys + 2 * kWaves);
-    uint32_t *s_flag = s_wsum + kWaves;
-    uint32_t *s_out = (uint32_t *)s_keys;
-    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
-
-    uint32_t it = blockIdx.x;
-    if (it >= num_tiles) return;
-    // (wave-uniform: the tile index comes from the workgroup index and the grid size — kept in scalar registers)
-    auto descriptor = [&](uint32_t i, size_t &vt, uint32_t &start, uint32_t &n) {
-        const uint32_t t = __builtin_amdgcn_readfirstlane(order ? (order[2 * (size_t)i] & kItemTileMask) : i);
-        vt = t;
-        start = __builtin_amdgcn_readfirstlane(tile_start[t]);
-        n = __builtin_amdgcn_readfirstlane(tile_start[t + 1]) - start;
-    };
-    auto sortable = [&](uint32_t start, uint32_t n) { return n >= 2u && n <= (uint32_t)CAP && (uint64_t)start + n <= ho.capacity; };
-    uint64_t kreg[PERK];
-    auto load_keys = [&](uint32_t start, uint32_t n) {
-        const uint64_t *src = keys + start;
-#pragma unroll
-        for (int q = 0; q < PERK; ++q) {
-            const uint32_t i = tid + q * THREADS;
-            const uint64_t k = src[min(i, n - 1)];   // unconditional (clamped): all loads in flight together
-            kreg[q] = i < n ? k : ~0ull;
-        }
-    };
-    size_t vt; uint32_t start, n;
-    descriptor(it, vt, start, n);
-#pragma unroll
-    for (int q = 0; q < PERK; ++q) kreg[q] = ~0ull;
-    if (sortable(start, n)) load_keys(start, n);
-    for (;;) {
-        const uint32_t nit = it + gridDim.x;
-        const bool has_next = nit < num_tiles;
-        size_t nvt = 0; uint32_t nstart = 0, nn = 0;
-        if (has_next) descriptor(nit, nvt, nstart, nn);
-        uint32_t *hcnt = ho.half_count + 2 * vt, *hdst = ho.half_list + 2 * (size_t)start;
-        const bool sorting = sortable(start, n);
-        if (!sorting) {
-            if (n > 0 && (uint64_t)start + n > ho.capacity) {   // a list beyond the workspace: flag, render nothing
-                if (tid < 2) hcnt[tid] = 0;
-                if (tid == 0) ho.header[kHdrOverflow] = 1u;
-            } else if (n > (uint32_t)CAP) {                     // a later tier's list
-                if (tid == 0) {
-                    const int cls = n > (uint32_t)kSortTier2 ? 1 : 0;
-                    const uint32_t i = atomicAdd(ho.long_count[cls], 1u);
-                    ho.long_list[cls ? ho.long_cap - 1u - i : i] = (uint32_t)vt;
-                }
-            } else if (n == 1) {
-                if (tid == 0) {
-                    const uint32_t w = (uint32_t)keys[start], idx = key_index(w);
-                    point_list[start] = idx;
-                    const uint32_t m = code_mask(w & 0xFFu);
-                    for (int h = 0; h < 2; ++h) {
-                        const uint32_t bits = half_bits(m, h);
-                        if (bits) hdst[h] = idx | (bits << kListBitsShift);
-                        hcnt[h] = bits ? 1u : 0u;
-                    }
-                }
-            } else if (tid < 2) {
-                hcnt[tid] = 0;                                  // n == 0
-            }
-        } else {
-            // ---- key range ----
-            uint64_t kmin = ~0ull, kmax = 0ull;
-#pragma unroll
-            for (int q = 0; q < PERK; ++q) {
-                const uint64_t k = kreg[q];
-                kmin = k < kmin ? k : kmin;
-                if (tid + q * THREADS < n) kmax = k > kmax ? k : kmax;
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint64_t a = __shfl_xor(kmin, off), b = __shfl_xor(kmax, off);
-                kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
-            }
-            if (lane == 0) { s_red[2 * wid] = kmin; s_red[2 * wid + 1] = kmax; }
-            for (int b = tid; b < NB; b += THREADS) s_cnt[b] = 0;
-            if (tid < 2 * LSR_WAVE) s_chunk[tid] = 0;
-            if (tid == 0) *s_flag = 0;
-            __syncthreads();
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) {
-                kmin = s_red[2 * w] < kmin ? s_red[2 * w] : kmin;
-                kmax = s_red[2 * w + 1] > kmax ? s_red[2 * w + 1] : kmax;
-            }
-            const uint64_t range = kmax - kmin;
-            const int bits = range ? 64 - __builtin_clzll(range) : 0;
-            const int shift = bits > LOGNB ? bits - LOGNB : 0;
-            // ---- histogram (the returning atomic is the key's arrival rank in its bucket), scan ----
-            uint32_t rnk[PERK];
-#pragma unroll
-            for (int q = 0; q < PERK; ++q)
-                if (tid + q * THREADS < n) rnk[q] = atomicAdd(&s_cnt[(uint32_t)((kreg[q] - kmin) >> shift)], 1u);
-            __syncthreads();
-            uint32_t loc[PER], sum = 0, mx = 0;
-#pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                loc[q] = (NB % THREADS == 0 || tid * PER + q < NB) ? s_cnt[min(tid * PER + q, NB - 1)] : 0u;
-                sum += loc[q]; mx = loc[q] > mx ? loc[q] : mx;
-            }
-            uint32_t incl = sum;
-#pragma unroll
-            for (int off = 1; off < LSR_WAVE; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-            if (lane == LSR_WAVE - 1) s_wsum[wid] = incl;
-            if (mx > kBucketOverflow) *s_flag = 1;
-            __syncthreads();
-            uint32_t run = incl - sum;
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) run += w < wid ? s_wsum[w] : 0u;
-            const bool overflow = *s_flag != 0;
-            if (!overflow) {
-#pragma unroll
-                for (int q = 0; q < PER; ++q) { if (NB % THREADS == 0 || tid * PER + q < NB) s_cnt[tid * PER + q] = run; run += loc[q]; }
-                __syncthreads();   // also: every thread is done with the aliased scratch
-#pragma unroll
-                for (int q = 0; q < PERK; ++q)
-                    if (tid + q * THREADS < n) s_keys[s_cnt[(uint32_t)((kreg[q] - kmin) >> shift)] + rnk[q]] = kreg[q];
-                __syncthreads();
-                uint32_t dst[PERK];
-#pragma unroll
-                for (int q = 0; q < PERK; ++q) {
-                    dst[q] = 0;
-                    if (tid + q * THREADS < n) {
-                        const uint64_t key = kreg[q];
-                        const uint32_t b = (uint32_t)((key - kmin) >> shift);
-                        const uint32_t lo = s_cnt[b], hi = b + 1 < (uint32_t)NB ? s_cnt[b + 1] : n;
-                        uint32_t below = 0;
-                        for (uint32_t j = lo; j < hi; j += 4) {
-                            const uint32_t last = hi - 1;
-                            const uint64_t m0 = s_keys[j], m1 = s_keys[min(j + 1, last)], m2 = s_keys[min(j + 2, last)], m3 = s_keys[min(j + 3, last)];
-                            below += (m0 < key) + (j + 1 < hi && m1 < key) + (j + 2 < hi && m2 < key) + (j + 3 < hi && m3 < key);
-                        }
-                        dst[q] = lo + below;
-                    }
-                }
-                __syncthreads();   // all reads of the key array done: its storage becomes the sorted low words
-#pragma unroll
-                for (int q = 0; q < PERK; ++q)
-                    if (tid + q * THREADS < n) {
-                        const uint32_t w = (uint32_t)kreg[q], m16 = code_mask(w & 0xFFu);
-                        s_out[dst[q]] = w;
-                        if (m16 & 0x00FFu) atomicAdd(&s_chunk[dst[q] >> 6], 1u);
-                        if (m16 & 0xFF00u) atomicAdd(&s_chunk[LSR_WAVE + (dst[q] >> 6)], 1u);
-                    }
-            } else {
-                // ---- bitonic network over the padded list (a heavy cluster plus a far outlier overfilled a bucket) ----
-                uint32_t npad = 2;
-                while (npad < n) npad <<= 1;
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < PERK; ++q) s_keys[tid + q * THREADS] = kreg[q];   // padding = ~0
-                for (uint32_t i = CAP + tid; i < npad; i += THREADS) s_keys[i] = ~0ull;   // (CAP = 3072 pads to 4096: the counter array's bytes)
-                __syncthreads();
-                for (uint32_t k = 2; k <= npad; k <<= 1) {
-                    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                        for (uint32_t t = tid; t < (npad >> 1); t += THREADS) {
-                            const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                            const uint32_t hi = lo | j;
-                            const bool up = (lo & k) == 0;
-                            const uint64_t a = s_keys[lo], b = s_keys[hi];
-                            if ((a > b) == up) { s_keys[lo] = b; s_keys[hi] = a; }
-                        }
-                        __syncthreads();
-                    }
-                }
-                uint32_t lowq[PERK];
-#pragma unroll
-                for (int q = 0; q < PERK; ++q) lowq[q] = (uint32_t)s_keys[tid + q * THREADS];
-                __syncthreads();
-                if (tid < 2 * LSR_WAVE) s_chunk[tid] = 0;     // (the padded network may have run over the counts)
-                __syncthreads();
-#pragma unroll
-                for (int q = 0; q < PERK; ++q) {
-                    const uint32_t pos = tid + q * THREADS;
-                    if (pos < n) {
-                        const uint32_t m16 = code_mask(lowq[q] & 0xFFu);
-                        s_out[pos] = lowq[q];
-                        if (m16 & 0x00FFu) atomicAdd(&s_chunk[pos >> 6], 1u);
-                        if (m16 & 0xFF00u) atomicAdd(&s_chunk[LSR_WAVE + (pos >> 6)], 1u);
-                    }
-                }
-            }
-            __syncthreads();   // sorted low words + chunk counts complete; the key registers are dead
-        }
-        // ---- the next tile's keys: in flight while this tile's lists are written ----
-        if (has_next && sortable(nstart, nn)) load_keys(nstart, nn);
-        if (sorting) {
-            for (uint32_t i = tid; i < n; i += THREADS) point_list[start + i] = key_index(s_out[i]);
-            // every wave scans the 64 chunk counts of both halves in registers (two 32-bit fields of one u64)
-            const uint64_t v = (uint64_t)s_chunk[lane] | ((uint64_t)s_chunk[LSR_WAVE + lane] << 32);
-            uint64_t incl = v;
-#pragma unroll
-            for (int off = 1; off < LSR_WAVE; off <<= 1) { const uint64_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-            const uint64_t excl = incl - v, tot = __shfl(incl, LSR_WAVE - 1);
-            const int nchunks = (int)((n + LSR_WAVE - 1) / LSR_WAVE);
-            for (int c = wid; c < nchunks; c += kWaves) {
-                const uint32_t p = (uint32_t)(c * LSR_WAVE + lane);
-                const uint32_t w = s_out[min(p, n - 1)];
-                const uint32_t idx = key_index(w), m16 = p < n ? code_mask(w & 0xFFu) : 0u;
-                const uint64_t off = __shfl(excl, c);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t bits = half_bits(m16, h);
-                    const uint64_t bal = __ballot(bits != 0u);
-                    if (bits) {
-                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                        hdst[(size_t)h * n + (uint32_t)(off >> (32 * h)) + below] = idx | (bits << kListBitsShift);
-                    }
-                }
-            }
-            if (tid == 0) { hcnt[0] = (uint32_t)tot; hcnt[1] = (uint32_t)(tot >> 32); }
-        }
-        if (!has_next) break;
-        it = nit; vt = nvt; start = nstart; n = nn;
-        __syncthreads();   // the LDS arrays are reused by the next tile
-    }
-}
-
 // Global-memory path for lists longer than the LDS capacity: bottom-up merge sort by one
 // workgroup per oversized tile (rank-by-binary-search merges, ping-pong between keys and tmp).
 // Rare (needs > kSortLdsMax Gaussians over one 16x16 tile); correctness path, not tuned.
@@ -775,22 +532,6 @@ k_sort_tiles_global(const uint32_t *__restrict__ tile_start, uint64_t *keys, uin
 // Dynamic LDS of a sort variant, and (once per process, device and variant) the function attribute the larger ones need.
 template <int CAP>
 constexpr size_t sort_lds_bytes() { return (size_t)CAP * 8 + (size_t)(CAP < 2048 ? CAP : 2048) * 4; }
-// persistent first tier: resident workgroups only (the register budget gives 6 waves per SIMD = 24 per CU, the LDS
-// allocation must let as many workgroups in), each walking the costliest-first tile list with the grid's stride
-template <int CAP, int THREADS, int MINW>
-static void sort_launch_p2(uint32_t tiles, hipStream_t s, const uint32_t *order, const uint32_t *ts, const uint64_t *keys,
-                           uint32_t *plist, const HalfOut &ho) {
-    constexpr size_t lds = sort_lds_bytes<CAP>() + 2 * LSR_WAVE * 4;
-    const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>((4u * MINW) / (THREADS / LSR_WAVE), (uint32_t)((160 * 1024) / lds)));
-    const uint32_t grid = std::min<uint32_t>(tiles, (uint32_t)device_cus() * per_cu);
-    hipLaunchKernelGGL((k_sort_tiles_p<CAP, THREADS, MINW>), dim3(grid), dim3(THREADS), lds, s, order, tiles, ts, keys, plist, ho);
-}
-template <int CAP, int THREADS>
-static void sort_launch_p(int minw, uint32_t tiles, hipStream_t s, const uint32_t *order, const uint32_t *ts, const uint64_t *keys,
-                          uint32_t *plist, const HalfOut &ho) {
-    if (minw == 5) sort_launch_p2<CAP, THREADS, 5>(tiles, s, order, ts, keys, plist, ho);
-    else sort_launch_p2<CAP, THREADS, 6>(tiles, s, order, ts, keys, plist, ho);
-}
 template <int CAP, int THREADS, bool PERS>
 static void sort_launch(dim3 grid, hipStream_t s, int cls, const uint32_t *order, const uint32_t *ts, const uint64_t *keys,
                         uint32_t *plist, const HalfOut &ho, unsigned long long *trace) {
@@ -896,15 +637,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         const int forced = env_int("LSR_SORT_TIER1", 0);      // measurement aid: first-tier capacity whatever the longest list is
         const int32_t longest = forced > 0 ? forced : (device_counts ? std::max<int32_t>(max_tile_pairs, 4096) : max_tile_pairs);
         int32_t tier1;     // capacity of the first tier
-        const int persist = env_int("LSR_SORT_PERSIST", 1);   // 0: one workgroup per tile; 1 / 2: persistent workgroups at 6 / 5 waves per SIMD
-        if (persist && legacy != 1) {
-            const uint32_t tiles = grid.x;
-            const int minw = persist == 2 ? 5 : 6;
-            if (longest <= 1024) { tier1 = 1024; sort_launch_p<1024, 128>(minw, tiles, s, order, ts, keys, plist, ho); }
-            else if (longest <= 2048) { tier1 = 2048; sort_launch_p<2048, 256>(minw, tiles, s, order, ts, keys, plist, ho); }
-            else if (longest <= 3072) { tier1 = 3072; sort_launch_p<3072, 384>(minw, tiles, s, order, ts, keys, plist, ho); }
-            else { tier1 = 4096; sort_launch_p<4096, 512>(minw, tiles, s, order, ts, keys, plist, ho); }
-        } else if (legacy == 1) {
+        if (legacy == 1) {
             if (longest <= 1024) { tier1 = 1024; sort_launch<1024, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
             else if (longest <= 2048) { tier1 = 2048; sort_launch<2048, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
             else { tier1 = 4096; sort_launch<4096, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }

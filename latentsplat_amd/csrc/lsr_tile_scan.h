@@ -12,12 +12,16 @@
 
 namespace lsr {
 
+constexpr int kScanClasses = 1024;   // cost classes of the work-item order (whatever the workgroup size: with the folded
+                                     // instance's 256 threads = 256 classes the bench scene's lists fell into 43 classes
+                                     // instead of 172 and the compositing backward, whose first 4096 items are assigned
+                                     // statically in this order, ran 3 % longer)
 template <int THREADS>
 struct TileScanShared {
     uint32_t wave[THREADS / LSR_WAVE];
     uint32_t mx[THREADS / LSR_WAVE];
     uint64_t tot64[THREADS / LSR_WAVE];
-    uint32_t cls[THREADS];      // counting-sort classes: histogram -> running offsets
+    uint32_t cls[kScanClasses];      // counting-sort classes: histogram -> running offsets
 };
 
 // What the host of a synchronous forward reads from its mapped words: [0] pair count (saturated), [1] longest list,
@@ -164,10 +168,13 @@ __device__ __forceinline__ void tile_scan_block(const uint32_t *count, uint32_t 
     // correctness matter. ----
     // class = THREADS - 1 - floor(w THREADS / (maxc + 1)), in float (a software 64-bit division per count was a third of
     // this stage; the classes only steer scheduling, and both passes below evaluate the same expression)
-    const float cls_scale = (float)THREADS / ((float)maxc + 1.0f);
-    auto cls = [&](uint32_t w) -> uint32_t { return THREADS - 1 - min((uint32_t)((float)w * cls_scale), (uint32_t)(THREADS - 1)); };
+    const float cls_scale = (float)kScanClasses / ((float)maxc + 1.0f);
+    auto cls = [&](uint32_t w) -> uint32_t { return kScanClasses - 1 - min((uint32_t)((float)w * cls_scale), (uint32_t)(kScanClasses - 1)); };
     if (tid == 0) header[kHdrNumItems] = 2u * (uint32_t)N;
-    sh.cls[tid] = 0;
+    constexpr int CPT = kScanClasses / THREADS;   // classes per thread of the offset scan
+    static_assert(kScanClasses % THREADS == 0, "whole classes per thread");
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) sh.cls[tid * CPT + k] = 0;
     __syncthreads();
     if (in_regs) {
 #pragma unroll
@@ -181,10 +188,13 @@ __device__ __forceinline__ void tile_scan_block(const uint32_t *count, uint32_t 
         for (int i = lo; i < hi; ++i) atomicAdd(&sh.cls[cls(scan_load<ATOMIC>(&count[i]))], 2u);
     }
     __syncthreads();
-    const uint32_t mine = sh.cls[tid];
+    uint32_t cnt[CPT], mine = 0;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) { cnt[k] = sh.cls[tid * CPT + k]; mine += cnt[k]; }
     uint32_t num_items;
-    const uint32_t first = block_exclusive_scan<THREADS>(mine, sh.wave, num_items);   // exclusive start of class tid
-    sh.cls[tid] = first;
+    uint32_t first = block_exclusive_scan<THREADS>(mine, sh.wave, num_items);   // exclusive start of this thread's classes
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) { sh.cls[tid * CPT + k] = first; first += cnt[k]; }
     __syncthreads();
     if (in_regs) {
 #pragma unroll

@@ -28,8 +28,10 @@
 #include <algorithm>
 #include <type_traits>
 
-#include "lsr_internal.h"
+#include "lsr_blend.h"
+#include "lsr_project.h"
 #include "lsr_sh.h"
+#include "lsr_tile_scan.h"
 
 namespace lsr {
 
@@ -54,13 +56,14 @@ struct ShParams {
     uint32_t mdiv[2];         // ceil(2^22 / ks): x / ks == (x * mdiv) >> 22 for x < 8192
     uint32_t mdivK, mdivKf;   // same for K (coefficients per colour channel) and Kf
     GroupStrides gs;          // view groups: blockIdx.y = group, every pointer above advances by the group's slices
-    int full_line;            // forward, 64-byte records: re-read the geometry half and store the WHOLE line (LSR_SH_FULL_LINE)
 };
 // the launch's parameters as seen by view group blockIdx.y (uniform: scalar arithmetic)
 __device__ __forceinline__ ShParams group_params(const ShParams &pk) {
     ShParams p = pk;
     const int64_t g = blockIdx.y;
     p.in.views += g * pk.gs.views; p.in.means3D += g * pk.gs.means;
+    if (p.in.cov3D) p.in.cov3D += g * pk.gs.cov;
+    if (p.in.opacities) p.in.opacities += g * pk.gs.opac;
     if (p.in.color) p.in.color += g * pk.gs.color;
     if (p.in.features) p.in.features += g * pk.gs.feat;
     p.vis += g * pk.gs.slots * pk.vis_stride; p.rec += g * pk.gs.slots * pk.RF; p.clamp += g * pk.gs.slots;
@@ -182,12 +185,6 @@ k_sh_fwd(ShParams pk) {
         if (!(active && f.visf > 0.0f)) return;
         const ShDir dir = sh_direction(p, v, f.pos);
         float *R = p.rec + o * (size_t)p.RF + 8;
-        // Whole-line store (LSR_SH_FULL_LINE, 64-byte records): k_preprocess wrote this record's line as a whole; a
-        // 32-byte store into it is a PARTIAL line write, which the memory system turns into a read-modify-write once the
-        // line has left the Infinity Cache (16 views x 393 216 records = 403 MB at configs[4]).  Re-reading the geometry
-        // half and storing all 64 bytes keeps every write a full line.
-        float4 geo0 = make_float4(0, 0, 0, 0), geo1 = geo0;
-        if (p.full_line) { geo0 = *(const float4 *)(R - 8); geo1 = *(const float4 *)(R - 4); }
         float basF[9];
         // features use the reference's axis naming: B^ref(x,y,z) = B(z,x,y) up to degree 2
         if (hasF) sh_basis<2>(degF, dir.dz, dir.dx, dir.dy, basF);
@@ -239,7 +236,6 @@ k_sh_fwd(ShParams pk) {
             for (int c = c_next; c < pad; c += 4)
                 *(float4 *)(R + COFF + c) = make_float4(feat(c), feat(c + 1), feat(c + 2), feat(c + 3));
         }
-        if (p.full_line) { *(float4 *)(R - 8) = geo0; *(float4 *)(R - 4) = geo1; }
     };
 
     if (sh_shared_scene(p)) {
@@ -260,6 +256,197 @@ k_sh_fwd(ShParams pk) {
             const Fetched f = fetch(v);
             staged_barrier();
             if (wave == (v & (kShWaves - 1))) compute(v, f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage K1 and the SH payload pass as ONE kernel (round 4), for calls whose payload is evaluated from harmonics only
+// (colour SH and / or latent-feature SH: the reference's configs[3] / [4] shape) and whose views share their inputs
+// (one scene, or view groups).  The two-kernel form wrote every visible record twice — k_preprocess the whole 64-byte
+// line, k_sh_fwd the payload half of it: a PARTIAL line write that the memory system turns into a read-modify-write
+// once the line has left the Infinity Cache (16 views x 393 216 records = 403 MB at configs[4]: k_sh_fwd ran at 0.26 of
+// the HBM peak there) — and read the means and the visibility words a second time.  Here thread (wave = view, lane =
+// Gaussian) projects its Gaussian (lsr_project.h: the same IEEE sequence as k_preprocess, bit for bit), evaluates the
+// harmonics from the coefficient rows its workgroup staged in LDS and stores the finished record, one whole line.
+// A workgroup walks `chunks` consecutive 64-Gaussian chunks so that its LDS-privatised tile histogram is flushed once
+// per 512 Gaussians (as in k_preprocess); the last workgroup to finish runs the tile scan (lsr_tile_scan.h).
+struct PreShArgs {
+    char *binrec; int narrow;
+    int32_t *radii;
+    uint32_t *tile_count, *header;
+    FoldedScan fs;
+    int chunks;         // 64-Gaussian chunks per workgroup
+    int lds_hist;       // tile histogram of the group's views privatised in LDS (behind the coefficient rows)
+    int hist_off;       // its offset in the dynamic LDS allocation, in words
+    int views_total;    // views of the whole call (the scan's count array)
+};
+
+template <int DEGC, int COFF, bool FMA>
+__global__ void __launch_bounds__(kShThreads)
+k_preprocess_sh(ShParams pk, PreShArgs a) {
+    const ShParams p = group_params(pk);
+    extern __shared__ float s_lds[];
+    __shared__ float2 s_focal[64];
+    const lsr_dims &d = p.d;
+    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wave = __builtin_amdgcn_readfirstlane(tid / LSR_WAVE);
+    const int G = d.num_gaussians, V = d.num_views;        // the GROUP's views (all views of a call without groups)
+    const int gx = (d.width + LSR_TILE - 1) / LSR_TILE, gy = (d.height + LSR_TILE - 1) / LSR_TILE, T = gx * gy;
+    const int C = d.feat_channels, K = d.sh_coeffs, Kf = d.feat_sh_coeffs, degF = d.feat_sh_degree;
+    const bool hasF = p.has[1] != 0;
+    const bool cmaj = d.color_sh_channel_major != 0;
+    const bool cax = d.color_sh_convention == LSR_SH_AXES_REFERENCE;
+    const int ce = d.cov_elems;
+    const int RF = p.RF;
+    const size_t slot0 = (size_t)blockIdx.y * pk.gs.slots;             // first (view, Gaussian) slot of this group
+    const int view0 = blockIdx.y * (pk.gs.slots ? V : 0);               // first view of this group in the call
+    int32_t *radii = a.radii + slot0;
+    char *binrec = a.binrec + slot0 * (a.narrow ? sizeof(BinRec) : sizeof(BinRecWide));
+    uint32_t *tile_count = a.tile_count + (size_t)view0 * T;
+    uint32_t *s_hist = (uint32_t *)s_lds + a.hist_off;
+    const float *my = s_lds + lane * p.ks[0];
+    const float *myF = s_lds + p.offF + lane * p.ks[1];
+    // per-view constants that cost an IEEE division each: once per workgroup
+    for (int v = tid; v < V && v < 64; v += kShThreads) {
+        const float *vw = p.in.views + (size_t)v * LSR_VIEW_FLOATS;
+        s_focal[v] = make_float2(d.width / (2.0f * vw[35]), d.height / (2.0f * vw[36]));
+    }
+    if (a.lds_hist)
+        for (int t = tid; t < V * T; t += kShThreads) s_hist[t] = 0;
+
+    for (int c = 0; c < a.chunks; ++c) {
+        const int g0 = (blockIdx.x * a.chunks + c) * LSR_WAVE;
+        if (g0 >= G) break;                                   // block-uniform
+        const int i = g0 + lane;
+        const int rows = G - g0 < LSR_WAVE ? G - g0 : LSR_WAVE;
+        const bool active = i < G;
+        const size_t ii = active ? (size_t)i : 0;
+        __syncthreads();                                      // the previous chunk is done with the coefficient rows (first pass: s_focal, histogram cleared)
+        stage_group(s_lds, p, 0, 0, g0, rows, tid);
+        stage_group(s_lds, p, 1, 0, g0, rows, tid);
+        // the Gaussian, once for all views of this lane's waves (the four waves read the same 64 rows: cache hits)
+        const float *mp = p.in.means3D + 3 * ii;
+        const float q0 = mp[0], q1 = mp[1], q2 = mp[2];
+        const float *c6 = p.in.cov3D + (size_t)ce * ii;
+        const float r0 = c6[0], r1 = c6[1], r2 = c6[2];
+        const float r3 = c6[ce == 9 ? 4 : 3], r4 = c6[ce == 9 ? 5 : 4], r5 = c6[ce == 9 ? 8 : 5];
+        const float opacity = p.in.opacities[ii];
+        staged_barrier();
+        for (int v = wave; v < V; v += kShWaves) {
+            const kfloat_ptr vw = (kfloat_ptr)(p.in.views + (size_t)v * LSR_VIEW_FLOATS);
+            float vm[16], pm[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { vm[k] = vw[k]; pm[k] = vw[16 + k]; }
+            const float limx = 1.3f * vw[35], limy = 1.3f * vw[36];
+            const float2 focal = s_focal[v < 64 ? v : 0];
+            const float focal_x = v < 64 ? focal.x : d.width / (2.0f * vw[35]), focal_y = v < 64 ? focal.y : d.height / (2.0f * vw[36]);
+            const float scale = vw[40], scale2 = scale * scale;
+            const float p0 = q0 * scale, p1 = q1 * scale, p2 = q2 * scale;
+            const Projected pj = project_gaussian<FMA>(vm, pm, limx, limy, focal_x, focal_y, p0, p1, p2, r0 * scale2, r1 * scale2, r2 * scale2,
+                                                       r3 * scale2, r4 * scale2, r5 * scale2, d.width, d.height, gx, gy, active);
+            const bool ok = pj.ok;
+            const size_t o = (size_t)v * G + ii;
+            if (ok) {
+                uint32_t *hist = a.lds_hist ? s_hist + v * T : tile_count + (size_t)v * T;
+                for (int y = pj.rminy; y < pj.rmaxy; ++y)
+                    for (int x = pj.rminx; x < pj.rmaxx; ++x) atomicAdd(&hist[y * gx + x], 1u);
+            }
+            if (active) {
+                const uint32_t span = ok ? footprint_cells(pj.px, pj.py, pj.conic_a, pj.conic_b, pj.conic_c, opacity, pj.rminx, pj.rminy) : kSpanNone;
+                radii[o] = ok ? (int32_t)pj.radius : 0;
+                const float out_depth = ok ? pj.tz : 0.0f;
+                if (a.narrow) {
+                    BinRec br;
+                    br.rect = ok ? ((uint32_t)pj.rminx | ((uint32_t)pj.rminy << 8) | ((uint32_t)pj.rmaxx << 16) | ((uint32_t)pj.rmaxy << 24)) : 0u;
+                    br.depth = out_depth; br.span = span;
+                    ((BinRec *)binrec)[o] = br;
+                } else {
+                    BinRecWide br;
+                    br.rect = ok ? make_ushort4((unsigned short)pj.rminx, (unsigned short)pj.rminy, (unsigned short)pj.rmaxx, (unsigned short)pj.rmaxy)
+                                 : make_ushort4(0, 0, 0, 0);
+                    br.depth = out_depth; br.span = span;
+                    ((BinRecWide *)binrec)[o] = br;
+                }
+            }
+            if (!ok) continue;
+            // ---- payload from the harmonics (the arithmetic of k_sh_fwd, operation for operation) ----
+            const ShDir dir = sh_direction(p, v, ShPos{q0, q1, q2});
+            float basF[9];
+            if (hasF) sh_basis<2>(degF, dir.dz, dir.dx, dir.dy, basF);
+            auto feat = [&](int ch) -> float {
+                if (ch >= C) return 0.0f;
+                return sh_dot<2, 1>(basF, myF + ch * Kf, degF) + 0.5f;
+            };
+            float col[3] = {0.0f, 0.0f, 0.0f};
+            if (DEGC >= 0) {
+                float basC[25];
+                sh_basis<DEGC>(DEGC, cax ? dir.dz : dir.dx, cax ? dir.dx : dir.dy, cax ? dir.dy : dir.dz, basC);
+                uint32_t bits = 0;
+                float a0, a1, a2;
+                if (cmaj) {
+                    a0 = sh_dot<DEGC, 1>(basC, my, DEGC) + 0.5f;
+                    __builtin_amdgcn_sched_barrier(0);
+                    a1 = sh_dot<DEGC, 1>(basC, my + K, DEGC) + 0.5f;
+                    __builtin_amdgcn_sched_barrier(0);
+                    a2 = sh_dot<DEGC, 1>(basC, my + 2 * K, DEGC) + 0.5f;
+                } else {
+                    a0 = sh_dot<DEGC, 3>(basC, my, DEGC) + 0.5f;
+                    __builtin_amdgcn_sched_barrier(0);
+                    a1 = sh_dot<DEGC, 3>(basC, my + 1, DEGC) + 0.5f;
+                    __builtin_amdgcn_sched_barrier(0);
+                    a2 = sh_dot<DEGC, 3>(basC, my + 2, DEGC) + 0.5f;
+                }
+                if (a0 < 0.0f) bits |= 1u;
+                if (a1 < 0.0f) bits |= 2u;
+                if (a2 < 0.0f) bits |= 4u;
+                col[0] = a0 > 0.0f ? a0 : 0.0f; col[1] = a1 > 0.0f ? a1 : 0.0f; col[2] = a2 > 0.0f ? a2 : 0.0f;
+                p.clamp[o] = (uint8_t)bits;
+            }
+            float4 *R = (float4 *)(p.rec + o * (size_t)RF);
+            R[0] = make_float4(pj.px, pj.py, pj.conic_a, pj.conic_b);
+            R[1] = make_float4(pj.conic_c, opacity, pj.tz, 0.0f);
+            // payload slots 8.. : rgb (COFF = 3) then the feature channels, zero padded to the record
+            auto slot = [&](int ch) -> float { return ch < COFF ? col[ch < 3 ? ch : 0] : (hasF ? feat(ch - COFF) : 0.0f); };
+#pragma unroll 1
+            for (int j = 2; j < RF / 4; ++j) {
+                const int ch = 4 * (j - 2);
+                R[j] = make_float4(slot(ch), slot(ch + 1), slot(ch + 2), slot(ch + 3));
+            }
+        }
+    }
+    if (a.lds_hist) {
+        __syncthreads();
+        for (int t = tid; t < V * T; t += kShThreads) {
+            const uint32_t cnt = s_hist[t];
+            if (cnt) atomicAdd(&tile_count[t], cnt);
+        }
+    }
+    // ---- the tile scan in the last workgroup to arrive (as in k_preprocess; the counts pass through LDS) ----
+    if (a.fs.enabled) {
+        __shared__ uint32_t s_last;
+        __shared__ TileScanShared<kShThreads> s_scan;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t arrived = __hip_atomic_fetch_add(&a.header[kHdrPreDone], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = arrived == gridDim.x * gridDim.y - 1u;
+        }
+        __syncthreads();
+        if (s_last) {
+            uint32_t *s_counts = (uint32_t *)s_lds;
+            const int N = a.views_total * T;
+            for (int i0 = tid; i0 < N; i0 += 4 * kShThreads) {
+                uint32_t cc[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    cc[k] = __hip_atomic_load(&a.tile_count[min(i0 + k * kShThreads, N - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (i0 + k * kShThreads < N) s_counts[i0 + k * kShThreads] = cc[k];
+            }
+            __syncthreads();
+            tile_scan_block<kShThreads, 0, false>(s_counts, a.fs.tile_start, a.header, HostMirror{a.fs.host_words, a.fs.host_seq},
+                                                  a.fs.tile_order, N, a.fs.capacity, s_scan);
         }
     }
 }
@@ -499,8 +686,6 @@ static ShParams make_params(const lsr_dims &d, const lsr_inputs &in, const GeomL
     p.rec = (float *)const_cast<char *>(geom + L.rec);
     p.clamp = (uint8_t *)const_cast<char *>(geom + L.sh_clamp);
     p.grec = nullptr; p.RF = L.rec_floats; p.g = lsr_in_grads{};
-    // (only when the payload half is written completely: colour + features filling slots 8..15, or features alone)
-    p.full_line = 0;
     p.has[0] = group_enabled(d, 0); p.has[1] = group_enabled(d, 1);
     p.ks[0] = p.has[0] ? d.sh_coeffs * 3 : 0;
     p.ks[1] = p.has[1] ? d.feat_sh_coeffs * d.feat_channels : 0;
@@ -526,14 +711,59 @@ hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom
     if (d.num_gaussians == 0) return hipSuccess;
     if (!group_enabled(d, 0) && !group_enabled(d, 1)) return hipSuccess;
     const GeomLayout L = geom_layout(d);
-    ShParams p = make_params(d, in, L, geom);
+    const ShParams p = make_params(d, in, L, geom);
     const int degc = p.has[0] ? d.sh_degree : -1, coff = d.color_mode != LSR_COLOR_NONE ? 3 : 0;
-    p.full_line = L.rec_floats == 16 && p.has[1] && (coff == 0 || p.has[0]) && coff + d.feat_channels > 4 && env_int("LSR_SH_FULL_LINE", 0) != 0;
     const dim3 grid((d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE, num_view_groups(d)), block(kShThreads);
     const size_t shm = ((size_t)p.offF + (size_t)LSR_WAVE * p.ks[1]) * 4;
     prof_begin(kStShFwd, s);
     LSR_SH_DISPATCH(k_sh_fwd, degc, coff, grid, block, shm, s, p);
     prof_end(kStShFwd, s);
+    return hipGetLastError();
+}
+
+bool fused_preprocess_sh(const lsr_dims &d) {
+    if (d.num_gaussians == 0 || !env_int("LSR_FUSE_SH", 1)) return false;
+    const bool color_sh = d.color_mode == LSR_COLOR_SH, feat_sh = d.feat_channels > 0 && d.feat_mode == LSR_FEAT_SH;
+    if (!color_sh && !feat_sh) return false;
+    if (d.color_mode == LSR_COLOR_PRECOMP || (d.feat_channels > 0 && !feat_sh)) return false;   // a payload channel that is not a harmonic
+    // the views of a workgroup read one input slice: a shared scene or view groups
+    const bool shared = d.vs_means == 0 && d.vs_cov == 0 && d.vs_opac == 0 && (!color_sh || d.vs_color == 0) && (!feat_sh || d.vs_feat == 0);
+    return shared || d.views_per_group > 1;
+}
+
+hipError_t launch_preprocess_sh(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, const FoldedScan &fs_in, hipStream_t s) {
+    const GeomLayout L = geom_layout(d);
+    {
+        hipError_t e = launch_clear(geom + L.header, L.tile_start - L.header, s);   // header + tile_count + tile_cursor
+        if (e != hipSuccess) return e;
+    }
+    const ShParams p = make_params(d, in, L, geom);
+    const int degc = p.has[0] ? d.sh_degree : -1;
+    const int T = (int)num_tiles(d), groups = num_view_groups(d), Vg = group_dims(d).num_views;
+    PreShArgs a;
+    a.binrec = geom + L.bin; a.narrow = narrow_bins(d) ? 1 : 0; a.radii = radii;
+    a.tile_count = (uint32_t *)(geom + L.tile_count); a.header = (uint32_t *)(geom + L.header);
+    a.fs = fs_in;
+    a.fs.tile_start = (uint32_t *)(geom + L.tile_start); a.fs.tile_order = (uint32_t *)(geom + L.tile_order);
+    a.views_total = d.num_views;
+    // chunks per workgroup: one round of resident workgroups (three per CU) when the scene is large enough, at most 8
+    const int64_t resident = (int64_t)device_cus() * 3 / groups;
+    const int64_t nchunks = (d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE;
+    a.chunks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (nchunks + std::max<int64_t>(resident, 1) - 1) / std::max<int64_t>(resident, 1)));
+    const size_t coef_words = (size_t)p.offF + (size_t)LSR_WAVE * p.ks[1];
+    a.lds_hist = (size_t)Vg * T <= 8192 ? 1 : 0;
+    a.hist_off = (int)((coef_words + 3) & ~(size_t)3);
+    size_t shm = ((size_t)a.hist_off + (a.lds_hist ? (size_t)Vg * T : 0)) * 4;
+    if (a.fs.enabled) shm = std::max<size_t>(shm, (size_t)kFoldTiles * 4);            // the scan stages the counts at the start of the allocation
+    const dim3 grid((unsigned)((nchunks + a.chunks - 1) / a.chunks), groups), block(kShThreads);
+    const bool fma = projection_contraction();
+    prof_begin(kStPreprocess, s);
+#define LSR_PSH(DC, CO) do { if (fma) hipLaunchKernelGGL((k_preprocess_sh<DC, CO, true>), grid, block, shm, s, p, a); \
+                             else hipLaunchKernelGGL((k_preprocess_sh<DC, CO, false>), grid, block, shm, s, p, a); } while (0)
+    if (degc == 4) LSR_PSH(4, 3); else if (degc == 3) LSR_PSH(3, 3); else if (degc == 2) LSR_PSH(2, 3);
+    else if (degc == 1) LSR_PSH(1, 3); else if (degc == 0) LSR_PSH(0, 3); else LSR_PSH(-1, 0);
+#undef LSR_PSH
+    prof_end(kStPreprocess, s);
     return hipGetLastError();
 }
 

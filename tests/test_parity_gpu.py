@@ -3,6 +3,8 @@
 Bars (BASELINE.json north_star): tile / sort indices bit-exact; rendered colour / latent / mask /
 depth within 1e-4 abs; gradients within 1e-4 (relative to the gradient scale, see below).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -370,6 +372,55 @@ def test_fused_scene_inputs_match_oracle(hip_device, cfg, shared):
         else:
             for v in range(V):
                 util.assert_grad_close_except_fragile(got[v], want[v], frag[v][0], frag[v][1], ABS_TOL, f"dL/d{k}[view {v}]", clean_tol=CLEAN_TOL)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(G=3001, size=64, b=1, v=3, color_sh_degree=4, feature_channels=4, feature_sh_degree=2),    # shared scene, odd G (unaligned rows)
+    dict(G=2000, size=(40, 72), b=3, v=2, color_sh_degree=4, feature_channels=4, feature_sh_degree=2),   # view groups: the decoder's shape
+    dict(G=2500, size=48, b=1, v=6, color_sh_degree=3, feature_channels=None),                       # colour only, > 4 views per workgroup
+    dict(G=1800, size=48, b=2, v=1, color_sh_degree=None, feature_channels=8, feature_sh_degree=1),  # latent harmonics only, 8 channels
+    dict(G=900, size=32, b=1, v=2, color_sh_degree=1, feature_channels=20, feature_sh_degree=1),     # 23 channels: 64-float records
+])
+def test_fused_projection_and_sh_kernel_equals_the_two_kernel_path(hip_device, cfg):
+    """Calls whose payload is harmonics only and whose views share their inputs run the projection and the SH payload
+    pass as ONE kernel (sh.hip k_preprocess_sh); everything else runs k_preprocess + k_sh_fwd.  Same arithmetic, so
+    every output, the radii and every gradient must be bitwise identical between the two (LSR_FUSE_SH, switched in
+    process), in the synchronous and the no-sync forward."""
+    from latentsplat_amd import _lib
+    from latentsplat_amd.decoder import cuda_splatting as cs
+    from latentsplat_amd.rasterizer import make_view_table, rasterize_views
+    cfg = dict(cfg)
+    G, size, b, v = cfg.pop("G"), cfg.pop("size"), cfg.pop("b"), cfg.pop("v")
+    H, W = (size, size) if isinstance(size, int) else size
+    dev = hip_device
+    scenes = [util.make_scene(G, image_size=max(H, W), views=v, seed=70 + s, **cfg) for s in range(b)]
+    tables = []
+    for sc in scenes:
+        cams, scale = cs._scaled_cameras(sc.extrinsics, sc.intrinsics, sc.near * torch.linspace(1.0, 1.2, v), sc.far, True)
+        tables.append(make_view_table(cams.view_matrix, cams.full_projection, cams.campos, cams.tan_fov_x,
+                                      cams.tan_fov_y, torch.tensor([[0.3, 0.2, 0.1]]).expand(v, 3), scale))
+    views = torch.cat(tables).to(dev)
+    stack = lambda name: None if getattr(scenes[0], name) is None else torch.stack([getattr(s, name) for s in scenes])
+    sq = (lambda t: None if t is None else t[0]) if b == 1 else (lambda t: t)          # b = 1: shared (G, ...) tensors
+    fields = dict(means=sq(stack("means")), cov=sq(stack("covariances")), opac=sq(stack("opacities")[..., None]),
+                  shs=sq(stack("color_sh")), fsh=sq(stack("feature_sh")))
+    deg = 0 if fields["shs"] is None else int(round(fields["shs"].shape[-1] ** 0.5)) - 1
+    gen = torch.Generator().manual_seed(5)
+    results = {}
+    for fuse in (1, 0):
+        _lib.set_knob("LSR_FUSE_SH", fuse)
+        for mode, kw in (("sync", {}), ("nosync", dict(pair_capacity=4 * b * v * G + 16, max_tile_hint=4096))):
+            leaf = {k: (None if x is None else x.to(dev).clone().requires_grad_(True)) for k, x in fields.items()}
+            out = rasterize_views(views, H, W, deg, leaf["means"], leaf["cov"], leaf["opac"], shs=leaf["shs"],
+                                  feature_sh=leaf["fsh"], shs_channel_major=True, **kw)
+            results[(fuse, mode)] = [None if o is None else o.detach().clone() for o in out]
+    _lib.set_knob("LSR_FUSE_SH", 1)
+    ref = results[(0, "sync")]
+    for key, res in results.items():
+        for name, a, r in zip(("colour", "feature", "mask", "depth", "radii"), res, ref):
+            assert (a is None) == (r is None), (key, name)
+            if a is not None:
+                assert torch.equal(a, r), f"{key}: {name} differs between the fused and the two-kernel path"
 
 
 @pytest.mark.parametrize("cfg,direct", [

@@ -20,7 +20,7 @@ import bench  # noqa: E402
 from latentsplat_amd import _lib  # noqa: E402
 from latentsplat_amd.rasterizer import rasterize_views  # noqa: E402
 
-DEFAULTS = {"LSR_FOLD_SCAN": 1, "LSR_HOST_POLL": 1, "LSR_SORT_LPT": 1, "LSR_SORT_VARIANT": 0, "LSR_SH_PLACEMENT": 0,
+DEFAULTS = {"LSR_FOLD_SCAN": 1, "LSR_HOST_POLL": 1, "LSR_SORT_LPT": 1, "LSR_SORT_VARIANT": 0, "LSR_SH_PLACEMENT": 1, "LSR_FUSE_SH": 1,
             "LSR_FWD8_VARIANT": 0, "LSR_FWD_VARIANT": 0, "LSR_BWD_VARIANT": 0, "LSR_SCATTER_VARIANT": 0, "LSR_SORT_PERSIST": 1, "LSR_SORT_TIER1": 0, "LSR_SH_FULL_LINE": 0}
 
 
@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--workloads", default="raster16,cfg3,cfg4")
+    ap.add_argument("--gaussians", type=int, default=300_000, help="scene size of the raster16 workload")
     ap.add_argument("sets", nargs="*")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -58,7 +59,7 @@ def main():
     wl = {}
     want = args.workloads.split(",")
     if "raster16" in want:
-        inp = bench.build_inputs(300_000, 16, 256, dev, 1234)
+        inp = bench.build_inputs(args.gaussians, 16, 256, dev, 1234)
         gf = torch.randn((16, 4, 256, 256), device=dev)
 
         def r_fwd():
