@@ -206,26 +206,24 @@ int lsr_pack_view(const float *viewmatrix, const float *projmatrix, const float 
  * (ABI v7: no separate scan kernel for calls of up to 4096 (view, tile) pairs) and writes the two numbers plus the
  * call's sequence number into mapped host memory as soon as it has them; the host polls that word (an event behind
  * the kernel is the fallback) — the rest of the scan is still running when the call returns.
- * Also starts the view-dependent payload pass (colour / latent features from SH), which only depends on
- * the preprocess: it runs on a library-owned side stream (one per device, forked from `stream` with an
- * event) while the host fetches the pair count and the binning of phase 2 runs; phase 2 joins it
- * before compositing.  Every lsr_forward_prepare must be followed by lsr_forward_render or, if the forward
- * is given up, by lsr_forward_abandon before geom_ws is released.  lsr_forward_nosync does the same inside one call (event fork / join are
- * captured by a stream capture).  LSR_SH_SIDE_STREAM=0 keeps every launch on `stream`. */
+ * The view-dependent payload (colour / latent features from SH) is evaluated by the same kernel as the projection
+ * when the call's payload is harmonics only and its views share their inputs (one scene or view groups: ABI v7), else by
+ * a second launch right behind it — all on `stream` (rounds 2-3 ran that pass on a library-owned side stream; it lost
+ * to the in-line launch once the host stopped sleeping on an event, see api.hip). */
 int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii,
                         int64_t *num_pairs_host, int32_t *max_tile_pairs_host,
                         lsr_stream_t stream);
 
 /* ---- forward, phase 2: binning, per-tile depth sort, front-to-back compositing. Async.  Must follow
- * the lsr_forward_prepare of the same geom_ws on the same device (it waits for that call's SH pass). */
+ * the lsr_forward_prepare of the same geom_ws on the same stream. */
 int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, void *bin_ws,
                        void *img_ws, int64_t num_pairs, int32_t max_tile_pairs,
                        const lsr_outputs *out, lsr_stream_t stream);
 
-/* ---- a forward that is given up between lsr_forward_prepare and lsr_forward_render (e.g. the binning
- * workspace could not be allocated): lsr_forward_prepare may have left the SH payload pass running on the
- * library's side stream, writing into geom_ws.  This makes `stream` wait for everything on the side stream,
- * so that geom_ws can be released in `stream` order (what a caching allocator does).  Async. */
+/* ---- a forward that is given up between lsr_forward_prepare and lsr_forward_render (e.g. the binning workspace
+ * could not be allocated).  ABI v6 had to join the library's side stream here before geom_ws could be released; since
+ * v7 every launch of a forward is on `stream`, stream-ordered release is safe by itself and this call does nothing.
+ * Kept so that v6 callers keep linking. */
 int lsr_forward_abandon(lsr_stream_t stream);
 
 /* ---- forward WITHOUT host synchronisation (latency mode; graph-capturable).  The same stages as

@@ -173,106 +173,31 @@ static int check_dims(const lsr_dims *d) {
     return LSR_OK;
 }
 
-// The library owns ONE side stream per device, shared by all host threads, for work that may run beside
-// the caller's stream inside a call:
-//   * the SH payload pass (sh.hip) depends on k_preprocess only and touches nothing that tile_scan / scatter /
-//     sort read or write: forked after the preprocess launch, joined before the first compositing launch
-//     (in the synchronous forward this also fills the host's round trip for the pair count);
-//   * the backward's per-scene geometry / SH kernels of odd scenes.
-// Every cross-stream edge is an event record + a stream wait.  The events are shared too, so a record and the
-// wait that consumes it are issued under the context's mutex (a wait binds to the record that precedes it):
-// another host thread re-recording the same event can then only make a LATER wait cover more work, never less
-// — the side stream executes in order, so a wait on the latest record covers every earlier one.
-// LSR_SH_PLACEMENT (development knob): 0 = side stream, 1 (default since round 4) = on the caller's stream right behind
-// k_preprocess, 2 = on the caller's stream behind the binning (in front of the compositing launch).  Measured on MI355X
-// (tools/ab_knobs.py): beside the binning chain the SH pass and the per-tile sort slow each other down by
-// more than the overlap hides — configs[3] forward 0.325 (side) / 0.313 (1) / 0.321 ms (2), configs[4] 0.926 / 0.912 /
-// 0.921 ms.  LSR_SH_SIDE_STREAM=0 is the older spelling of 1.
-struct SideCtx {
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;            // caller -> side, side -> caller
-    std::mutex mu;
-    bool tried = false;
-};
-static int sh_placement() {
-    if (!env_int("LSR_SH_SIDE_STREAM", 1)) return 1;
-    const int p = env_int("LSR_SH_PLACEMENT", 1);
-    return p < 0 || p > 2 ? 0 : p;
-}
-static SideCtx *side_ctx() {
-    if (sh_placement() != 0) return nullptr;
-    static SideCtx ctx[64];
-    static std::mutex mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    SideCtx &c = ctx[dev];
-    if (!c.tried) {
-        c.tried = true;
-        bool ok = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&c.fork, hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&c.join, hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            (void)hipGetLastError();
-            c.side = nullptr;
-        }
-    }
-    return c.side ? &c : nullptr;
-}
-// `to` waits for everything queued on `from` so far (ev: one of the context's events)
-static hipError_t cross_edge(SideCtx *c, hipEvent_t ev, hipStream_t from, hipStream_t to) {
-    std::lock_guard<std::mutex> lock(c->mu);
-    hipError_t e = hipEventRecord(ev, from);
-    if (e != hipSuccess) return e;
-    return hipStreamWaitEvent(to, ev, 0);
-}
-
 // a separate SH payload pass behind k_preprocess (not when the fused projection + SH kernel handles the call)
 static bool has_sh_payload(const lsr_dims &d) {
     return d.num_gaussians > 0 && (d.color_mode == LSR_COLOR_SH || (d.feat_channels > 0 && d.feat_mode == LSR_FEAT_SH)) &&
            !fused_preprocess_sh(d);
 }
-// SH forward of all view groups: on the side stream (forked from what is queued on `s` so far; the caller
-// joins with sh_forward_join before the compositing launch), or in line on `s`.
-static int sh_forward_fork(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s) {
-    if (!has_sh_payload(d) || sh_placement() == 2) return LSR_OK;
-    SideCtx *c = side_ctx();
-    hipStream_t q = s;
-    if (c) {
-        LSR_HIP(cross_edge(c, c->fork, s, c->side));
-        q = c->side;
-    }
-    LSR_STAGE("sh_forward", q, launch_sh_forward(d, in, geom, q));   // all view groups in one launch
-    if (c) {
-        std::lock_guard<std::mutex> lock(c->mu);
-        LSR_HIP(hipEventRecord(c->join, c->side));
-    }
-    return LSR_OK;
-}
-// The caller's stream waits for the SH pass (the latest record of the join event: this call's, or a later one
-// of another host thread, which the in-order side stream completes after this call's).
-static int sh_forward_join(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s) {
+// The SH payload pass of calls the fused kernel does not cover (per-view inputs, direct payload channels next to
+// harmonics) runs IN LINE on the caller's stream, right behind k_preprocess.  Rounds 2-3 ran it on a library-owned side
+// stream beside the tile scan, the host round trip and the binning chain (forked / joined with events).  Measured in
+// round 4 (tools/ab_knobs.py): beside the binning chain the SH pass and the per-tile sort slow each other
+// down by more than the overlap hides — configs[3] forward 0.325 ms (side stream) vs 0.313 (in line), configs[4] 0.926 vs
+// 0.912 — and with the host polling for the pair count there is no round trip left to fill.  The side stream, its events
+// and its mutex are gone; lsr_forward_abandon stays in the ABI as a no-op.
+static int sh_forward_inline(const lsr_dims &d, const lsr_inputs &in, char *geom, hipStream_t s) {
     if (!has_sh_payload(d)) return LSR_OK;
-    if (sh_placement() == 2) {   // in line, behind the binning
-        LSR_STAGE("sh_forward", s, launch_sh_forward(d, in, geom, s));
-        return LSR_OK;
-    }
-    if (SideCtx *c = side_ctx()) {
-        std::lock_guard<std::mutex> lock(c->mu);
-        LSR_HIP(hipStreamWaitEvent(s, c->join, 0));
-    }
+    LSR_STAGE("sh_forward", s, launch_sh_forward(d, in, geom, s));   // all view groups in one launch
     return LSR_OK;
 }
 
-// Binning + forward compositing on `s`; the compositing launch waits for the SH payload pass on the side stream.
+// Binning + forward compositing on `s`.
 // (Round 3 also carried an in-call pipeline that ran the binning of one half of the views beside the compositing of
-// the other half on the side stream: bit-identical, never faster — both halves are issue-bound — and deleted in
+// the other half on a side stream: bit-identical, never faster — both halves are issue-bound — and deleted in
 // round 4.  Callers with independent batches overlap whole calls on two streams instead: INTEGRATION.md.)
 static int forward_tail(const lsr_dims &d, const lsr_inputs &in, char *geom, char *bin, char *img, int64_t num_pairs,
                         int32_t max_tile_pairs, const lsr_outputs &out, hipStream_t s, bool device_counts) {
     LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts));
-    int rc = sh_forward_join(d, in, geom, s);
-    if (rc) return rc;
     LSR_STAGE("render_forward", s, launch_render_forward(d, in, geom, bin, num_pairs, img, out, s));
     return LSR_OK;
 }
@@ -476,7 +401,7 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
     if (fused_preprocess_sh(*d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(*d, *in, geom, radii, fs, s));
     else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, fs, s));
     if (fold && mapped) LSR_HIP(hipEventRecord(h_event, s));
-    rc = sh_forward_fork(*d, *in, geom, s);   // view-dependent payload: beside the host round trip and the binning
+    rc = sh_forward_inline(*d, *in, geom, s);   // view-dependent payload of calls the fused kernel does not cover
     if (rc) return rc;
     if (!fold) {
         LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, mapped ? h_hdr_dev : nullptr, h_seq, 0xFFFFFFFFu, s));
@@ -518,8 +443,8 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
 }
 
 int lsr_forward_abandon(lsr_stream_t stream) {
+    (void)stream;   // ABI v6 joined the library's side stream here; since v7 every launch of a forward is on the caller's stream
     g_last_hip_error = 0;
-    if (SideCtx *c = side_ctx()) LSR_HIP(cross_edge(c, c->join, c->side, (hipStream_t)stream));
     return LSR_OK;
 }
 
@@ -544,7 +469,7 @@ int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     fs.capacity = (uint32_t)pair_capacity;
     if (fused_preprocess_sh(*d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(*d, *in, geom, out->radii, fs, s));
     else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, fs, s));
-    rc = sh_forward_fork(*d, *in, geom, s);
+    rc = sh_forward_inline(*d, *in, geom, s);
     if (rc) return rc;
     if (!fold) LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, 0u, (uint32_t)pair_capacity, s));
     return forward_tail(*d, *in, geom, (char *)bin_ws, (char *)img_ws, pair_capacity, max_tile_hint, *out, s, true);

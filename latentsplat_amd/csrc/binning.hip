@@ -246,8 +246,8 @@ __device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint
     if (tid < 2) hcnt[tid] = tid == 0 ? run0 : run1;
 }
 
-// One workgroup of THREADS threads per (tile, view); list length n <= CAP = 8 * THREADS for the first tier (the keys of a
-// list live in registers, eight per thread), keys sorted inside LDS.
+// One workgroup of THREADS (= 512) threads per (tile, view); list length n <= CAP, keys in registers (CAP / THREADS per
+// thread), sorted inside LDS.
 //
 // Order-preserving bucket sort: bucket = (key - min) >> shift is monotone in the key, so a histogram +
 // scan puts every key into its final neighbourhood; inside a bucket (about one key on average) a
@@ -264,11 +264,12 @@ __device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint
 // that was half of the kernel (phase trace: 5.1 of 10.2 us per workgroup).  All LDS scratch lives in the dynamic
 // allocation (the reduction scratch aliases the key array before keys are placed).
 //
-// Round 4: the first tier's workgroup size follows the longest list of the call — 128 / 256 / 384 / 512 threads for
-// lists up to 1024 / 2048 / 3072 / 4096 keys, always eight keys per thread and ~76 VGPRs — because the kernel is a
-// chain of a dozen barrier-separated, latency-bound phases: what it needs is TILES IN FLIGHT per compute unit (24
-// resident waves = 12 / 6 / 4 / 3 tiles), not threads per tile.  Round 3 ran every call whose longest list exceeded
-// 2048 keys on the 512-thread variant (the bench scene: lists of 1 920 +- 50 keys, longest 2 130 -> 3 tiles per CU).
+// Round 4, measured and rejected (tools/ab_knobs.py): smaller workgroups for shorter lists (128 / 256 / 384
+// threads for up to 1024 / 2048 / 3072 keys, always eight keys per thread, i.e. more TILES in flight per CU: 0.0675 vs
+// 0.0597 ms on a scene whose longest list is 2 741 keys — the 384-thread variant loses 13 %); persistent workgroups that
+// request the next tile's keys while the current tile's lists are written and count the half-list entries while the
+// sorted words are placed (no counting pass, two barriers fewer): 0.074 ms at 80 VGPRs with spills, 0.086 at 96, against
+// 0.065 for this kernel — on gfx9 the wait for the prefetched keys also waits for the list stores issued behind them.
 constexpr uint32_t kBucketOverflow = 48;   // longest bucket the in-bucket pass may get
 
 // tier: 0 = first launch of a call (also owns the empty lists), 1 = a later tier (its tiles come from a long list)
@@ -624,29 +625,20 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
             (void)hipMemsetAsync(trace, 0, (size_t)grid.x * 64, s);
         }
 #endif
-        // Tiers: (1) one workgroup per tile, the variant whose capacity (8 keys per thread) covers the longest list the
-        // host knows of — 128 / 256 / 384 / 512 threads for up to 1024 / 2048 / 3072 / 4096 keys; longer lists are
-        // appended to one of two lists by that launch and sorted by persistent launches of (2) the 8192-key variant (two
-        // workgroups per CU), (3) the 16 384-key variant (one) and (4) the global merge path.  The later tiers are
+        // Tiers: (1) one 512-thread workgroup per tile, in costliest-first order, with the variant that fits the longest
+        // list the host knows of (1024 / 2048 / 4096 keys); longer lists are appended to one of two lists by that launch
+        // and sorted by persistent launches of (2) the 8192-key variant (two workgroups per CU), (3) the 16 384-key variant
+        // (one) and (4) the global merge path.  The later tiers are
         // launched when the host knows they are needed (synchronous forward) or cannot know (no-sync forward: a few
         // hundred workgroups each that find an empty list; its first tier is always the 4096-key variant, whatever the
         // caller's hint says, so that only lists beyond 4096 keys take the later tiers).
         prof_begin(kStSort, s);
         const uint32_t *order = env_int("LSR_SORT_LPT", 1) ? (const uint32_t *)(geom + L.tile_order) : nullptr;
-        const int legacy = env_int("LSR_SORT_VARIANT", 0);    // 1: round 3's choice (512 threads whatever the list length)
-        const int forced = env_int("LSR_SORT_TIER1", 0);      // measurement aid: first-tier capacity whatever the longest list is
-        const int32_t longest = forced > 0 ? forced : (device_counts ? std::max<int32_t>(max_tile_pairs, 4096) : max_tile_pairs);
+        const int32_t longest = device_counts ? std::max<int32_t>(max_tile_pairs, 4096) : max_tile_pairs;
         int32_t tier1;     // capacity of the first tier
-        if (legacy == 1) {
-            if (longest <= 1024) { tier1 = 1024; sort_launch<1024, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
-            else if (longest <= 2048) { tier1 = 2048; sort_launch<2048, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
-            else { tier1 = 4096; sort_launch<4096, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
-        } else {
-            if (longest <= 1024) { tier1 = 1024; sort_launch<1024, 128, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
-            else if (longest <= 2048) { tier1 = 2048; sort_launch<2048, 256, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
-            else if (longest <= 3072) { tier1 = 3072; sort_launch<3072, 384, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
-            else { tier1 = 4096; sort_launch<4096, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
-        }
+        if (longest <= 1024) { tier1 = 1024; sort_launch<1024, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
+        else if (longest <= 2048) { tier1 = 2048; sort_launch<2048, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
+        else { tier1 = 4096; sort_launch<4096, 512, false>(grid, s, 0, order, ts, keys, plist, ho, trace); }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         const uint32_t cus = (uint32_t)device_cus();

@@ -393,10 +393,10 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     } while (0)
     const int variant = env_int("LSR_FWD_VARIANT", 0);
     if (nchp == 4) { if (variant == 2) LSR_RF(4, 16, 16); else if (variant == 3) LSR_RF(4, 14, 28); else LSR_RF(4, 12, 24); }   // 2 x 12 waves per CU: 0.245 vs 0.281 ms per 16 views with 16
-    else if (nchp == 8) {   // 7 / 8 channels (colour + 4 latent channels: the reference's configs[3] / [4] payload): 7.3 KB of LDS and 90 VGPRs per wave
-        const int v8 = env_int("LSR_FWD8_VARIANT", 0);
-        if (v8 == 1) LSR_RF(8, 10, 20); else if (v8 == 2) LSR_RF(8, 8, 16); else LSR_RF(8, 16, 16);
-    }
+    // 7 / 8 channels (colour + 4 latent channels: the reference's configs[3] / [4] payload; 7.3 KB of LDS and 90 VGPRs per
+    // wave).  Round 4 measured 2 x 10 waves per CU (what LDS and registers allow at most) and 2 x 8: configs[3] 0.1426 /
+    // 0.1367 ms against 0.1377 for one 16-wave workgroup, configs[4] 0.3019 / 0.3006 / 0.3017 — no gain, the shape stays.
+    else if (nchp == 8) LSR_RF(8, 16, 16);
     else if (nchp == 12) LSR_RF(12, 12, 12);
     else LSR_RF(36, 4, 8);
 #undef LSR_RF

@@ -314,3 +314,31 @@ def render_depth_cuda(
                       gaussian_means, gaussian_covariances, gaussian_opacities, color_sh,
                       scale_invariant=scale_invariant)
     return out.color.mean(dim=1)
+
+
+def render_depth_scenes(
+    extrinsics: Tensor,             # (b,v,4,4)
+    intrinsics: Tensor,             # (b,v,3,3)
+    near: Tensor,                   # (b,v)
+    far: Tensor,                    # (b,v)
+    image_shape: tuple[int, int],
+    gaussian_means: Tensor,         # (b,g,3)      -- NOT replicated per view
+    gaussian_covariances: Tensor,   # (b,g,3,3)
+    gaussian_opacities: Tensor,     # (b,g)
+    scale_invariant: bool = True,
+    mode: DepthRenderingMode = "depth",
+) -> Tensor:
+    """Scene-major form of ``render_depth_cuda`` (what ``DecoderSplattingCUDA.render_depth`` calls): the same
+    images as the reference's v-fold ``repeat`` of the Gaussians (decoder_splatting_cuda.py:93-114), but only the
+    grey "colour" — the one per-(view, Gaussian) quantity — is per view; means, covariances and opacities of a scene
+    are handed to the rasterizer once, shared by its v views (one call per scene).  Returns (b,v,h,w)."""
+    b, v = extrinsics.shape[:2]
+    views = _view_table(extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(0, 1), far.flatten(0, 1),
+                        torch.zeros(3, dtype=torch.float32, device=extrinsics.device), scale_invariant)
+    outs = []
+    for s in range(b):
+        fake = _depth_as_color(extrinsics[s], near[s], far[s], gaussian_means[s][None].expand(v, -1, -1), mode)   # (v,g)
+        out = _render_views(views[s * v:(s + 1) * v], image_shape, gaussian_means[s][None], gaussian_covariances[s][None],
+                            gaussian_opacities[s][None], fake[:, :, None, None].expand(-1, -1, 3, 1), None, True)
+        outs.append(out.color.mean(dim=1))
+    return torch.stack(outs)

@@ -14,7 +14,7 @@ from typing import Literal, Optional
 import torch
 from torch import Tensor
 
-from .cuda_splatting import DepthRenderingMode, RenderOutput, render_depth_cuda, render_scenes
+from .cuda_splatting import DepthRenderingMode, RenderOutput, render_depth_scenes, render_scenes
 from .decoder import Decoder, DecoderOutput
 from .types import DiagonalGaussianDistribution, Gaussians
 
@@ -71,12 +71,9 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
     def render_depth(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor,
                      far: Tensor, image_shape: tuple[int, int],
                      mode: DepthRenderingMode = "depth") -> Tensor:
-        b, v = extrinsics.shape[:2]
-        rep = lambda t: t[:, None].expand(b, v, *t.shape[1:]).flatten(0, 1)
-        result = render_depth_cuda(extrinsics.flatten(0, 1), intrinsics.flatten(0, 1), near.flatten(0, 1),
-                                   far.flatten(0, 1), image_shape, rep(gaussians.means),
-                                   rep(gaussians.covariances), rep(gaussians.opacities), mode=mode)
-        return result.unflatten(0, (b, v))
+        # scene-major: the Gaussians are not replicated per view (the reference repeats them v-fold, :105-110)
+        return render_depth_scenes(extrinsics, intrinsics, near, far, image_shape, gaussians.means,
+                                   gaussians.covariances, gaussians.opacities, mode=mode)
 
     def last_layer_weights(self) -> None:
         return None

@@ -232,8 +232,6 @@ class _RasterizeViews(torch.autograd.Function):
                            "lsr_forward_nosync")
             else:
                 try:
-                    # prepare() forks the SH payload pass onto the library's side stream before its own later failure
-                    # points (the wait for the pair count, the unsupported-size return): it sits inside the try as well
                     _lib.check(lib.lsr_forward_prepare(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii),
                                                        C.byref(npairs), C.byref(maxtile), stream),
                                "lsr_forward_prepare")
@@ -243,8 +241,7 @@ class _RasterizeViews(torch.autograd.Function):
                                                       npairs.value, maxtile.value, C.byref(outs), stream),
                                "lsr_forward_render")
                 except BaseException:
-                    # the SH payload pass may still be writing `geom` on the side stream: the current stream has to
-                    # wait for it before the caching allocator may hand these blocks out again
+                    # (a no-op since ABI v7 — every launch of a forward is on the caller's stream — kept for v6 libraries)
                     lib.lsr_forward_abandon(stream)
                     raise
             if debug:

@@ -142,45 +142,13 @@ torch.save(a.cpu(), sys.argv[1])
     assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
 
 
-def test_sh_side_stream_does_not_change_results(hip_device):
-    """The SH payload pass runs on a library-owned side stream (forked after the preprocess, joined before
-    compositing).  With LSR_SH_SIDE_STREAM=0 (read once per process, hence a subprocess) every launch stays
-    on the caller's stream: both modes must give bitwise identical images, synchronous and no-sync."""
-    import hashlib
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import sys, torch, hashlib
-sys.path.insert(0, %r)
-from tests.test_latency_gpu import _inputs, _render
-dev = torch.device("cuda:0")
-bi, views, t, size = _inputs(dev, G=30000, V=3, size=96, sh=3)
-h = hashlib.sha1()
-for kw in ({}, dict(pair_capacity=400000, max_tile_hint=2048)):
-    for _ in range(3):          # back-to-back calls: forks and joins of successive forwards interleave on the side stream
-        out = _render(views, t, size, 3, **kw)
-    for o in out[:4]:
-        h.update(o.cpu().numpy().tobytes())
-print("HASH", h.hexdigest())
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    digests = {}
-    for side in ("1", "0"):
-        env = dict(os.environ, LSR_SH_SIDE_STREAM=side)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        digests[side] = r.stdout.strip().splitlines()[-1]
-    assert digests["1"].startswith("HASH ") and digests["1"] == digests["0"], digests
-
-
 def test_launch_structure_knobs_do_not_change_results(hip_device):
     """Where the tile scan runs (folded into the last workgroup of k_preprocess or as a kernel of its own:
     LSR_FOLD_SCAN), how the host waits for the pair count (polling the mapped words or sleeping on the event:
-    LSR_HOST_POLL), where the SH payload pass runs (side stream, behind the preprocess, behind the binning:
-    LSR_SH_PLACEMENT), the order in which the per-tile sort visits the tiles (LSR_SORT_LPT) and its workgroup size
-    (LSR_SORT_VARIANT) only change WHEN and WHERE kernels run: images, the per-pixel workspaces the backward reads and
-    the gradients must be bitwise identical (knobs are read once per process, hence subprocesses), in the synchronous
-    and the no-sync forward, under back-to-back calls and inside a captured hipGraph."""
+    LSR_HOST_POLL) and the order in which the per-tile sort visits the tiles (LSR_SORT_LPT) only change WHEN and WHERE
+    kernels run: images, the per-pixel workspaces the backward reads and the gradients must be bitwise identical (knobs
+    are read once per process, hence subprocesses), in the synchronous and the no-sync forward, under back-to-back
+    calls and inside a captured hipGraph."""
     import os
     import subprocess
     import sys
@@ -224,8 +192,7 @@ print("HASH", h.hexdigest())
     digests = {}
     variants = {"default": {}, "scan_kernel": dict(LSR_FOLD_SCAN="0"), "event_wait": dict(LSR_HOST_POLL="0"),
                 "scan_kernel_event_wait": dict(LSR_FOLD_SCAN="0", LSR_HOST_POLL="0"),
-                "sh_after_preprocess": dict(LSR_SH_PLACEMENT="1"), "sh_after_binning": dict(LSR_SH_PLACEMENT="2"),
-                "sort_natural_order": dict(LSR_SORT_LPT="0"), "sort_512_threads": dict(LSR_SORT_VARIANT="1")}
+                "sort_natural_order": dict(LSR_SORT_LPT="0")}
     for name, extra in variants.items():
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)

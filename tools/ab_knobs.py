@@ -2,7 +2,7 @@
 """A/B of the library's development knobs in ONE process (lsr_debug_set_knob): per-kernel times (hipEvents inside the
 library) and wall-clock step times of the bench workloads for each knob set, alternating, several rounds.
 
-    python tools/ab_knobs.py [--rounds 2] [--workloads raster16,cfg3,cfg4] '{"LSR_FOLD_SCAN":0}' '{"LSR_SORT_VARIANT":1}' ...
+    python tools/ab_knobs.py [--rounds 2] [--workloads raster16,cfg3,cfg4] '{"LSR_FOLD_SCAN":0}' '{"LSR_FUSE_SH":0}' ...
 
 The first (implicit) set is the default configuration {}.  A knob set stays in force until the next one resets it: every
 knob named anywhere on the command line is reset to its default (given as NAME=default in --defaults, else 0) first."""
@@ -20,8 +20,7 @@ import bench  # noqa: E402
 from latentsplat_amd import _lib  # noqa: E402
 from latentsplat_amd.rasterizer import rasterize_views  # noqa: E402
 
-DEFAULTS = {"LSR_FOLD_SCAN": 1, "LSR_HOST_POLL": 1, "LSR_SORT_LPT": 1, "LSR_SORT_VARIANT": 0, "LSR_SH_PLACEMENT": 1, "LSR_FUSE_SH": 1,
-            "LSR_FWD8_VARIANT": 0, "LSR_FWD_VARIANT": 0, "LSR_BWD_VARIANT": 0, "LSR_SCATTER_VARIANT": 0, "LSR_SORT_PERSIST": 1, "LSR_SORT_TIER1": 0, "LSR_SH_FULL_LINE": 0}
+DEFAULTS = {"LSR_FOLD_SCAN": 1, "LSR_HOST_POLL": 1, "LSR_SORT_LPT": 1, "LSR_FUSE_SH": 1, "LSR_FWD_VARIANT": 0, "LSR_BWD_VARIANT": 0}
 
 
 def timed(fn, steps, dev):
