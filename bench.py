@@ -215,7 +215,11 @@ def decoder_step_timing(dev, steps=10, scenes=1):
     _lib.profile_enable(False)
     prof = _lib.profile_read()
     G, V, coeff = 393_216, 4, (25 * 3 + 9 * 4) * 4
+    # (round 4: the forward SH pass runs inside the projection kernel for this shape — `preprocess` below is that fused
+    # kernel: coefficients + geometry in, one 64-byte record per visible (view, Gaussian) [~0.7 of them], the 12-byte bin
+    # record, the radius and the clamp byte out)
     sh_bytes = {"sh_forward": scenes * (G * coeff + V * G * (4 + 12 + 1)),
+                "preprocess": scenes * (G * (coeff + 12 + 36 + 4) + V * G * (12 + 4 + 1) + int(0.7 * V * G) * 64),
                 "sh_backward": scenes * (2 * G * coeff + V * G * (4 + 12 + 1) + G * 12)}
     res["kernel_ms"] = {k: round(ms / n, 4) for k, (ms, n) in prof.items() if n}
     res["sh_roofline"] = {k: dict(ms=round(prof[k][0] / prof[k][1], 4), algorithmic_bytes=nb,
@@ -698,6 +702,7 @@ def main():
                 traffic, tinfo = None, None
         roofline = dict(bound="hbm", kernel="k_render_fwd", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic,
+                        traffic_source=None if tinfo is None else tinfo.get("source_commit"),
                         algorithmic_bytes_per_launch=render_bytes, launch_ms=render_ms_per_launch)
         # The kernel is bound by f32 VALU issue, not by HBM: report that ceiling next to the required
         # HBM figure.  Instruction counts come from the committed PMC pass (same workload), the
@@ -723,11 +728,13 @@ def main():
         # every stage against the HBM roofline with its own algorithmic bytes
         stage_bytes = dict(
             # the shared scene is read once per block of 4 views; written: one 64-byte record per visible
-            # (view, Gaussian), an 8-byte bin record and the 4-byte radius for every one
-            preprocess=-(-V // 4) * G * (12 + 36 + 4 + 4 * C) + g_vis * 64 + V * G * (8 + 4),
+            # (view, Gaussian), a 12-byte bin record and the 4-byte radius for every one (the tile scan runs in the
+            # kernel's last workgroup since round 4; `tile_scan` only appears for calls with more than 4096 tiles)
+            preprocess=-(-V // 4) * G * (12 + 36 + 4 + 4 * C) + g_vis * 64 + V * G * (12 + 4),
             tile_scan=V * (S // 16) * (S // 16) * 12,
-            scatter=V * G * 8 + P * 8,
-            sort_tiles=P * (8 + 4),
+            scatter=V * G * 12 + P * 8,
+            # keys in, canonical list + the two half-tile render lists (0.94 entries per pair) out
+            sort_tiles=P * (8 + 4 + 4),
             render_forward=render_bytes)
         stage_roofline = {}
         for k, nbytes in stage_bytes.items():
@@ -792,7 +799,7 @@ def main():
         pick = lambda d, keys: None if d is None else {k: r4(d.get(k)) for k in keys if k in d}
         line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                      "scaling", "vs_baseline", "dtype", "data", "config")}
-        line["roofline"] = pick(roofline, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "launch_ms"))
+        line["roofline"] = pick(roofline, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "launch_ms"))
         line["cpu_baseline"] = None if cpu is None else dict(
             pick(cpu, ("value", "unit", "cores", "kind", "sample", "fwdbwd_value")),
             torch_oracle=pick(cpu.get("torch_oracle"), ("value", "unit", "cores", "kind")))
@@ -811,6 +818,10 @@ def main():
             shr = lambda d: {k: [v["ms"], v["frac"]] for k, v in (d.get("sh_roofline") or {}).items()}
             line["decoder_step"]["sh_roofline"] = {"cfg3": shr(dec_step), "cfg4": shr(dec_step["batch4"]),
                                                    "unit": "[ms per launch, lower-bound fraction of the 8 TB/s HBM peak]"}
+            # per-kernel times of the forward+backward step at the reference's real shapes (hipEvents inside the library;
+            # `preprocess` is the fused projection + SH payload kernel there)
+            line["decoder_step"]["cfg3_kernel_ms"] = dec_step.get("kernel_ms")
+            line["decoder_step"]["cfg4_kernel_ms"] = dec_step["batch4"].get("kernel_ms")
         if path_step is not None:
             line["path_step"] = pick(path_step, ("forward_ms", "forward_backward_ms"))
         line["full"] = None if side is None else os.path.relpath(side, ROOT)

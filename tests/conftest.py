@@ -42,6 +42,10 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     if not acc:
         return
     tr = terminalreporter
+    if util.PSNR_LOG:
+        tr.section("PSNR of the HIP renders against the oracle's (reference metric, src/evaluation/metrics.py:13-20)")
+        for r in util.PSNR_LOG:
+            tr.write_line(f"{r['what']:64s} {r['db']:8.2f} dB")
     tr.section("parity accounting (what was held to the bar)")
     worst = {}
     for a in acc:
@@ -63,4 +67,4 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     if os.path.isdir(out_dir):
         import json
         with open(os.path.join(out_dir, "parity_accounting.json"), "w") as f:
-            json.dump(acc, f)
+            json.dump(acc + [dict(kind="psnr", **r) for r in util.PSNR_LOG], f)

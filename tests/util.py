@@ -202,6 +202,19 @@ class HipRun:
             self.d.num_views, self.d.height, self.d.width)
 
 
+def psnr(ground_truth: np.ndarray, predicted: np.ndarray) -> float:
+    """PSNR of one (C,H,W) image in dB, as the reference's evaluation computes it (src/evaluation/metrics.py:13-20: both
+    images clipped to [0, 1], mean squared error over channels and pixels, -10 log10).  Used to report the HIP render
+    against the oracle's render of the same scene (BASELINE configs[4] names "PSNR vs reference")."""
+    gt = np.clip(np.asarray(ground_truth, dtype=np.float64), 0.0, 1.0)
+    pr = np.clip(np.asarray(predicted, dtype=np.float64), 0.0, 1.0)
+    mse = float(((gt - pr) ** 2).mean())
+    return float("inf") if mse == 0.0 else -10.0 * float(np.log10(mse))
+
+
+PSNR_LOG: list = []     # (what, dB) records; tests/conftest.py prints them and adds them to parity_accounting.json
+
+
 # ---- accounting of what the parity assertions actually held to the bar -------------------------
 # Every call appends one record; tests/conftest.py prints the table at the end of the session and
 # writes it to tests/_parity_accounting.json (so a reader sees how many pixels / rows were exempt).

@@ -1,15 +1,17 @@
 #!/bin/bash
 # Round profile on the GPU box (run through gpurun): bench JSON + rocprofv3 kernel stats + PMC.
-# usage: tools/collect_profile.sh <tag>       outputs under gpurun_out/<tag>/
+# usage: tools/collect_profile.sh <tag> [commit]      outputs under gpurun_out/<tag>/
+# (`commit` = the HEAD the snapshot was taken from — there is no .git on the box — stamped into the traffic file)
 set -u
 TAG=${1:-r01}
+export LSR_PROFILE_COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err || tail -3 $OUT/bench.err
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err || tail -3 $OUT/bench.err
 cp gpurun_out/bench_full.json $OUT/bench_full.json 2>/dev/null   # the side file of THIS run (later bench invocations overwrite it)
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python bench.py --no-cpu-baseline --no-latency > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err || tail -3 $OUT/rocprof.err
-bash tools/pmc_profile.sh $TAG --steps 3 --warmup 1 --no-cpu-baseline --no-latency > /dev/null 2>&1
-python tools/rocpd_summary.py $OUT/stats/bench_results.db "$TAG: python bench.py (16 views x 300k Gaussians, 256x256; fwd then fwd+bwd)" > $OUT/kernel_stats.md
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-latency > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err || tail -3 $OUT/rocprof.err
+bash tools/pmc_profile.sh $TAG --steps 3 --warmup 1 --clock-warmup 0 --no-cpu-baseline --no-latency > /dev/null 2>&1
+python tools/rocpd_summary.py $OUT/stats/bench_results.db "$TAG ($LSR_PROFILE_COMMIT): python bench.py --steps 40 (16 views x 300k Gaussians, 256x256; fwd then fwd+bwd, decoder legs)" > $OUT/kernel_stats.md
 python tools/pmc_summary.py gpurun_out/pmc_$TAG --traffic-json $OUT/traffic_render_forward.json > $OUT/pmc.md
 cat $OUT/bench.json

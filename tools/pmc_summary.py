@@ -29,14 +29,19 @@ def write_traffic_json(root, acc, path, kernel="lsr::k_render_fwd<4"):
             "kernel": "k_render_fwd", "instance": k,
             "source": f"{root} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, mean per launch)",
             "fetch_size_kib": fetch, "write_size_kib": write,
-            "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
-            "hbm_bytes_per_launch_uncorrected": (fetch + write) * 1024,
+            # calibrated in round 4 (tools/microbench/gather_fetch.hip, profiles/r04_fetch_calibration.md): a 64-byte
+            # record gather is counted EXACTLY (one 64-byte request per record: 564.6 MB counted for 570.4 MB issued, the
+            # difference being the streamed 4-byte index reads, which travel as 128-byte requests tallied at 64 — the only
+            # pattern the guide's factor 2 applies to); WRITE_SIZE is exact (2 GiB written, 2 097 152 KiB counted)
+            "hbm_bytes_per_launch": (fetch + write) * 1024,
+            "hbm_bytes_per_launch_guide_2x": (2 * fetch + write) * 1024,
+            "source_commit": os.environ.get("LSR_PROFILE_COMMIT"),
             "valu_insts_per_launch": c.get("SQ_INSTS_VALU"),
             "valu_trans_insts_per_launch": c.get("SQ_INSTS_VALU_TRANS_F32"),
             "valu_active_quad_cycles_per_launch": c.get("SQ_ACTIVE_INST_VALU"),
-            "note": "corrected = 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950 "
-                    "(FETCH_SIZE tallies 128-B requests at 64 B); the kernel's reads are 64-byte record gathers, "
-                    "for which the factor is uncalibrated, so the uncorrected figure is given too",
+            "note": "FETCH_SIZE + WRITE_SIZE as counted: this kernel's reads are 64-byte record gathers, which the counter "
+                    "tallies exactly (calibration above); the guide's 2 x FETCH_SIZE applies to wide streaming reads only "
+                    "and is kept as hbm_bytes_per_launch_guide_2x",
         }, open(path, "w"), indent=1)
         return
 
