@@ -165,7 +165,7 @@ def rank_seed(base, rank):
     return base + rank
 
 
-def decoder_step_timing(dev, steps=10, scenes=1):
+def decoder_step_timing(dev, steps=40, scenes=1):
     """BASELINE configs[3] shape through the decoder surface: DecoderSplattingCUDA.forward
     (+ backward of an MSE-like loss on colour and latent mean) for batch_size 1 x 4 target views,
     G = 393 216 Gaussians (2 context views x 256^2 x 3), colour SH degree 4 + 4-channel latent SH
@@ -195,7 +195,7 @@ def decoder_step_timing(dev, steps=10, scenes=1):
 
     res = {}
     for name, fn in (("forward", fwd), ("forward_backward", fwdbwd)):
-        el = timed_region(fn, steps, 3, None, lambda: torch.cuda.synchronize(dev))
+        el = timed_region(fn, steps, 10, None, lambda: torch.cuda.synchronize(dev))
         res[name] = dict(ms_per_step=1e3 * el / steps, views_per_s=4 * scenes * steps / el)
     res["config"] = (f"configs[{3 if scenes == 1 else 4}] per-GPU shape: {scenes} scene(s) x 4 views, 393216 Gaussians each, "
                      "colour SH deg 4 + 4-ch latent SH deg 2, 256x256")
@@ -228,7 +228,7 @@ def decoder_step_timing(dev, steps=10, scenes=1):
     return res
 
 
-def path_step_timing(dev, steps=10):
+def path_step_timing(dev, steps=40):
     """The three stages chained as the training step runs them (model_wrapper.py:361-385) at configs[3]'s shape:
     Gaussian adapter tail (2 context cameras x 256^2 rays x 3 samples = 393 216 Gaussians, packed covariances)
     -> DecoderSplattingCUDA.forward (1 x 4 views, colour SH 4 + latent SH 2) -> posterior sample + 1/8 rescale +
@@ -273,7 +273,7 @@ def path_step_timing(dev, steps=10):
 
     res = {}
     for name, fn in (("forward_ms", fwd), ("forward_backward_ms", fwdbwd)):
-        el = timed_region(fn, steps, 3, None, lambda: torch.cuda.synchronize(dev))
+        el = timed_region(fn, steps, 10, None, lambda: torch.cuda.synchronize(dev))
         res[name] = 1e3 * el / steps
     res["config"] = "configs[3] shape: adapter tail (393216 Gaussians) -> decoder (1 x 4 views, SH 4 + latent SH 2, 256x256) -> latent epilogue (factor 8)"
     return res
@@ -496,10 +496,12 @@ def pipelined_timing(dev, inp, V, S, steps, warmup):
         streams = [torch.cuda.Stream(dev) for _ in range(2)]
         for name, n_streams in (("one_stream_nosync", 1), ("two_streams_nosync", 2)):
             def run(k):
-                keep = []
+                # (only the last result of each stream stays referenced: keeping all k alive made the caching allocator
+                # grow by ~44 MB of outputs per step inside the timed loop — hipMalloc, an implicit device synchronisation)
+                keep = [None] * n_streams
                 for i in range(k):
                     with torch.cuda.stream(streams[i % n_streams]):
-                        keep.append(call(**kw))
+                        keep[i % n_streams] = call(**kw)
                 return keep
             for st_ in streams:
                 st_.wait_stream(torch.cuda.current_stream(dev))

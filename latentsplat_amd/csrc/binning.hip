@@ -498,34 +498,53 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t 
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
     return lo;
 }
+// one oversized tile; s_tab: kEmitTab words of LDS scratch
+__device__ __forceinline__ void sort_tile_global(size_t vt, const uint32_t *__restrict__ tile_start, uint64_t *keys, uint64_t *tmp,
+                                                 uint32_t *point_list, const HalfOut &ho, uint64_t *s_tab) {
+    const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
+    uint64_t *src = keys + start, *dst = tmp + start;
+    // width-1 runs are trivially sorted; keys are unique (index in the low word) so ranks are exact
+    for (uint32_t w = 1; w < n; w <<= 1) {
+        for (uint32_t i = threadIdx.x; i < n; i += kSortThreads) {
+            const uint32_t pair = i / (2 * w), a0 = pair * 2 * w;
+            const uint32_t a1 = min(a0 + w, n), b1 = min(a0 + 2 * w, n);
+            const uint64_t x = src[i];
+            uint32_t pos;
+            if (i < a1) pos = a0 + (i - a0) + lower_bound_u64(src + a1, b1 - a1, x);
+            else pos = a0 + (i - a1) + lower_bound_u64(src + a0, a1 - a0, x);
+            dst[pos] = x;
+        }
+        __threadfence_block();
+        __syncthreads();
+        uint64_t *t = src; src = dst; dst = t;
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
+        point_list[start + i] = key_index((uint32_t)src[i]);
+    const uint64_t *sorted = src;
+    emit_half_lists<kSortThreads>(n, ho.half_list + 2 * (size_t)start, ho.half_count + 2 * vt, s_tab, [&](uint32_t p) { return (uint32_t)sorted[p]; });
+}
 __global__ void __launch_bounds__(kSortThreads)
 k_sort_tiles_global(const uint32_t *__restrict__ tile_start, uint64_t *keys, uint64_t *tmp, uint32_t *point_list, HalfOut ho) {
     __shared__ uint64_t s_tab[kEmitTab];
     const uint32_t count = *ho.long_count[1];
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {   // persistent over the tiles beyond the LDS sort
         const size_t vt = long_tile(ho, 1, it);
-        const uint32_t start = tile_start[vt], n = tile_start[vt + 1] - start;
-        if (n <= (uint32_t)kSortLdsMax) continue;   // the class's shorter lists belong to the largest LDS variant
-        uint64_t *src = keys + start, *dst = tmp + start;
-        // width-1 runs are trivially sorted; keys are unique (index in the low word) so ranks are exact
-        for (uint32_t w = 1; w < n; w <<= 1) {
-            for (uint32_t i = threadIdx.x; i < n; i += kSortThreads) {
-                const uint32_t pair = i / (2 * w), a0 = pair * 2 * w;
-                const uint32_t a1 = min(a0 + w, n), b1 = min(a0 + 2 * w, n);
-                const uint64_t x = src[i];
-                uint32_t pos;
-                if (i < a1) pos = a0 + (i - a0) + lower_bound_u64(src + a1, b1 - a1, x);
-                else pos = a0 + (i - a1) + lower_bound_u64(src + a0, a1 - a0, x);
-                dst[pos] = x;
-            }
-            __threadfence_block();
-            __syncthreads();
-            uint64_t *t = src; src = dst; dst = t;
-        }
-        for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
-            point_list[start + i] = key_index((uint32_t)src[i]);
-        const uint64_t *sorted = src;
-        emit_half_lists<kSortThreads>(n, ho.half_list + 2 * (size_t)start, ho.half_count + 2 * vt, s_tab, [&](uint32_t p) { return (uint32_t)sorted[p]; });
+        if (tile_start[vt + 1] - tile_start[vt] <= (uint32_t)kSortLdsMax) continue;   // the class's shorter lists belong to the largest LDS variant
+        sort_tile_global(vt, tile_start, keys, tmp, point_list, ho, s_tab);
+        __syncthreads();
+    }
+}
+// The no-sync forward cannot know whether any list exceeds the first tier: instead of three mostly empty launches (the
+// two persistent LDS tiers and the merge path) it issues ONE, whose workgroups walk both long-tile lists with the
+// largest LDS variant and the merge path behind it.
+__global__ void __launch_bounds__(kSortThreads, 2)
+k_sort_tiles_long(const uint32_t *__restrict__ tile_start, uint64_t *keys, uint64_t *tmp, uint32_t *point_list, HalfOut ho) {
+    extern __shared__ uint64_t s_keys[];
+    const uint32_t c0 = *ho.long_count[0], c1 = *ho.long_count[1];
+    for (uint32_t it = blockIdx.x; it < c0 + c1; it += gridDim.x) {
+        const size_t vt = it < c0 ? long_tile(ho, 0, it) : long_tile(ho, 1, it - c0);
+        if (tile_start[vt + 1] - tile_start[vt] <= (uint32_t)kSortLdsMax) sort_tile<kSortLdsMax, kSortThreads>(s_keys, vt, 1, tile_start, keys, point_list, ho, nullptr);
+        else sort_tile_global(vt, tile_start, keys, tmp, point_list, ho, s_keys);   // (its scratch: the start of the same allocation)
         __syncthreads();
     }
 }
@@ -581,7 +600,12 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         const int64_t work = (int64_t)d.num_views * d.num_gaussians;
         const int64_t rounds = (work + resident * kScatThreads * kScatItems - 1) / (resident * kScatThreads * kScatItems);
         int items = (int)((work + resident * kScatThreads * rounds - 1) / (resident * kScatThreads * rounds));
-        items = std::max(1, std::min(kScatItems, items));
+        // ... but never more than ~160 workgroups per view: every workgroup reserves its share of a tile's segment with ONE
+        // global atomic per tile, and the workgroups of a view hit the same T cursor words — same-address atomics serialise
+        // at ~60 ns each.  With one Gaussian per thread a single 300 k view ran 1 172 workgroups and spent 55 of its 66 us
+        // queueing on those words (round 4: V = 1 scatter 0.066 -> see DESIGN.md §4; V = 4 0.027).
+        const int min_items = (int)((d.num_gaussians + (int64_t)kScatThreads * 160 - 1) / ((int64_t)kScatThreads * 160));
+        items = std::max(1, std::min(kScatItems, std::max(items, min_items)));
         const uint32_t chunks = (uint32_t)((d.num_gaussians + kScatThreads * items - 1) / (kScatThreads * items));
         dim3 grid(chunks * (uint32_t)d.num_views);
         unsigned long long *strace = nullptr;
@@ -643,20 +667,38 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         if (e != hipSuccess) return e;
         const uint32_t cus = (uint32_t)device_cus();
         const dim3 pgrid(cus);
-        if (device_counts || max_tile_pairs > tier1) {   // class 0: two 72 KB workgroups per CU
+        if (device_counts) {   // one launch for whatever the first tier left over (usually nothing)
+            constexpr size_t lds = sort_lds_bytes<kSortLdsMax>();
+            static uint64_t attr_done = 0;     // one bit per device id
+            static std::mutex attr_mu;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            {
+                std::lock_guard<std::mutex> lock(attr_mu);
+                if (dev < 0 || dev >= 64 || !((attr_done >> dev) & 1ull)) {
+                    (void)hipFuncSetAttribute((const void *)k_sort_tiles_long, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (dev >= 0 && dev < 64) attr_done |= 1ull << dev;
+                }
+            }
+            hipLaunchKernelGGL(k_sort_tiles_long, pgrid, dim3(kSortThreads), lds, s, ts, keys, (uint64_t *)(bin + B.tmp), plist, ho);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        } else {
+        if (max_tile_pairs > tier1) {   // class 0: two 72 KB workgroups per CU
             sort_launch<kSortTier2, 512, true>(dim3(2 * cus), s, 0, nullptr, ts, keys, plist, ho, trace);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }
-        if (device_counts || max_tile_pairs > kSortTier2) {   // class 1 up to the LDS capacity
+        if (max_tile_pairs > kSortTier2) {   // class 1 up to the LDS capacity
             sort_launch<kSortLdsMax, 512, true>(pgrid, s, 1, nullptr, ts, keys, plist, ho, trace);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
         }
-        if (device_counts || max_tile_pairs > kSortLdsMax) {
+        if (max_tile_pairs > kSortLdsMax) {
             hipLaunchKernelGGL(k_sort_tiles_global, pgrid, dim3(kSortThreads), 0, s, ts, keys, (uint64_t *)(bin + B.tmp), plist, ho);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
+        }
         }
         prof_end(kStSort, s);
 #ifdef LSR_ENABLE_TRACE

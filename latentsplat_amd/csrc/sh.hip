@@ -282,8 +282,11 @@ struct PreShArgs {
     int views_total;    // views of the whole call (the scan's count array)
 };
 
+#ifndef LSR_PSH_WAVES
+#define LSR_PSH_WAVES 1
+#endif
 template <int DEGC, int COFF, bool FMA>
-__global__ void __launch_bounds__(kShThreads)
+__global__ void __launch_bounds__(kShThreads, LSR_PSH_WAVES)
 k_preprocess_sh(ShParams pk, PreShArgs a) {
     const ShParams p = group_params(pk);
     extern __shared__ float s_lds[];

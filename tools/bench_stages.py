@@ -19,22 +19,30 @@ from latentsplat_amd.rasterizer import rasterize_views  # noqa: E402
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else ""
+    V = 16
+    for a in sys.argv:
+        if a.startswith("--views="):
+            V = int(a.split("=")[1])
     dev = torch.device("cuda", 0)
     _lib.load()
-    out = {"tag": tag}
-    inp = bench.build_inputs(300_000, 16, 256, dev, 1234)
-    gf = torch.randn((16, 4, 256, 256), device=dev)
+    out = {"tag": tag, "views": V}
+    inp = bench.build_inputs(300_000, V, 256, dev, 1234)
+    gf = torch.randn((V, 4, 256, 256), device=dev)
 
     def step():
         m, c, o, f = (t.detach().requires_grad_(True) for t in (inp["means"], inp["cov"], inp["opac"], inp["features"]))
         res = rasterize_views(inp["views"], 256, 256, 0, m, c, o, features=f)
         res[1].backward(gf)
 
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < (0.5 if "--warm" in sys.argv else 0.0):
+        step()
     for _ in range(3):
         step()
     torch.cuda.synchronize()
     _lib.profile_read(); _lib.profile_enable(True)
-    for _ in range(10):
+    for _ in range(40 if "--warm" in sys.argv else 10):
         step()
     torch.cuda.synchronize()
     _lib.profile_enable(False)
