@@ -6,6 +6,8 @@
 // Build this file with -ffp-contract=off: radius / rectangle / depth bits feed the bit-exact
 // tile lists, so every float operation must be the single IEEE operation written here (the CPU
 // oracle performs the identical sequence).  Spec: SURVEY.md Appendix A.1-A.3.
+#include <algorithm>
+
 #include "lsr_blend.h"
 #include "lsr_project.h"
 #include "lsr_tile_scan.h"
@@ -24,9 +26,9 @@ constexpr int kPreItems = 8;  // (Gaussian, view) items per thread: 2048 per blo
 // 578 MB were per-view re-reads of the scene from L2/MALL).  Items per thread shrink by the same
 // factor, so the grid keeps its size.
 template <int COLOR_MODE, bool LDS_HIST, int VB, bool FMA>
-__global__ void __launch_bounds__(kPreThreads)
+__global__ void __launch_bounds__(kPreThreads, 6)   // six waves per SIMD (80 VGPRs): the kernel streams, occupancy hides its latencies
 k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *__restrict__ binrec, int narrow,
-             int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count, uint32_t *header, FoldedScan fs) {
+             int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count, uint32_t *header, FoldedScan fs, int kItems) {
     extern __shared__ uint32_t s_hist[];   // [VB][T] pair counts
     // 64-byte records are staged here and stored by the whole block as one contiguous run
     // (lane-contiguous 16-byte stores) instead of 4 strided partial-line stores per thread.
@@ -58,7 +60,8 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
     constexpr int coff = COLOR_MODE == LSR_COLOR_NONE ? 0 : 3;
     const bool direct_feat = d.feat_mode == LSR_FEAT_DIRECT;
 
-    constexpr int kItems = kPreItems / VB;
+    // kItems Gaussians per thread (at most kPreItems / VB: 2048 (Gaussian, view) items per block and histogram flush;
+    // fewer when the call is small, so that a single view still fills the machine: launch_preprocess)
     const int base = blockIdx.x * (kPreThreads * kItems);
 #pragma unroll 1
     for (int it = 0; it < kItems; ++it) {
@@ -253,8 +256,12 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
                         (d.feat_channels == 0 || d.vs_feat == 0);
     const int span = shared ? d.num_views : (d.views_per_group > 1 ? d.views_per_group : 1);   // views per input slice
     const int vb = (span % 4 == 0 || (shared && span >= 4)) ? 4 : ((span % 2 == 0 || (shared && span >= 2)) ? 2 : 1);
-    const int items = kPreItems / vb;
-    dim3 grid((d.num_gaussians + kPreThreads * items - 1) / (kPreThreads * items), (d.num_views + vb - 1) / vb);
+    // Gaussians per thread: kPreItems / vb (one LDS histogram flush per 2048 items) unless that leaves fewer than two
+    // workgroups per CU — a single 300 k view was 147 workgroups of 8 sequential Gaussians per thread on 256 CUs
+    const int64_t yblocks = (d.num_views + vb - 1) / vb;
+    const int64_t fill = ((int64_t)d.num_gaussians * yblocks + (int64_t)kPreThreads * 2 * device_cus() - 1) / ((int64_t)kPreThreads * 2 * device_cus());
+    const int items = (int)std::max<int64_t>(1, std::min<int64_t>(kPreItems / vb, fill));
+    dim3 grid((d.num_gaussians + kPreThreads * items - 1) / (kPreThreads * items), (unsigned)yblocks);
     float *rec = (float *)(geom + L.rec);
     char *binrec = geom + L.bin;
     const int narrow = narrow_bins(d) ? 1 : 0;
@@ -265,7 +272,7 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     const bool lds = (size_t)T * vb <= 4096;
     const size_t shm = lds ? (size_t)T * vb * 4 : 0;
     const bool fma = projection_contraction();
-#define LSR_PRE3(CM, LH, VBV, FM) hipLaunchKernelGGL((k_preprocess<CM, LH, VBV, FM>), grid, dim3(kPreThreads), shm, s, d, in, rec, RF, binrec, narrow, radii, tc, (uint32_t *)(geom + L.header), fs)
+#define LSR_PRE3(CM, LH, VBV, FM) hipLaunchKernelGGL((k_preprocess<CM, LH, VBV, FM>), grid, dim3(kPreThreads), shm, s, d, in, rec, RF, binrec, narrow, radii, tc, (uint32_t *)(geom + L.header), fs, items)
 #define LSR_PRE2(CM, LH, VBV) do { if (fma) LSR_PRE3(CM, LH, VBV, true); else LSR_PRE3(CM, LH, VBV, false); } while (0)
 #define LSR_PRE(CM)                                                                              \
     do {                                                                                         \
