@@ -486,7 +486,10 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     const int variant = env_int("LSR_BWD_VARIANT", 0);
     if (nchp == 4 && !dg) { if (variant == 1) launch_variant<4, false, 10, 2>(p, s); else if (variant == 2) launch_variant<4, false, 12, 1>(p, s); else launch_variant<4, false, 16, 1>(p, s); }
     else if (nchp == 4) LSR_RB(4, 16, 1);
-    else if (nchp == 8 && !dg) launch_variant<8, false, 16, 1>(p, s);   // packed table rows: 16 waves per CU fit
+    // packed table rows: 16 waves per CU fit with 64-byte staged entries.  (Round 4: this instance shows 34 % LDS bank-conflict
+    // cycles — eight lane groups reading eight 64-byte records start in one of only four bank groups — but the odd
+    // 80-byte stride costs a wave: 15 waves 0.969-0.977 ms, 14 waves 1.02 against 0.945-0.954 at configs[4].)
+    else if (nchp == 8 && !dg) launch_variant<8, false, 16, 1>(p, s);
     else if (nchp == 8) launch_variant<8, true, 12, 1>(p, s);
     else if (nchp == 12) LSR_RB(12, 8, 1);
     else LSR_RB(36, 4, 1);
