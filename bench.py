@@ -754,9 +754,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(G, S, 1234)
         cpu["torch_oracle"] = cpu_baseline_torch()
-    # (the decoder / adapter / latent / chained-path legs run BEFORE the pipelined and latency legs: measured after them —
-    # two extra streams, a captured hipGraph and its private memory pool in the process — the configs[4] forward+backward
-    # step read 2.8 ms where the same function in a fresh process, and tools/drift_probe.py over 240 steps, read 2.43)
+    # (the decoder / adapter / latent / chained-path legs run BEFORE the pipelined and latency legs: measured behind them in
+    # two runs without the CPU baselines — a minute of uninterrupted GPU load, two extra streams, a captured hipGraph and its
+    # private memory pool in the process — the configs[4] forward+backward step read 2.8 ms; in a fresh process, in runs with
+    # the CPU baselines in between and in tools/drift_probe.py over 240 steps the same function reads 2.39-2.43)
     dec_step = adapter_step = latent_step = path_step = None
     if rank == 0 and world == 1 and not args.no_bwd:
         torch.cuda.empty_cache()
