@@ -162,7 +162,8 @@ typedef struct lsr_layout {
      *           geom_half_count[2*(v*T+t)+h] entries `index | sub-block bits << 24`: the canonical list restricted to
      *           the entries whose alpha >= 1/255 footprint box reaches the half, in canonical order; bit (4*r + c) =
      *           the entry can reach the half's 4x4-pixel sub-block (c, r).  img_n_contrib counts positions of THESE
-     *           lists.  (Sort keys are `depth << 32 | index << 8 | sub-block code`: at most 2^24 Gaussians per scene.) */
+     *           lists.  (Sort keys are `depth << 32 | index << 8 | sub-block code`; scenes beyond 2^24 Gaussians use
+     *           `depth << 32 | index` and list entries without bits: every entry then reaches every sub-block.) */
     size_t geom_rec, geom_rec_floats, geom_bin, geom_tile_count, geom_tile_start, geom_header;
     size_t bin_keys, bin_point_list;
     size_t img_final_T, img_n_contrib;

@@ -141,9 +141,9 @@ static int check_dims(const lsr_dims *d) {
     if (tiles_x(*d) > 65535 || tiles_y(*d) > 65535) return LSR_EUNSUPPORTED;
     // work items pack (view*T + tile) into 28 bits (kItemTileMask)
     if ((int64_t)d->num_views * num_tiles(*d) >= (int64_t)1 << 28) return LSR_EUNSUPPORTED;
-    // (view, Gaussian) slots are indexed with 31 bits; sort keys and render-list entries keep the Gaussian index in 24
+    // (view, Gaussian) slots are indexed with 31 bits (scenes beyond 2^24 Gaussians run without footprint culling:
+    // lsr_internal.h IndexPacking)
     if ((int64_t)d->num_views * d->num_gaussians >= (int64_t)1 << 31) return LSR_EUNSUPPORTED;
-    if ((int64_t)d->num_gaussians > (int64_t)kMaxGaussians) return LSR_EUNSUPPORTED;
     // per-view strides: 0 (shared scene) or exactly one dense (G, ...) array per view
     const int64_t G = d->num_gaussians;
     const int64_t color_elems = d->color_mode == LSR_COLOR_SH ? (int64_t)d->sh_coeffs * 3 : 3;

@@ -59,7 +59,7 @@ template <bool LDS_RESERVE, bool NARROW>
 __global__ void __launch_bounds__(kScatThreads, 8)
 k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
           const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ tile_cursor,
-          uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, unsigned long long *trace) {
+          uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, uint32_t key_shift, unsigned long long *trace) {
 #ifdef LSR_ENABLE_TRACE
 #define LSR_STAMP(k) do { if (trace && threadIdx.x == 0) trace[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
 #else
@@ -129,7 +129,7 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
         unpack(it, x0, y0, x1, y1);
         if (x1 <= x0 || y1 <= y0) continue;
         // key = depth bits << 32 | index << 8 | sub-block code of THIS tile (lsr_internal.h)
-        const uint64_t key = ((uint64_t)__float_as_uint(dep[it]) << 32) | (i << kKeyIndexShift);
+        const uint64_t key = ((uint64_t)__float_as_uint(dep[it]) << 32) | (i << key_shift);
         const uint32_t sp = span[it];
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) {
@@ -137,7 +137,7 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
                 uint32_t pos;
                 if (LDS_RESERVE) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
                 else pos = ts[t] + atomicAdd(&cur[t], 1u);
-                const uint32_t code = span_code(sp, x - x0, y - y0);
+                const uint32_t code = key_shift ? span_code(sp, x - x0, y - y0) : 0u;   // (no room for a code beside a 32-bit index)
                 // The position is CLAMPED to the workspace (one v_min; a store under a per-lane bounds test cost 17 % of
                 // this kernel): in the no-sync forward tile_scan clamps the offsets to the capacity, in the synchronous one
                 // the capacity is the host's early pair count — if that ever came out short, the surplus pairs land
@@ -179,12 +179,16 @@ struct HalfOut {
     uint32_t *long_list;
     uint32_t long_cap;        // entries of the array (tiles of the call)
     uint32_t *long_count[2];  // header words
+    IndexPacking ip;          // how keys and list entries carry the Gaussian index (lsr_internal.h)
 };
 constexpr int kSortTier2 = 8192;
 __device__ __forceinline__ uint32_t long_tile(const HalfOut &ho, int cls, uint32_t i) {
     return ho.long_list[cls ? ho.long_cap - 1u - i : i];
 }
-__device__ __forceinline__ uint32_t key_index(uint32_t low_word) { return low_word >> kKeyIndexShift; }
+__device__ __forceinline__ uint32_t key_index(const HalfOut &ho, uint32_t low_word) { return low_word >> ho.ip.key_shift; }
+// 16-bit sub-block mask of a sorted key's low word; list entry of a half
+__device__ __forceinline__ uint32_t key_mask(const HalfOut &ho, uint32_t low_word) { return ho.ip.key_shift ? code_mask(low_word & 0xFFu) : 0xFFFFu; }
+__device__ __forceinline__ uint32_t list_entry(const HalfOut &ho, uint32_t idx, uint32_t bits) { return idx | ((bits << kListBitsShift) & ~ho.ip.index_mask); }
 constexpr int kEmitTab = 130;   // uint64 words of LDS scratch emit_half_lists needs
 
 // Block-wide (THREADS threads): walks the tile's depth-sorted list in order and appends every entry to
@@ -195,7 +199,7 @@ constexpr int kEmitTab = 130;   // uint64 words of LDS scratch emit_half_lists n
 // entry's place is chunk offset + lanes below it in the ballot.
 // hdst = half_list + 2 * tile_start: the list of half h starts at hdst + h * n.
 template <int THREADS, class LowWord>
-__device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint32_t *hcnt, uint64_t *s_tab, LowWord low_word) {
+__device__ __forceinline__ void emit_half_lists(const HalfOut &ho, uint32_t n, uint32_t *hdst, uint32_t *hcnt, uint64_t *s_tab, LowWord low_word) {
     const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
     constexpr int kWaves = THREADS / LSR_WAVE;
     uint32_t run0 = 0u, run1 = 0u;
@@ -207,7 +211,7 @@ __device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint
             uint64_t packed = 0;
             if (p - lane < n) {                                        // wave-uniform: chunks beyond the list only write their zero
                 const uint32_t w = low_word(min(p, n - 1));            // unconditional at a clamped position
-                const uint32_t m16 = p < n ? code_mask(w & 0xFFu) : 0u;
+                const uint32_t m16 = p < n ? key_mask(ho, w) : 0u;
                 packed = (uint64_t)__builtin_popcountll(__ballot((m16 & 0x00FFu) != 0u)) |
                          ((uint64_t)__builtin_popcountll(__ballot((m16 & 0xFF00u) != 0u)) << 32);
             }
@@ -228,7 +232,7 @@ __device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint
             const uint32_t p = base + (uint32_t)(c * LSR_WAVE + lane);
             if (p - lane >= n) break;                                  // wave-uniform
             const uint32_t w = low_word(min(p, n - 1));
-            const uint32_t idx = key_index(w), m16 = p < n ? code_mask(w & 0xFFu) : 0u;
+            const uint32_t idx = key_index(ho, w), m16 = p < n ? key_mask(ho, w) : 0u;
             const uint64_t off = s_tab[LSR_WAVE + c];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -236,7 +240,7 @@ __device__ __forceinline__ void emit_half_lists(uint32_t n, uint32_t *hdst, uint
                 const uint64_t bal = __ballot(bits != 0u);
                 if (bits) {
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    hdst[(size_t)h * n + (h ? run1 : run0) + (uint32_t)(off >> (32 * h)) + below] = idx | (bits << kListBitsShift);
+                    hdst[(size_t)h * n + (h ? run1 : run0) + (uint32_t)(off >> (32 * h)) + below] = list_entry(ho, idx, bits);
                 }
             }
         }
@@ -310,12 +314,12 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
     const uint64_t *src = keys + start;
     if (n == 1) {
         if (tid == 0) {
-            const uint32_t w = (uint32_t)src[0], idx = key_index(w);
+            const uint32_t w = (uint32_t)src[0], idx = key_index(ho, w);
             point_list[start] = idx;
-            const uint32_t m = code_mask(w & 0xFFu);
+            const uint32_t m = key_mask(ho, w);
             for (int h = 0; h < 2; ++h) {
                 const uint32_t bits = half_bits(m, h);
-                if (bits) hdst[h] = idx | (bits << kListBitsShift);
+                if (bits) hdst[h] = list_entry(ho, idx, bits);
                 hcnt[h] = bits ? 1u : 0u;
             }
         }
@@ -418,9 +422,9 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
             if (tid + q * THREADS < n) s_out[dst[q]] = (uint32_t)kreg[q];
         __syncthreads();
         LSR_STAMP(5);
-        for (uint32_t i = tid; i < n; i += THREADS) point_list[start + i] = key_index(s_out[i]);
+        for (uint32_t i = tid; i < n; i += THREADS) point_list[start + i] = key_index(ho, s_out[i]);
         // half-tile render lists (the bucket offsets in s_cnt are dead: scratch of the emitter)
-        emit_half_lists<THREADS>(n, hdst, hcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return s_out[p]; });
+        emit_half_lists<THREADS>(ho, n, hdst, hcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return s_out[p]; });
         LSR_STAMP(6);
     } else {
         // ---- bitonic network over the padded list ----
@@ -454,8 +458,8 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
             }
         }
         // (the emitter's scratch, the counter array, only overlaps padding keys: it reads positions < n <= CAP)
-        for (uint32_t i = tid; i < n; i += THREADS) point_list[start + i] = key_index((uint32_t)s_keys[i]);
-        emit_half_lists<THREADS>(n, hdst, hcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return (uint32_t)s_keys[p]; });
+        for (uint32_t i = tid; i < n; i += THREADS) point_list[start + i] = key_index(ho, (uint32_t)s_keys[i]);
+        emit_half_lists<THREADS>(ho, n, hdst, hcnt, (uint64_t *)s_cnt, [&](uint32_t p) { return (uint32_t)s_keys[p]; });
     }
 #ifdef LSR_ENABLE_TRACE
     if (trace && tid == 0) {
@@ -519,9 +523,9 @@ __device__ __forceinline__ void sort_tile_global(size_t vt, const uint32_t *__re
         uint64_t *t = src; src = dst; dst = t;
     }
     for (uint32_t i = threadIdx.x; i < n; i += kSortThreads)
-        point_list[start + i] = key_index((uint32_t)src[i]);
+        point_list[start + i] = key_index(ho, (uint32_t)src[i]);
     const uint64_t *sorted = src;
-    emit_half_lists<kSortThreads>(n, ho.half_list + 2 * (size_t)start, ho.half_count + 2 * vt, s_tab, [&](uint32_t p) { return (uint32_t)sorted[p]; });
+    emit_half_lists<kSortThreads>(ho, n, ho.half_list + 2 * (size_t)start, ho.half_count + 2 * vt, s_tab, [&](uint32_t p) { return (uint32_t)sorted[p]; });
 }
 __global__ void __launch_bounds__(kSortThreads)
 k_sort_tiles_global(const uint32_t *__restrict__ tile_start, uint64_t *keys, uint64_t *tmp, uint32_t *point_list, HalfOut ho) {
@@ -591,6 +595,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     ho.long_list = (uint32_t *)(geom + L.tile_cursor);
     ho.long_cap = (uint32_t)d.num_views * (uint32_t)T;
     ho.long_count[0] = ho.header + kHdrLongTiles; ho.long_count[1] = ho.long_count[0] + 1;
+    ho.ip = index_packing(d);
     {
         const bool lds = T <= 8192;
         // Items per thread: the launch should be ONE round of resident workgroups (8 per CU, fewer when
@@ -620,7 +625,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         const uint32_t capacity = (uint32_t)(num_pairs < 0xFFFFFFFFll ? num_pairs : 0xFFFFFFFFll);
 #define LSR_SCAT2(LDSR, NRW, SHM)                                                                         \
     hipLaunchKernelGGL((k_scatter<LDSR, NRW>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T, \
-                       (const char *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, strace)
+                       (const char *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, index_packing(d).key_shift, strace)
 #define LSR_SCAT(LDSR, SHM) do { if (narrow_bins(d)) LSR_SCAT2(LDSR, true, SHM); else LSR_SCAT2(LDSR, false, SHM); } while (0)
         if (lds) LSR_SCAT(true, (size_t)T * 8);
         else LSR_SCAT(false, 0);

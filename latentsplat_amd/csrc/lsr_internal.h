@@ -162,6 +162,18 @@ constexpr int kItemHalfShift = 28;
 constexpr uint32_t kListIndexMask = 0x00FFFFFFu;   // half_list entry = Gaussian index | sub-block bits << 24
 constexpr int kListBitsShift = 24;
 constexpr int kMaxGaussians = 1 << 24;             // index field of the sort keys (index << 8 | code) and of the list entries
+// Scenes with MORE Gaussians than that (round 4; round 3 rejected them) keep the full 32-bit index in the key's low word
+// and in the list entries and give up the footprint culling instead: every entry of a tile's list goes to both half lists
+// and is evaluated on every sub-block — the published algorithm's work, correct, slower.  The kernels take the two
+// constants below as launch arguments (uniform; two scalar operations per staged entry).
+struct IndexPacking {
+    uint32_t key_shift;      // sort key low word = index << key_shift | code
+    uint32_t index_mask;     // list entry & index_mask = Gaussian index
+    uint32_t all_bits;       // OR-ed onto a list entry's 8 sub-block bits (0xFF when the entries carry none)
+};
+inline IndexPacking index_packing(const lsr_dims &d) {
+    return d.num_gaussians > kMaxGaussians ? IndexPacking{0u, 0xFFFFFFFFu, 0xFFu} : IndexPacking{(uint32_t)kKeyIndexShift, kListIndexMask, 0u};
+}
 // The compositing kernels run one 16-wave workgroup (4 waves per SIMD) per compute unit; the number
 // of CUs is queried per device (api.hip), so a partitioned (CPX) or binned part gets its own static
 // assignment.  wave slots = CUs x SIMDs x resident compositing waves per SIMD.

@@ -53,6 +53,7 @@ struct RenderBwdParams {
     const float4 *geo;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
     int rec_f4;
     const uint32_t *tile_start, *half_list;
+    IndexPacking ip;              // how the list entries carry the Gaussian index and the sub-block bits
     const float *final_T;
     const uint32_t *n_contrib;
     const float *g_color, *g_feat, *g_mask, *g_depth;  // dL/d outputs (any may be NULL)
@@ -261,7 +262,7 @@ k_render_bwd(RenderBwdParams p) {
         auto load_rec = [&](uint32_t w) {
             StageRec r;
             r.w = w;
-            const float4 *R = p.geo + (vG + (w & kListIndexMask)) * (size_t)p.rec_f4;
+            const float4 *R = p.geo + (vG + (w & p.ip.index_mask)) * (size_t)p.rec_f4;
             r.a = R[0]; r.b = R[1];
 #pragma unroll
             for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];
@@ -287,7 +288,7 @@ k_render_bwd(RenderBwdParams p) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) s_list[b][lane] = (uint16_t)LSR_WAVE;   // every list slot starts as the null record's slot
             const uint32_t rel = cbase + lane;  // 0-based position in the half's list
-            const uint32_t m = rel < maxlast ? (cur.w >> kListBitsShift) : 0u;
+            const uint32_t m = rel < maxlast ? (((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) : 0u;
             if (m) {
                 const float4 a = cur.a, b = cur.b;
                 const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);   // same folding as the forward
@@ -295,7 +296,7 @@ k_render_bwd(RenderBwdParams p) {
                 s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z, __uint_as_float(rel + 1u));
 #pragma unroll
                 for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[lane][2 + c4] = cur.pay[c4];
-                s_gid[lane] = cur.w & kListIndexMask;
+                s_gid[lane] = cur.w & p.ip.index_mask;
             }
             const uint64_t staged = __ballot(m != 0);
             // compaction: per sub-block, the staged entries that can reach it, in list order.  An entry
@@ -465,6 +466,7 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     p.geo = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
     p.tile_start = (const uint32_t *)(geom + L.tile_start);
     p.half_list = (const uint32_t *)(bin + B.half_list);
+    p.ip = index_packing(d);
     p.final_T = (const float *)(img + I.final_T); p.n_contrib = (const uint32_t *)(img + I.n_contrib);
     p.g_color = gout.color; p.g_feat = gout.feature; p.g_mask = gout.mask; p.g_depth = gout.depth;
     p.f_color = fwd.color; p.f_feat = fwd.feature; p.f_depth = fwd.depth;

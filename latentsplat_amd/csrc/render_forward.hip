@@ -80,6 +80,7 @@ struct RenderFwdParams {
     const float4 *rec;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
     int rec_f4;
     const uint32_t *tile_start, *half_count, *half_list;
+    IndexPacking ip;              // how the list entries carry the Gaussian index and the sub-block bits
     float *out_color, *out_feat, *out_mask, *out_depth;
     float *final_T;
     uint32_t *n_contrib;
@@ -200,7 +201,7 @@ k_render_fwd(RenderFwdParams p) {
         auto load_rec = [&](uint32_t w) {
             StageRec r;
             r.w = w;
-            const float4 *R = p.rec + (vG + (w & kListIndexMask)) * (size_t)p.rec_f4;
+            const float4 *R = p.rec + (vG + (w & p.ip.index_mask)) * (size_t)p.rec_f4;
             r.a = R[0]; r.b = R[1];  // (x,y,A,B) (C,o,z,-)
 #pragma unroll
             for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];  // payload, zero padded
@@ -229,7 +230,7 @@ k_render_fwd(RenderFwdParams p) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) s_list[b][lane] = null_off;
             const uint32_t e = base + lane;
-            const uint32_t m = e < hn ? (cur.w >> kListBitsShift) : 0u;   // sub-blocks of this half the entry can reach (never 0 for a list entry)
+            const uint32_t m = e < hn ? (((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) : 0u;   // sub-blocks of this half the entry can reach (never 0 for a list entry)
             if (m) {
                 const float4 a = cur.a, b = cur.b;
                 const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
@@ -369,6 +370,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.tile_start = (const uint32_t *)(geom + L.tile_start);
     p.half_count = (const uint32_t *)(geom + L.half_count);
     p.half_list = (const uint32_t *)(bin + B.half_list);
+    p.ip = index_packing(d);
     p.out_color = out.color; p.out_feat = out.feature; p.out_mask = out.mask; p.out_depth = out.depth;
     p.final_T = (float *)(img + I.final_T); p.n_contrib = (uint32_t *)(img + I.n_contrib);
     const int nch = (p.has_color ? 3 : 0) + d.feat_channels;

@@ -606,3 +606,43 @@ def test_odd_gaussian_count_unaligned_sh_slices(hip_device):
                                     features=None, opacities=o, cov3D_precomp=c[0])[0]
     o0 = util.oracle_forward(bi, 0)
     util.assert_close_except_fragile(img.cpu().numpy(), o0["color"], o0, 1e-4, "colour (unaligned shs view)")
+
+
+def test_more_than_2_to_24_gaussians_run_without_footprint_culling(hip_device):
+    """Scenes beyond 2^24 Gaussians (round 3 returned LSR_EUNSUPPORTED: the sort key packs `index << 8 | sub-block code`)
+    keep the full 32-bit index in keys and list entries and give up the footprint culling instead — every entry of a
+    tile's list goes to both half lists and is evaluated on every sub-block: the published algorithm's work.  16 780 216
+    Gaussians, the visible ones at the END of the array (indices above 2^24), everything in front of them behind the
+    camera: radii, pair count, the sorted canonical lists bit for bit, images and gradients against the oracle."""
+    from latentsplat_amd.synthetic import Scene
+    G_vis, pad, size = 6000, (1 << 24) - 3000, 64
+    sc = util.make_scene(G_vis, image_size=size, views=1, color_sh_degree=None, feature_channels=4, seed=21)
+    behind = torch.zeros(pad, 3); behind[:, 2] = -5.0                    # view z < 0.2: culled
+    big = Scene(torch.cat([behind, sc.means]), torch.cat([torch.eye(3).expand(pad, 3, 3) * 1e-4, sc.covariances]),
+                torch.cat([torch.full((pad,), 0.5), sc.opacities]), None,
+                torch.cat([torch.zeros(pad, 4, 1), sc.feature_sh]), sc.extrinsics, sc.intrinsics, sc.near, sc.far)
+    assert big.means.shape[0] > (1 << 24)
+    bi = util.boundary_inputs(big, size, size)
+    run = util.HipRun(bi, hip_device, shared_means=True)
+    o = util.oracle_forward(bi, 0)
+    np.testing.assert_array_equal(run.radii[0].cpu().numpy(), o["radii"])
+    assert run.P == o["P"] and (o["radii"][pad:] > 0).sum() > 1000 and (o["radii"][:pad] > 0).sum() == 0
+    ts, pl = run.tile_start(), run.point_list()
+    np.testing.assert_array_equal(np.diff(ts), o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0])
+    np.testing.assert_array_equal(pl[:o["P"]], o["point_list"])
+    assert int(pl[:o["P"]].min()) >= pad                                  # every listed index needs more than 24 bits
+    util.assert_close_except_fragile(run.feat_out[0].cpu().numpy(), o["feature"], o, 1e-4, "feature (> 2^24 Gaussians)")
+    util.assert_close_except_fragile(run.mask_out[0].cpu().numpy(), o["mask"], o, 1e-4, "mask (> 2^24 Gaussians)")
+    # and the backward through the autograd op
+    from latentsplat_amd.rasterizer import rasterize_views
+    dev = hip_device
+    leaf = lambda t: t.to(dev).clone().requires_grad_(True)
+    means, cov6, opac, feats = leaf(bi["means"][0]), leaf(bi["cov6"][0]), leaf(bi["opac"]), leaf(bi["features"][0])
+    color, feat, mask, depth, radii = rasterize_views(util.view_table(bi, dev), size, size, 0, means, cov6, opac, features=feats)
+    gf = torch.randn(feat.shape, generator=torch.Generator().manual_seed(2))
+    (feat * gf.to(dev)).sum().backward()
+    b = util.oracle_backward(bi, 0, o, None, gf[0].numpy())
+    direct, behind_px = util.fragile_gaussians(o, size)
+    util.assert_grad_close_except_fragile(feats.grad.cpu().numpy(), b["features"], direct, behind_px, 1e-4, "dL/dfeatures (> 2^24 Gaussians)", clean_tol=2e-5)
+    util.assert_grad_close_except_fragile(opac.grad.cpu().numpy(), b["opacities"][:, None], direct, behind_px, 1e-4, "dL/dopacities (> 2^24 Gaussians)", clean_tol=2e-5)
+    assert float(means.grad[:pad].abs().max()) == 0.0
