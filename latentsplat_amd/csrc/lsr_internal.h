@@ -5,6 +5,12 @@
 
 #include "lsr_rasterizer.h"
 
+// gfx950 (MI355X) only, by construction: wave64 lane maps, DPP row operations, the packed-f32 inline asm without the
+// compiler's wait states (tools/microbench/pk_hazard.hip measured the forwarding on this part only) and the LDS sizing all
+// assume it.  A device pass for any other target is a build error, not a slower fallback.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "liblsr_hip is written for gfx950 (MI355X / CDNA4) only: build with --offload-arch=gfx950"
+#endif
 #define LSR_WAVE 64
 #define LSR_NEAR_CULL 0.2f
 #define LSR_LOWPASS 0.3f
