@@ -351,6 +351,204 @@ k_render_fwd(RenderFwdParams p) {
     }  // persistent item loop
 }
 
+// ---- small view batches (round 4): one wave = one ROW of four sub-blocks (16 x 4 pixels), one pixel per lane ----
+// A launch over few views cannot fill the wave slots: 512 half tiles of a single 256 x 256 view on 6144 slots leave every
+// wave alone on its SIMD, walking a ~900-entry list with every dependent latency exposed (V = 1: 0.078 ms, V = 4: 0.088 ms
+// for 1/16 and 1/4 of the 16-view launch's work).  Here each half tile is rendered by TWO waves — rows 0-3 and rows 4-7 of
+// the half — each walking the same half-tile list but compacting only its own four sub-block lists (16-lane groups, one
+// pixel per lane): twice the waves, fewer iterations per batch (the longest of four lists instead of eight) and a
+// shorter, unpacked loop body.  Per evaluation it costs ~1.5x the instructions of the two-pixel kernel, which is why the
+// launcher uses it only when the two-pixel launch would leave wave slots empty.
+// The arithmetic per pixel is the two-pixel kernel's, operation for operation (a packed f32 operation is two IEEE
+// operations): images, final_T and n_contrib are bitwise identical, and so are the keep / skip decisions the backward
+// (which recomputes them with lsr_blend.h's sequence) relies on.
+template <int NCHP, int WPB>
+__global__ void __launch_bounds__(LSR_WAVE * WPB)
+k_render_fwd_rows(RenderFwdParams p) {
+    constexpr int kEnt = (2 + NCHP / 4) | 1;
+    struct Lds {
+        float4 ent[WPB][LSR_WAVE + 1][kEnt];
+        uint32_t list[WPB][4][LSR_WAVE + 1];
+    };
+    __shared__ Lds s_lds;
+    const int lane = threadIdx.x & (LSR_WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / LSR_WAVE);
+    float4 (*s_ent)[kEnt] = s_lds.ent[wid];
+    uint32_t (*s_list)[LSR_WAVE + 1] = s_lds.list[wid];
+    const char *ent_base = (const char *)&s_lds.ent[0][0][0];
+    const uint32_t wave_off = (uint32_t)(wid * (LSR_WAVE + 1) * kEnt * 16);
+    const uint32_t my_off = wave_off + (uint32_t)(lane * kEnt * 16);
+    const uint32_t null_off = wave_off + (uint32_t)(LSR_WAVE * kEnt * 16);
+    if (lane < 4) s_list[lane][LSR_WAVE] = null_off;
+    if (lane == 0) {
+        s_ent[LSR_WAVE][0] = make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
+        s_ent[LSR_WAVE][1] = make_float4(0.0f, 0.0f, 0.0f, -kInv255);
+#pragma unroll
+        for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    const uint32_t num_items = 2u * p.num_items;          // two row items per half-tile item
+    const int coff = p.has_color ? 3 : 0;
+    const size_t HW = (size_t)p.H * p.W;
+    const int gcol = lane >> 4, lx = lane & 3, ly = (lane >> 2) & 3;   // 16-lane group -> sub-block column; lane -> pixel of the sub-block
+
+    const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = (uint32_t)p.num_cus * (uint32_t)p.waves_per_cu;
+    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);
+    const uint32_t bin = (blockIdx.x % (uint32_t)p.num_cus) * 4u + (vwave & 3u);
+    const uint32_t j0 = vwave >> 2;
+    bool first = true;
+    for (;;) {
+        uint32_t qi;
+        if (first) {
+            qi = (j0 & 1u) ? (j0 + 1u) * simd_bins - 1u - bin : j0 * simd_bins + bin;
+            first = false;
+            if (qi >= num_items) continue;
+        } else {
+            if (num_items <= slots) break;
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(p.queue, 1u);
+            qi = slots + __builtin_amdgcn_readfirstlane(t);
+            if (qi >= num_items) break;
+        }
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        const uint32_t item = p.items[qi >> 1];
+        const int grow = (int)(qi & 1u);                  // sub-block row of the half this wave renders
+        const uint32_t vt = item & kItemTileMask, half = item >> kItemHalfShift;
+        const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
+        const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)half + 4 * grow;
+        const size_t vG = (size_t)v * p.G;
+        const uint32_t tstart = p.tile_start[vt], tn = p.tile_start[vt + 1] - tstart;
+        const uint32_t hn = p.half_count[2 * (size_t)vt + half];
+        const uint32_t *hlist = p.half_list + 2 * (size_t)tstart + (size_t)half * tn;
+
+        const int px = tx0 + 4 * gcol + lx, py = ty0 + ly;
+        const bool inside = px < p.W && py < p.H;
+        float pxx = inside ? (float)px : __builtin_nanf("");   // a finished (or outside) pixel gets x = NaN: never kept again
+        const float pyf = (float)py;
+        float T = 1.0f, D = 0.0f;
+        float acc[NCHP];
+#pragma unroll
+        for (int c = 0; c < NCHP; ++c) acc[c] = 0.0f;
+        uint32_t stop_pos = 0;
+        float kmax = kAlphaMax255;
+        asm volatile("" : "+v"(kmax));
+        uint64_t done = __ballot(!inside);
+
+        struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t w; };
+        const uint32_t last = hn - 1u;
+        auto load_ent = [&](uint32_t e) -> uint32_t { return hlist[min(e, last)]; };
+        auto load_rec = [&](uint32_t w) {
+            StageRec r;
+            r.w = w;
+            const float4 *R = p.rec + (vG + (w & p.ip.index_mask)) * (size_t)p.rec_f4;
+            r.a = R[0]; r.b = R[1];
+#pragma unroll
+            for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];
+            return r;
+        };
+        uint32_t w_ahead = 0;
+        StageRec nxt;
+        nxt.w = 0;
+        nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int c4 = 0; c4 < NCHP / 4; ++c4) nxt.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (hn > 0) {
+            w_ahead = load_ent(lane);
+            nxt = load_rec(w_ahead);
+            w_ahead = load_ent(LSR_WAVE + lane);
+        }
+        for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
+            if (done == ~0ull) break;
+            const StageRec cur = nxt;
+            nxt = load_rec(w_ahead);
+            w_ahead = load_ent(base + 2 * LSR_WAVE + lane);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s_list[b][lane] = null_off;
+            const uint32_t e = base + lane;
+            // the four sub-blocks of THIS row the entry can reach (bits 4 grow .. 4 grow + 3 of its half mask)
+            const uint32_t m = e < hn ? (((((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) >> (4 * grow)) & 0xFu) : 0u;
+            if (m) {
+                const float4 a = cur.a, b = cur.b;
+                const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
+                s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
+                s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z * kInv255, -kInv255);
+#pragma unroll
+                for (int c4 = 0; c4 < NCHP / 4; ++c4)
+                    s_ent[lane][2 + c4] = make_float4(cur.pay[c4].x * kInv255, cur.pay[c4].y * kInv255, cur.pay[c4].z * kInv255, cur.pay[c4].w * kInv255);
+            }
+            uint32_t nk = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint64_t bal = __ballot((m >> b) & 1u);
+                nk = max(nk, (uint32_t)__builtin_popcountll(bal));
+                if (__builtin_amdgcn_inverse_ballot_w64(bal)) {
+                    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    s_list[b][at] = my_off;
+                }
+            }
+            nk = __builtin_amdgcn_readfirstlane(nk);
+            wave_lds_fence();
+            const uint32_t *lp = &s_list[gcol][0];
+            for (uint32_t i = 0; i < nk; ++i) {
+                const uint32_t off = lp[i];
+                const float4 *E = (const float4 *)(ent_base + off);
+                const float4 a = E[0], b = E[1];
+                float pay[NCHP];
+#pragma unroll
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) {
+                    const float4 t = E[2 + c4];
+                    pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
+                }
+                // e' = dx (a2 dx + b2 dy) + (c2 dy^2 + l2o'): the two-pixel kernel's sequence for one pixel
+                const float d = a.x - pxx;
+                const float dy = a.y - pyf;
+                const float t = b.x * dy;
+                const float s = __builtin_fmaf(a.w * dy, dy, b.y);
+                const float p1 = __builtin_fmaf(a.z, d, t);
+                const float ex = __builtin_fmaf(p1, d, s);
+                const float al = fminf(kmax, fast_exp2(ex));                       // 255 alpha
+                const uint32_t lim = __float_as_uint(b.y);
+                const uint64_t ok = __ballot(__float_as_uint(ex) <= lim);
+                const float aT = al * T;                                          // 255 alpha T
+                const float tT = __builtin_fmaf(aT, b.w, T);                      // T (1 - alpha)   (b.w = -1 / 255)
+                const uint64_t room = __ballot(tT >= LSR_T_EPS);
+                const uint64_t stop = ok & ~room;
+                const float w = __builtin_amdgcn_inverse_ballot_w64(ok & room) ? aT : 0.0f;
+#pragma unroll
+                for (int c = 0; c < NCHP; ++c) acc[c] = __builtin_fmaf(pay[c], w, acc[c]);
+                D = __builtin_fmaf(b.z, w, D);                                    // depth += (z / 255) w'
+                T = __builtin_fmaf(b.w, w, T);                                    // T     -= w' / 255
+                if (stop) {
+                    const uint32_t pos = base + 1u + (off - wave_off) / (uint32_t)(kEnt * 16);
+                    const bool st = __builtin_amdgcn_inverse_ballot_w64(stop);
+                    stop_pos = st ? pos : stop_pos;
+                    pxx = st ? __builtin_nanf("") : pxx;
+                    done |= stop;
+                }
+            }
+            wave_lds_fence();
+        }
+        typedef const float __attribute__((address_space(4))) *kfloat_ptr;
+        const kfloat_ptr vw = (kfloat_ptr)(p.views + (size_t)v * LSR_VIEW_FLOATS);
+        if (inside) {
+            const size_t pix = (size_t)py * p.W + (size_t)px;
+            const size_t vp = (size_t)v * HW + pix;
+            p.final_T[vp] = T;
+            p.n_contrib[vp] = stop_pos ? stop_pos - 1u : hn;
+            p.out_mask[vp] = 1.0f - T;
+            p.out_depth[vp] = D;
+            if (p.has_color) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(T, vw[37 + c], acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < NCHP; ++c)
+                if (c >= coff && c - coff < p.C)
+                    p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[c];
+        }
+    }
+}
+
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                  const char *bin, int64_t num_pairs, char *img, const lsr_outputs &out,
                                  hipStream_t s) {
@@ -393,6 +591,17 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
         p.waves_per_cu = (WPC);                                                                            \
         hipLaunchKernelGGL((k_render_fwd<N, WPB>), dim3(p.num_cus * ((WPC) / (WPB))), dim3(LSR_WAVE * WPB), 0, s, p); \
     } while (0)
+    // Row items for small view batches (k_render_fwd_rows): when two waves per half tile still fit the wave slots the
+    // two-pixel launch would leave empty.  LSR_FWD_ROWS = 0 / 1 forces the choice.
+    const int rows_knob = env_int("LSR_FWD_ROWS", -1);
+    const bool rows = (nchp == 4 || nchp == 8) && (rows_knob >= 0 ? rows_knob != 0 : 2ull * p.num_items <= (uint64_t)p.num_cus * 24u);
+    if (rows) {
+        p.waves_per_cu = 24;
+        if (nchp == 4) hipLaunchKernelGGL((k_render_fwd_rows<4, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+        else hipLaunchKernelGGL((k_render_fwd_rows<8, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+        prof_end(kStRenderFwd, s);
+        return hipGetLastError();
+    }
     const int variant = env_int("LSR_FWD_VARIANT", 0);
     if (nchp == 4) { if (variant == 2) LSR_RF(4, 16, 16); else if (variant == 3) LSR_RF(4, 14, 28); else LSR_RF(4, 12, 24); }   // 2 x 12 waves per CU: 0.245 vs 0.281 ms per 16 views with 16
     // 7 / 8 channels (colour + 4 latent channels: the reference's configs[3] / [4] payload; 7.3 KB of LDS and 90 VGPRs per
