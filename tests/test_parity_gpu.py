@@ -50,7 +50,11 @@ def _check_forward(bi, run, views=None):
             util.assert_close_except_fragile(run.feat_out[v].cpu().numpy(), o["feature"], o, ABS_TOL, "feature")
         util.assert_close_except_fragile(run.mask_out[v].cpu().numpy(), o["mask"], o, ABS_TOL, "mask")
         dscale = max(1.0, float(np.abs(o["depth"]).max()))
-        util.assert_close_except_fragile(run.depth_out[v].cpu().numpy(), o["depth"], o, ABS_TOL * dscale, "depth")
+        # (a flipped alpha >= 1/255 decision moves the depth image by alpha * T * z of THAT Gaussian: the flip bound is in
+        # units of the deepest visible Gaussian, not of the blended image — tests/fuzz_parity.py found the difference in a
+        # low-opacity scene)
+        zmax = float(o["gdepth"][vis].max(initial=1.0))
+        util.assert_close_except_fragile(run.depth_out[v].cpu().numpy(), o["depth"], o, ABS_TOL * dscale, "depth", flip_bound=2e-2 * max(dscale, zmax))
         # the per-pixel list prefix kept for the backward pass may differ only where exp rounding
         # flips a decision: every mismatching pixel must be one the oracle flagged as fragile
         mism = np.flatnonzero(ncontrib[v].reshape(-1) != o["n_considered"].astype(np.int64).reshape(-1))
