@@ -549,6 +549,234 @@ k_render_fwd_rows(RenderFwdParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// One view per call (the reference's own call pattern, cuda_splatting.py:124-162): 512 half tiles on 6144 wave slots, and
+// the launch lasts as long as the longest list takes ONE wave.  Here a wave renders one 4x4 SUB-BLOCK (eight waves per half
+// tile) and its four 16-lane rows evaluate FOUR consecutive entries of the sub-block's list at once: the exponent, exp2 and
+// the payload multiply-adds — most of an entry's instructions — run in parallel, and only the transmittance recurrence
+// T' = fma(-1/255, keep ? 255 alpha T : 0, T) stays serial: every row receives the four 255-alpha values of its pixel
+// (v_permlane32_swap / v_permlane16_swap, gfx950) and runs the four steps redundantly, so T, the keep / stop decisions,
+// final_T and n_contrib are bit for bit those of the other two kernels.  The accumulators are per-row partial sums added
+// across the rows once per item: colour / feature / depth differ from the serial kernels in the order of that sum (~1e-7).
+template <int NCHP, int WPB>
+__global__ void __launch_bounds__(LSR_WAVE * WPB)
+k_render_fwd_quad(RenderFwdParams p) {
+    constexpr int kEnt = (2 + NCHP / 4) | 1;
+    constexpr int kListLen = LSR_WAVE + 4;                 // a batch's list, padded with null entries to a multiple of four
+    struct Lds {
+        float4 ent[WPB][LSR_WAVE + 1][kEnt];
+        uint32_t list[WPB][kListLen];
+    };
+    __shared__ Lds s_lds;
+    const int lane = threadIdx.x & (LSR_WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / LSR_WAVE);
+    float4 (*s_ent)[kEnt] = s_lds.ent[wid];
+    uint32_t *s_list = s_lds.list[wid];
+    const char *ent_base = (const char *)&s_lds.ent[0][0][0];
+    const uint32_t wave_off = (uint32_t)(wid * (LSR_WAVE + 1) * kEnt * 16);
+    const uint32_t my_off = wave_off + (uint32_t)(lane * kEnt * 16);
+    const uint32_t null_off = wave_off + (uint32_t)(LSR_WAVE * kEnt * 16);
+    if (lane < 4) s_list[LSR_WAVE + lane] = null_off;
+    if (lane == 0) {
+        s_ent[LSR_WAVE][0] = make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
+        s_ent[LSR_WAVE][1] = make_float4(0.0f, 0.0f, 0.0f, -kInv255);
+#pragma unroll
+        for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    const uint32_t num_items = 8u * p.num_items;          // eight sub-block items per half-tile item
+    const int coff = p.has_color ? 3 : 0;
+    const size_t HW = (size_t)p.H * p.W;
+    const int slot = lane >> 4, lx = lane & 3, ly = (lane >> 2) & 3;   // 16-lane row -> entry slot of a step; lane -> pixel of the sub-block
+    const uint32_t *my_list = s_list + slot;
+
+    // value of x in this lane's pixel of row 0, 1, 2, 3 — in every row
+    auto rows_of = [](float x, float &x0, float &x1, float &x2, float &x3) {
+        const uint32_t u = __float_as_uint(x);
+        const auto h = __builtin_amdgcn_permlane32_swap(u, u, false, false);    // h[0] = rows (0, 1, 0, 1), h[1] = rows (2, 3, 2, 3)
+        const auto lo = __builtin_amdgcn_permlane16_swap(h[0], h[0], false, false);   // lo[0] = row 0 everywhere, lo[1] = row 1 everywhere
+        const auto hi = __builtin_amdgcn_permlane16_swap(h[1], h[1], false, false);
+        x0 = __uint_as_float(lo[0]); x1 = __uint_as_float(lo[1]); x2 = __uint_as_float(hi[0]); x3 = __uint_as_float(hi[1]);
+    };
+    // (row 0 + row 1) + (row 2 + row 3) of this lane's pixel, in every row
+    auto rows_sum = [](float x) -> float {
+        const uint32_t u = __float_as_uint(x);
+        const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);    // a[0] = rows (0, 0, 2, 2), a[1] = rows (1, 1, 3, 3)
+        const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+        const uint32_t v = __float_as_uint(y);
+        const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);    // b[0] = lower half everywhere, b[1] = upper half
+        return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    };
+
+    const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = (uint32_t)p.num_cus * (uint32_t)p.waves_per_cu;
+    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);
+    const uint32_t bin = (blockIdx.x % (uint32_t)p.num_cus) * 4u + (vwave & 3u);
+    const uint32_t j0 = vwave >> 2;
+    bool first = true;
+    for (;;) {
+        uint32_t qi;
+        if (first) {
+            qi = (j0 & 1u) ? (j0 + 1u) * simd_bins - 1u - bin : j0 * simd_bins + bin;
+            first = false;
+            if (qi >= num_items) continue;
+        } else {
+            if (num_items <= slots) break;
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(p.queue, 1u);
+            qi = slots + __builtin_amdgcn_readfirstlane(t);
+            if (qi >= num_items) break;
+        }
+        qi = __builtin_amdgcn_readfirstlane(qi);
+        const uint32_t item = p.items[qi >> 3];
+        const int sub = (int)(qi & 7u);                   // sub-block of the half this wave renders: bit `sub` of the entries' masks
+        const uint32_t vt = item & kItemTileMask, half = item >> kItemHalfShift;
+        const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
+        const int tx0 = (tile % p.gx) * LSR_TILE + 4 * (sub & 3), ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)half + 4 * (sub >> 2);
+        const size_t vG = (size_t)v * p.G;
+        const uint32_t tstart = p.tile_start[vt], tn = p.tile_start[vt + 1] - tstart;
+        const uint32_t hn = p.half_count[2 * (size_t)vt + half];
+        const uint32_t *hlist = p.half_list + 2 * (size_t)tstart + (size_t)half * tn;
+
+        const int px = tx0 + lx, py = ty0 + ly;
+        const bool inside = px < p.W && py < p.H;
+        float pxx = inside ? (float)px : __builtin_nanf("");   // a finished (or outside) pixel gets x = NaN: never kept again
+        const float pyf = (float)py;
+        float T = 1.0f, D = 0.0f;                              // T: the pixel's transmittance, the same in all four rows; D, acc: this row's partial sums
+        float acc[NCHP];
+#pragma unroll
+        for (int c = 0; c < NCHP; ++c) acc[c] = 0.0f;
+        uint32_t stop_pos = 0;
+        float kmax = kAlphaMax255;
+        asm volatile("" : "+v"(kmax));
+        uint64_t done = __ballot(!inside);
+
+        struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t w; };
+        const uint32_t last = hn - 1u;
+        auto load_ent = [&](uint32_t e) -> uint32_t { return hlist[min(e, last)]; };
+        auto load_rec = [&](uint32_t w) {
+            StageRec r;
+            r.w = w;
+            const float4 *R = p.rec + (vG + (w & p.ip.index_mask)) * (size_t)p.rec_f4;
+            r.a = R[0]; r.b = R[1];
+#pragma unroll
+            for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];
+            return r;
+        };
+        uint32_t w_ahead = 0;
+        StageRec nxt;
+        nxt.w = 0;
+        nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int c4 = 0; c4 < NCHP / 4; ++c4) nxt.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (hn > 0) {
+            w_ahead = load_ent(lane);
+            nxt = load_rec(w_ahead);
+            w_ahead = load_ent(LSR_WAVE + lane);
+        }
+        for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
+            if (done == ~0ull) break;
+            const StageRec cur = nxt;
+            nxt = load_rec(w_ahead);
+            w_ahead = load_ent(base + 2 * LSR_WAVE + lane);
+            s_list[lane] = null_off;
+            const uint32_t e = base + lane;
+            const bool m = e < hn && (((((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) >> sub) & 1u);
+            if (m) {
+                const float4 a = cur.a, b = cur.b;
+                const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
+                s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
+                s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z * kInv255, -kInv255);
+#pragma unroll
+                for (int c4 = 0; c4 < NCHP / 4; ++c4)
+                    s_ent[lane][2 + c4] = make_float4(cur.pay[c4].x * kInv255, cur.pay[c4].y * kInv255, cur.pay[c4].z * kInv255, cur.pay[c4].w * kInv255);
+            }
+            const uint64_t bal = __ballot(m);
+            const uint32_t nk = (uint32_t)__builtin_popcountll(bal);
+            if (m) {
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                s_list[at] = my_off;
+            }
+            wave_lds_fence();
+            for (uint32_t i = 0; i < nk; i += 4) {
+                if (done == ~0ull) break;
+                const uint32_t off = my_list[i];             // row r takes entry i + r of the list (null entries beyond its end)
+                const float4 *E = (const float4 *)(ent_base + off);
+                const float4 a = E[0], b = E[1];
+                float pay[NCHP];
+#pragma unroll
+                for (int c4 = 0; c4 < NCHP / 4; ++c4) {
+                    const float4 t = E[2 + c4];
+                    pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
+                }
+                // e' = dx (a2 dx + b2 dy) + (c2 dy^2 + l2o'): the operation sequence of the other kernels
+                const float d = a.x - pxx;
+                const float dy = a.y - pyf;
+                const float t = b.x * dy;
+                const float s = __builtin_fmaf(a.w * dy, dy, b.y);
+                const float p1 = __builtin_fmaf(a.z, d, t);
+                const float ex = __builtin_fmaf(p1, d, s);
+                const float al = fminf(kmax, fast_exp2(ex));                       // 255 alpha
+                const float alz = __float_as_uint(ex) <= __float_as_uint(b.y) ? al : 0.0f;   // 0: the entry does not reach the pixel
+                float a4[4];
+                rows_of(alz, a4[0], a4[1], a4[2], a4[3]);
+                // the four steps of the recurrence, every row for its pixel.  While a pixel is alive T >= T_EPS, so a step
+                // with 255 alpha = 0 has room and changes nothing; a step without room stops the pixel for good.
+                uint64_t alive = ~done, stopped[4];
+                float w4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float aT = a4[k] * T;                                   // 255 alpha T
+                    const float tT = __builtin_fmaf(aT, -kInv255, T);             // T (1 - alpha)
+                    const uint64_t room = __ballot(tT >= LSR_T_EPS);
+                    stopped[k] = alive & ~room;
+                    w4[k] = __builtin_amdgcn_inverse_ballot_w64(alive & room) ? aT : 0.0f;
+                    T = __builtin_fmaf(-kInv255, w4[k], T);                       // T -= w' / 255
+                    alive &= room;
+                }
+                const float w = slot == 0 ? w4[0] : (slot == 1 ? w4[1] : (slot == 2 ? w4[2] : w4[3]));
+#pragma unroll
+                for (int c = 0; c < NCHP; ++c) acc[c] = __builtin_fmaf(pay[c], w, acc[c]);
+                D = __builtin_fmaf(b.z, w, D);                                    // depth += (z / 255) w'
+                const uint64_t stop = stopped[0] | stopped[1] | stopped[2] | stopped[3];
+                if (stop) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (!stopped[k]) continue;
+                        const uint32_t offk = s_list[i + k];
+                        const uint32_t pos = base + 1u + (offk - wave_off) / (uint32_t)(kEnt * 16);
+                        stop_pos = __builtin_amdgcn_inverse_ballot_w64(stopped[k]) ? pos : stop_pos;
+                    }
+                    pxx = __builtin_amdgcn_inverse_ballot_w64(stop) ? __builtin_nanf("") : pxx;
+                    done |= stop;
+                }
+            }
+            wave_lds_fence();
+        }
+        // the rows' partial sums -> the pixel's sums (the same fixed order in every row)
+        D = rows_sum(D);
+#pragma unroll
+        for (int c = 0; c < NCHP; ++c) acc[c] = rows_sum(acc[c]);
+        typedef const float __attribute__((address_space(4))) *kfloat_ptr;
+        const kfloat_ptr vw = (kfloat_ptr)(p.views + (size_t)v * LSR_VIEW_FLOATS);
+        if (inside && slot == 0) {
+            const size_t pix = (size_t)py * p.W + (size_t)px;
+            const size_t vp = (size_t)v * HW + pix;
+            p.final_T[vp] = T;
+            p.n_contrib[vp] = stop_pos ? stop_pos - 1u : hn;
+            p.out_mask[vp] = 1.0f - T;
+            p.out_depth[vp] = D;
+            if (p.has_color) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(T, vw[37 + c], acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < NCHP; ++c)
+                if (c >= coff && c - coff < p.C)
+                    p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[c];
+        }
+    }
+}
+
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                  const char *bin, int64_t num_pairs, char *img, const lsr_outputs &out,
                                  hipStream_t s) {
@@ -593,6 +821,17 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     } while (0)
     // Row items for small view batches (k_render_fwd_rows): when two waves per half tile still fit the wave slots the
     // two-pixel launch would leave empty.  LSR_FWD_ROWS = 0 / 1 forces the choice.
+    // Sub-block items for a single view (k_render_fwd_quad): eight waves per half tile while they fit the wave slots.
+    // LSR_FWD_QUAD = 0 / 1 forces the choice.
+    const int quad_knob = env_int("LSR_FWD_QUAD", -1);
+    const bool quad = (nchp == 4 || nchp == 8) && (quad_knob >= 0 ? quad_knob != 0 : 8ull * p.num_items <= (uint64_t)p.num_cus * 24u);
+    if (quad) {
+        p.waves_per_cu = 24;
+        if (nchp == 4) hipLaunchKernelGGL((k_render_fwd_quad<4, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+        else hipLaunchKernelGGL((k_render_fwd_quad<8, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+        prof_end(kStRenderFwd, s);
+        return hipGetLastError();
+    }
     const int rows_knob = env_int("LSR_FWD_ROWS", -1);
     const bool rows = (nchp == 4 || nchp == 8) && (rows_knob >= 0 ? rows_knob != 0 : 2ull * p.num_items <= (uint64_t)p.num_cus * 24u);
     if (rows) {

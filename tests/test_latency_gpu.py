@@ -191,16 +191,57 @@ with torch.no_grad():
 print("HASH", h.hexdigest())
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = {}
+    # (LSR_FWD_QUAD=0 throughout: the sub-block-item kernel this small shape would otherwise get sums its colour in a
+    # different order — test_subblock_items_forward_matches_the_serial_kernels holds it to its own contract)
     variants = {"default": {}, "scan_kernel": dict(LSR_FOLD_SCAN="0"), "event_wait": dict(LSR_HOST_POLL="0"),
                 "scan_kernel_event_wait": dict(LSR_FOLD_SCAN="0", LSR_HOST_POLL="0"),
                 "sort_natural_order": dict(LSR_SORT_LPT="0"),
                 "fwd_row_items": dict(LSR_FWD_ROWS="1"), "fwd_half_tile_items": dict(LSR_FWD_ROWS="0")}
     for name, extra in variants.items():
-        env = dict(os.environ, **extra)
+        env = dict(os.environ, LSR_FWD_QUAD="0", **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (name, r.stderr[-2000:])
         digests[name] = r.stdout.strip().splitlines()[-1]
     assert digests["default"].startswith("HASH ") and len(set(digests.values())) == 1, digests
+
+
+@pytest.mark.parametrize("case", [
+    dict(G=20_000, size=96, views=1, color_sh_degree=None, feature_channels=4),                      # 4 payload channels
+    dict(G=12_000, size=(70, 100), views=3, color_sh_degree=2, feature_channels=4),                  # 7 channels, ragged image
+    dict(G=3_000, size=64, views=2, color_sh_degree=1, feature_channels=4, sigma_px=(4.0, 30.0), opacity_scale=1.0),   # long lists, early stops
+    dict(G=300_000, size=256, views=1, color_sh_degree=None, feature_channels=4),                    # the latency workload itself
+])
+def test_subblock_items_forward_matches_the_serial_kernels(hip_device, case):
+    """k_render_fwd_quad (one wave per 4x4 sub-block, four list entries per step across the wave's 16-lane rows; chosen for
+    single-view-sized calls) runs the transmittance recurrence in exactly the serial kernels' order: mask (1 - T) and the
+    per-pixel list prefix the backward walks must be BITWISE those of the half-tile kernel; colour, features and depth are
+    per-row partial sums added once per item and may differ in the last bits only."""
+    from latentsplat_amd import _lib
+    case = dict(case)
+    size = case.pop("size")
+    H, W = (size, size) if isinstance(size, int) else size
+    sc = util.make_scene(case.pop("G"), image_size=max(H, W), **case)
+    bi = util.boundary_inputs(sc, H, W, bg=(0.2, 0.4, 0.6))
+    runs = {}
+    try:
+        for name, quad, rows in (("half_tile", 0, 0), ("rows", 0, 1), ("quad", 1, 0)):
+            _lib.set_knob("LSR_FWD_QUAD", quad)
+            _lib.set_knob("LSR_FWD_ROWS", rows)
+            r = util.HipRun(bi, hip_device)
+            runs[name] = dict(mask=r.mask_out.clone(), n=torch.as_tensor(r.n_contrib().astype("int64")), T=torch.as_tensor(r.final_T()), depth=r.depth_out.clone(),
+                              color=None if r.color_out is None else r.color_out.clone(), feat=None if r.feat_out is None else r.feat_out.clone())
+    finally:
+        _lib.set_knob("LSR_FWD_QUAD", -1)
+        _lib.set_knob("LSR_FWD_ROWS", -1)
+    a, q = runs["half_tile"], runs["quad"]
+    assert torch.equal(a["mask"], runs["rows"]["mask"]) and torch.equal(a["depth"], runs["rows"]["depth"])
+    assert torch.equal(a["mask"], q["mask"]), "mask = 1 - T must be bitwise identical"
+    assert torch.equal(a["n"], q["n"]) and torch.equal(a["T"], q["T"]), "the per-pixel list prefix and final T (what the backward reads) must be identical"
+    for k in ("depth", "color", "feat"):
+        if a[k] is None:
+            continue
+        scale = max(1.0, float(a[k].abs().max()))
+        assert float((a[k] - q[k]).abs().max()) <= 2e-6 * scale, k
 
 
 def test_early_pair_count_equals_the_device_header(hip_device):
