@@ -718,36 +718,50 @@ k_render_fwd_quad(RenderFwdParams p) {
                 const float alz = __float_as_uint(ex) <= __float_as_uint(b.y) ? al : 0.0f;   // 0: the entry does not reach the pixel
                 float a4[4];
                 rows_of(alz, a4[0], a4[1], a4[2], a4[3]);
-                // the four steps of the recurrence, every row for its pixel.  While a pixel is alive T >= T_EPS, so a step
-                // with 255 alpha = 0 has room and changes nothing; a step without room stops the pixel for good.
-                uint64_t alive = ~done, stopped[4];
+                // The four steps of the recurrence, every row for its pixel.  A pixel that is alive has T >= T_EPS (so does a
+                // finished one: its T is the value before the entry that stopped it, and its 255 alpha is 0 from then on), so
+                // a step with 255 alpha = 0 has room and changes nothing.  Fast path: nobody runs out of room in these four
+                // steps — no bookkeeping beyond one mask AND per step.
+                const float T0 = T;
+                uint64_t allroom = ~0ull;
                 float w4[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float aT = a4[k] * T;                                   // 255 alpha T
                     const float tT = __builtin_fmaf(aT, -kInv255, T);             // T (1 - alpha)
                     const uint64_t room = __ballot(tT >= LSR_T_EPS);
-                    stopped[k] = alive & ~room;
-                    w4[k] = __builtin_amdgcn_inverse_ballot_w64(alive & room) ? aT : 0.0f;
+                    allroom &= room;
+                    w4[k] = __builtin_amdgcn_inverse_ballot_w64(room) ? aT : 0.0f;
                     T = __builtin_fmaf(-kInv255, w4[k], T);                       // T -= w' / 255
-                    alive &= room;
+                }
+                if (allroom != ~0ull) {
+                    // some pixel stops inside this group of four (at most once per pixel and item): redo the steps from T0,
+                    // a stopped pixel keeping its T and contributing nothing afterwards
+                    T = T0;
+                    uint64_t alive = ~done, stop = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float aT = a4[k] * T;
+                        const float tT = __builtin_fmaf(aT, -kInv255, T);
+                        const uint64_t room = __ballot(tT >= LSR_T_EPS);
+                        const uint64_t stopped = alive & ~room;
+                        w4[k] = __builtin_amdgcn_inverse_ballot_w64(alive & room) ? aT : 0.0f;
+                        T = __builtin_fmaf(-kInv255, w4[k], T);
+                        alive &= room;
+                        if (stopped) {
+                            const uint32_t offk = s_list[i + k];
+                            const uint32_t pos = base + 1u + (offk - wave_off) / (uint32_t)(kEnt * 16);
+                            stop_pos = __builtin_amdgcn_inverse_ballot_w64(stopped) ? pos : stop_pos;
+                            stop |= stopped;
+                        }
+                    }
+                    pxx = __builtin_amdgcn_inverse_ballot_w64(stop) ? __builtin_nanf("") : pxx;
+                    done |= stop;
                 }
                 const float w = slot == 0 ? w4[0] : (slot == 1 ? w4[1] : (slot == 2 ? w4[2] : w4[3]));
 #pragma unroll
                 for (int c = 0; c < NCHP; ++c) acc[c] = __builtin_fmaf(pay[c], w, acc[c]);
                 D = __builtin_fmaf(b.z, w, D);                                    // depth += (z / 255) w'
-                const uint64_t stop = stopped[0] | stopped[1] | stopped[2] | stopped[3];
-                if (stop) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (!stopped[k]) continue;
-                        const uint32_t offk = s_list[i + k];
-                        const uint32_t pos = base + 1u + (offk - wave_off) / (uint32_t)(kEnt * 16);
-                        stop_pos = __builtin_amdgcn_inverse_ballot_w64(stopped[k]) ? pos : stop_pos;
-                    }
-                    pxx = __builtin_amdgcn_inverse_ballot_w64(stop) ? __builtin_nanf("") : pxx;
-                    done |= stop;
-                }
             }
             wave_lds_fence();
         }
