@@ -24,6 +24,8 @@
 // per item and derived the masks per staged entry (39 evaluations; a quarter of the staged pairs reached
 // no pixel).
 // Per-pixel blend / skip / stop decisions are scalar lane-mask algebra, one mask set per pixel of the lane.
+// Launches that cannot fill the wave slots get finer items: k_render_fwd_rows (two waves per half tile, one pixel per
+// lane: a few views) and k_render_fwd_quad (a wave per sub-block, four list entries per step: one view).
 #include <stdio.h>
 
 #include <vector>
