@@ -24,8 +24,9 @@
 // per item and derived the masks per staged entry (39 evaluations; a quarter of the staged pairs reached
 // no pixel).
 // Per-pixel blend / skip / stop decisions are scalar lane-mask algebra, one mask set per pixel of the lane.
-// Launches that cannot fill the wave slots get finer items: k_render_fwd_rows (two waves per half tile, one pixel per
-// lane: a few views) and k_render_fwd_quad (a wave per sub-block, four list entries per step: one view).
+// Launches that cannot fill the wave slots get finer items (k_render_fwd_small): ROW items (two waves per half tile, one
+// pixel per lane) and, for the longest lists while wave slots are left, SUB-BLOCK items (a wave per sub-block, four list
+// entries per step).
 #include <stdio.h>
 
 #include <vector>
@@ -76,6 +77,7 @@ struct RenderFwdParams {
     int waves_per_cu;             // resident compositing waves per CU the launch provides
     const uint32_t *items;        // work items, costliest first
     uint32_t num_items;           // items of this launch (2 per (view, tile))
+    uint32_t quad_items;          // k_render_fwd_small: leading (costliest) items rendered as sub-block items
     uint32_t *queue;              // work-queue head (zeroed per forward)
     unsigned long long *trace;    // debug builds (LSR_ENABLE_TRACE): per item {start clk, end clk, hw id, iterations << 32 | entries}
     const float *views;
@@ -364,194 +366,167 @@ k_render_fwd(RenderFwdParams p) {
 // The arithmetic per pixel is the two-pixel kernel's, operation for operation (a packed f32 operation is two IEEE
 // operations): images, final_T and n_contrib are bitwise identical, and so are the keep / skip decisions the backward
 // (which recomputes them with lsr_blend.h's sequence) relies on.
-template <int NCHP, int WPB>
-__global__ void __launch_bounds__(LSR_WAVE * WPB)
-k_render_fwd_rows(RenderFwdParams p) {
-    constexpr int kEnt = (2 + NCHP / 4) | 1;
-    struct Lds {
-        float4 ent[WPB][LSR_WAVE + 1][kEnt];
-        uint32_t list[WPB][4][LSR_WAVE + 1];
-    };
-    __shared__ Lds s_lds;
-    const int lane = threadIdx.x & (LSR_WAVE - 1);
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / LSR_WAVE);
-    float4 (*s_ent)[kEnt] = s_lds.ent[wid];
-    uint32_t (*s_list)[LSR_WAVE + 1] = s_lds.list[wid];
-    const char *ent_base = (const char *)&s_lds.ent[0][0][0];
-    const uint32_t wave_off = (uint32_t)(wid * (LSR_WAVE + 1) * kEnt * 16);
-    const uint32_t my_off = wave_off + (uint32_t)(lane * kEnt * 16);
-    const uint32_t null_off = wave_off + (uint32_t)(LSR_WAVE * kEnt * 16);
-    if (lane < 4) s_list[lane][LSR_WAVE] = null_off;
-    if (lane == 0) {
-        s_ent[LSR_WAVE][0] = make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
-        s_ent[LSR_WAVE][1] = make_float4(0.0f, 0.0f, 0.0f, -kInv255);
-#pragma unroll
-        for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    const uint32_t num_items = 2u * p.num_items;          // two row items per half-tile item
-    const int coff = p.has_color ? 3 : 0;
-    const size_t HW = (size_t)p.H * p.W;
+// ---- small view batches: finer work items for launches that cannot fill the wave slots ----
+// Per-wave LDS slice of k_render_fwd_small and what both item kinds need of it.
+template <int NCHP>
+struct SmallWave {
+    static constexpr int kEnt = (2 + NCHP / 4) | 1;
+    float4 (*s_ent)[kEnt];        // [64 staged entries + the null entry][kEnt]
+    uint32_t *s_flat;             // 4 x 65 list words: row items use them as [4][65], sub-block items the first 68
+    const char *ent_base;
+    uint32_t wave_off, my_off, null_off;
+    int lane, coff;
+    size_t HW;
+};
+
+// ROW item: one wave = one row of four sub-blocks (16 x 4 pixels) of a half tile; 16-lane groups, one pixel per lane, the
+// two-pixel kernel's arithmetic per pixel (bitwise identical outputs).
+template <int NCHP>
+__device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const SmallWave<NCHP> &w_, uint32_t item, int grow) {
+    constexpr int kEnt = SmallWave<NCHP>::kEnt;
+    const int lane = w_.lane, coff = w_.coff;
+    const size_t HW = w_.HW;
+    float4 (*s_ent)[kEnt] = w_.s_ent;
+    uint32_t (*s_list)[LSR_WAVE + 1] = (uint32_t (*)[LSR_WAVE + 1])w_.s_flat;
+    const char *ent_base = w_.ent_base;
+    const uint32_t wave_off = w_.wave_off, my_off = w_.my_off, null_off = w_.null_off;
     const int gcol = lane >> 4, lx = lane & 3, ly = (lane >> 2) & 3;   // 16-lane group -> sub-block column; lane -> pixel of the sub-block
+    const uint32_t vt = item & kItemTileMask, half = item >> kItemHalfShift;
+    const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
+    const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)half + 4 * grow;
+    const size_t vG = (size_t)v * p.G;
+    const uint32_t tstart = p.tile_start[vt], tn = p.tile_start[vt + 1] - tstart;
+    const uint32_t hn = p.half_count[2 * (size_t)vt + half];
+    const uint32_t *hlist = p.half_list + 2 * (size_t)tstart + (size_t)half * tn;
 
-    const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = (uint32_t)p.num_cus * (uint32_t)p.waves_per_cu;
-    const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);
-    const uint32_t bin = (blockIdx.x % (uint32_t)p.num_cus) * 4u + (vwave & 3u);
-    const uint32_t j0 = vwave >> 2;
-    bool first = true;
-    for (;;) {
-        uint32_t qi;
-        if (first) {
-            qi = (j0 & 1u) ? (j0 + 1u) * simd_bins - 1u - bin : j0 * simd_bins + bin;
-            first = false;
-            if (qi >= num_items) continue;
-        } else {
-            if (num_items <= slots) break;
-            uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(p.queue, 1u);
-            qi = slots + __builtin_amdgcn_readfirstlane(t);
-            if (qi >= num_items) break;
-        }
-        qi = __builtin_amdgcn_readfirstlane(qi);
-        const uint32_t item = p.items[qi >> 1];
-        const int grow = (int)(qi & 1u);                  // sub-block row of the half this wave renders
-        const uint32_t vt = item & kItemTileMask, half = item >> kItemHalfShift;
-        const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
-        const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)half + 4 * grow;
-        const size_t vG = (size_t)v * p.G;
-        const uint32_t tstart = p.tile_start[vt], tn = p.tile_start[vt + 1] - tstart;
-        const uint32_t hn = p.half_count[2 * (size_t)vt + half];
-        const uint32_t *hlist = p.half_list + 2 * (size_t)tstart + (size_t)half * tn;
+    const int px = tx0 + 4 * gcol + lx, py = ty0 + ly;
+    const bool inside = px < p.W && py < p.H;
+    float pxx = inside ? (float)px : __builtin_nanf("");   // a finished (or outside) pixel gets x = NaN: never kept again
+    const float pyf = (float)py;
+    float T = 1.0f, D = 0.0f;
+    float acc[NCHP];
+#pragma unroll
+    for (int c = 0; c < NCHP; ++c) acc[c] = 0.0f;
+    uint32_t stop_pos = 0;
+    float kmax = kAlphaMax255;
+    asm volatile("" : "+v"(kmax));
+    uint64_t done = __ballot(!inside);
 
-        const int px = tx0 + 4 * gcol + lx, py = ty0 + ly;
-        const bool inside = px < p.W && py < p.H;
-        float pxx = inside ? (float)px : __builtin_nanf("");   // a finished (or outside) pixel gets x = NaN: never kept again
-        const float pyf = (float)py;
-        float T = 1.0f, D = 0.0f;
-        float acc[NCHP];
+    struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t w; };
+    const uint32_t last = hn - 1u;
+    auto load_ent = [&](uint32_t e) -> uint32_t { return hlist[min(e, last)]; };
+    auto load_rec = [&](uint32_t w) {
+        StageRec r;
+        r.w = w;
+        const float4 *R = p.rec + (vG + (w & p.ip.index_mask)) * (size_t)p.rec_f4;
+        r.a = R[0]; r.b = R[1];
 #pragma unroll
-        for (int c = 0; c < NCHP; ++c) acc[c] = 0.0f;
-        uint32_t stop_pos = 0;
-        float kmax = kAlphaMax255;
-        asm volatile("" : "+v"(kmax));
-        uint64_t done = __ballot(!inside);
-
-        struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t w; };
-        const uint32_t last = hn - 1u;
-        auto load_ent = [&](uint32_t e) -> uint32_t { return hlist[min(e, last)]; };
-        auto load_rec = [&](uint32_t w) {
-            StageRec r;
-            r.w = w;
-            const float4 *R = p.rec + (vG + (w & p.ip.index_mask)) * (size_t)p.rec_f4;
-            r.a = R[0]; r.b = R[1];
+        for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];
+        return r;
+    };
+    uint32_t w_ahead = 0;
+    StageRec nxt;
+    nxt.w = 0;
+    nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-            for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];
-            return r;
-        };
-        uint32_t w_ahead = 0;
-        StageRec nxt;
-        nxt.w = 0;
-        nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int c4 = 0; c4 < NCHP / 4; ++c4) nxt.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (hn > 0) {
+        w_ahead = load_ent(lane);
+        nxt = load_rec(w_ahead);
+        w_ahead = load_ent(LSR_WAVE + lane);
+    }
+    for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
+        if (done == ~0ull) break;
+        const StageRec cur = nxt;
+        nxt = load_rec(w_ahead);
+        w_ahead = load_ent(base + 2 * LSR_WAVE + lane);
 #pragma unroll
-        for (int c4 = 0; c4 < NCHP / 4; ++c4) nxt.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (hn > 0) {
-            w_ahead = load_ent(lane);
-            nxt = load_rec(w_ahead);
-            w_ahead = load_ent(LSR_WAVE + lane);
+        for (int b = 0; b < 4; ++b) s_list[b][lane] = null_off;
+        const uint32_t e = base + lane;
+        // the four sub-blocks of THIS row the entry can reach (bits 4 grow .. 4 grow + 3 of its half mask)
+        const uint32_t m = e < hn ? (((((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) >> (4 * grow)) & 0xFu) : 0u;
+        if (m) {
+            const float4 a = cur.a, b = cur.b;
+            const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
+            s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
+            s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z * kInv255, -kInv255);
+#pragma unroll
+            for (int c4 = 0; c4 < NCHP / 4; ++c4)
+                s_ent[lane][2 + c4] = make_float4(cur.pay[c4].x * kInv255, cur.pay[c4].y * kInv255, cur.pay[c4].z * kInv255, cur.pay[c4].w * kInv255);
         }
-        for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
-            if (done == ~0ull) break;
-            const StageRec cur = nxt;
-            nxt = load_rec(w_ahead);
-            w_ahead = load_ent(base + 2 * LSR_WAVE + lane);
+        uint32_t nk = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) s_list[b][lane] = null_off;
-            const uint32_t e = base + lane;
-            // the four sub-blocks of THIS row the entry can reach (bits 4 grow .. 4 grow + 3 of its half mask)
-            const uint32_t m = e < hn ? (((((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) >> (4 * grow)) & 0xFu) : 0u;
-            if (m) {
-                const float4 a = cur.a, b = cur.b;
-                const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
-                s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
-                s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z * kInv255, -kInv255);
-#pragma unroll
-                for (int c4 = 0; c4 < NCHP / 4; ++c4)
-                    s_ent[lane][2 + c4] = make_float4(cur.pay[c4].x * kInv255, cur.pay[c4].y * kInv255, cur.pay[c4].z * kInv255, cur.pay[c4].w * kInv255);
+        for (int b = 0; b < 4; ++b) {
+            const uint64_t bal = __ballot((m >> b) & 1u);
+            nk = max(nk, (uint32_t)__builtin_popcountll(bal));
+            if (__builtin_amdgcn_inverse_ballot_w64(bal)) {
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                s_list[b][at] = my_off;
             }
-            uint32_t nk = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint64_t bal = __ballot((m >> b) & 1u);
-                nk = max(nk, (uint32_t)__builtin_popcountll(bal));
-                if (__builtin_amdgcn_inverse_ballot_w64(bal)) {
-                    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    s_list[b][at] = my_off;
-                }
-            }
-            nk = __builtin_amdgcn_readfirstlane(nk);
-            wave_lds_fence();
-            const uint32_t *lp = &s_list[gcol][0];
-            for (uint32_t i = 0; i < nk; ++i) {
-                const uint32_t off = lp[i];
-                const float4 *E = (const float4 *)(ent_base + off);
-                const float4 a = E[0], b = E[1];
-                float pay[NCHP];
-#pragma unroll
-                for (int c4 = 0; c4 < NCHP / 4; ++c4) {
-                    const float4 t = E[2 + c4];
-                    pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
-                }
-                // e' = dx (a2 dx + b2 dy) + (c2 dy^2 + l2o'): the two-pixel kernel's sequence for one pixel
-                const float d = a.x - pxx;
-                const float dy = a.y - pyf;
-                const float t = b.x * dy;
-                const float s = __builtin_fmaf(a.w * dy, dy, b.y);
-                const float p1 = __builtin_fmaf(a.z, d, t);
-                const float ex = __builtin_fmaf(p1, d, s);
-                const float al = fminf(kmax, fast_exp2(ex));                       // 255 alpha
-                const uint32_t lim = __float_as_uint(b.y);
-                const uint64_t ok = __ballot(__float_as_uint(ex) <= lim);
-                const float aT = al * T;                                          // 255 alpha T
-                const float tT = __builtin_fmaf(aT, b.w, T);                      // T (1 - alpha)   (b.w = -1 / 255)
-                const uint64_t room = __ballot(tT >= LSR_T_EPS);
-                const uint64_t stop = ok & ~room;
-                const float w = __builtin_amdgcn_inverse_ballot_w64(ok & room) ? aT : 0.0f;
-#pragma unroll
-                for (int c = 0; c < NCHP; ++c) acc[c] = __builtin_fmaf(pay[c], w, acc[c]);
-                D = __builtin_fmaf(b.z, w, D);                                    // depth += (z / 255) w'
-                T = __builtin_fmaf(b.w, w, T);                                    // T     -= w' / 255
-                if (stop) {
-                    const uint32_t pos = base + 1u + (off - wave_off) / (uint32_t)(kEnt * 16);
-                    const bool st = __builtin_amdgcn_inverse_ballot_w64(stop);
-                    stop_pos = st ? pos : stop_pos;
-                    pxx = st ? __builtin_nanf("") : pxx;
-                    done |= stop;
-                }
-            }
-            wave_lds_fence();
         }
-        typedef const float __attribute__((address_space(4))) *kfloat_ptr;
-        const kfloat_ptr vw = (kfloat_ptr)(p.views + (size_t)v * LSR_VIEW_FLOATS);
-        if (inside) {
-            const size_t pix = (size_t)py * p.W + (size_t)px;
-            const size_t vp = (size_t)v * HW + pix;
-            p.final_T[vp] = T;
-            p.n_contrib[vp] = stop_pos ? stop_pos - 1u : hn;
-            p.out_mask[vp] = 1.0f - T;
-            p.out_depth[vp] = D;
-            if (p.has_color) {
+        nk = __builtin_amdgcn_readfirstlane(nk);
+        wave_lds_fence();
+        const uint32_t *lp = &s_list[gcol][0];
+        for (uint32_t i = 0; i < nk; ++i) {
+            const uint32_t off = lp[i];
+            const float4 *E = (const float4 *)(ent_base + off);
+            const float4 a = E[0], b = E[1];
+            float pay[NCHP];
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(T, vw[37 + c], acc[c]);
+            for (int c4 = 0; c4 < NCHP / 4; ++c4) {
+                const float4 t = E[2 + c4];
+                pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
             }
+            // e' = dx (a2 dx + b2 dy) + (c2 dy^2 + l2o'): the two-pixel kernel's sequence for one pixel
+            const float d = a.x - pxx;
+            const float dy = a.y - pyf;
+            const float t = b.x * dy;
+            const float s = __builtin_fmaf(a.w * dy, dy, b.y);
+            const float p1 = __builtin_fmaf(a.z, d, t);
+            const float ex = __builtin_fmaf(p1, d, s);
+            const float al = fminf(kmax, fast_exp2(ex));                       // 255 alpha
+            const uint32_t lim = __float_as_uint(b.y);
+            const uint64_t ok = __ballot(__float_as_uint(ex) <= lim);
+            const float aT = al * T;                                          // 255 alpha T
+            const float tT = __builtin_fmaf(aT, b.w, T);                      // T (1 - alpha)   (b.w = -1 / 255)
+            const uint64_t room = __ballot(tT >= LSR_T_EPS);
+            const uint64_t stop = ok & ~room;
+            const float w = __builtin_amdgcn_inverse_ballot_w64(ok & room) ? aT : 0.0f;
 #pragma unroll
-            for (int c = 0; c < NCHP; ++c)
-                if (c >= coff && c - coff < p.C)
-                    p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[c];
+            for (int c = 0; c < NCHP; ++c) acc[c] = __builtin_fmaf(pay[c], w, acc[c]);
+            D = __builtin_fmaf(b.z, w, D);                                    // depth += (z / 255) w'
+            T = __builtin_fmaf(b.w, w, T);                                    // T     -= w' / 255
+            if (stop) {
+                const uint32_t pos = base + 1u + (off - wave_off) / (uint32_t)(kEnt * 16);
+                const bool st = __builtin_amdgcn_inverse_ballot_w64(stop);
+                stop_pos = st ? pos : stop_pos;
+                pxx = st ? __builtin_nanf("") : pxx;
+                done |= stop;
+            }
         }
+        wave_lds_fence();
+    }
+    typedef const float __attribute__((address_space(4))) *kfloat_ptr;
+    const kfloat_ptr vw = (kfloat_ptr)(p.views + (size_t)v * LSR_VIEW_FLOATS);
+    if (inside) {
+        const size_t pix = (size_t)py * p.W + (size_t)px;
+        const size_t vp = (size_t)v * HW + pix;
+        p.final_T[vp] = T;
+        p.n_contrib[vp] = stop_pos ? stop_pos - 1u : hn;
+        p.out_mask[vp] = 1.0f - T;
+        p.out_depth[vp] = D;
+        if (p.has_color) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(T, vw[37 + c], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NCHP; ++c)
+            if (c >= coff && c - coff < p.C)
+                p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[c];
     }
 }
 
-// ------------------------------------------------------------------------------------------
 // One view per call (the reference's own call pattern, cuda_splatting.py:124-162): 512 half tiles on 6144 wave slots, and
 // the launch lasts as long as the longest list takes ONE wave.  Here a wave renders one 4x4 SUB-BLOCK (eight waves per half
 // tile) and its four 16-lane rows evaluate FOUR consecutive entries of the sub-block's list at once: the exponent, exp2 and
@@ -560,37 +535,17 @@ k_render_fwd_rows(RenderFwdParams p) {
 // (v_permlane32_swap / v_permlane16_swap, gfx950) and runs the four steps redundantly, so T, the keep / stop decisions,
 // final_T and n_contrib are bit for bit those of the other two kernels.  The accumulators are per-row partial sums added
 // across the rows once per item: colour / feature / depth differ from the serial kernels in the order of that sum (~1e-7).
-template <int NCHP, int WPB>
-__global__ void __launch_bounds__(LSR_WAVE * WPB)
-k_render_fwd_quad(RenderFwdParams p) {
-    constexpr int kEnt = (2 + NCHP / 4) | 1;
-    constexpr int kListLen = LSR_WAVE + 4;                 // a batch's list, padded with null entries to a multiple of four
-    struct Lds {
-        float4 ent[WPB][LSR_WAVE + 1][kEnt];
-        uint32_t list[WPB][kListLen];
-    };
-    __shared__ Lds s_lds;
-    const int lane = threadIdx.x & (LSR_WAVE - 1);
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / LSR_WAVE);
-    float4 (*s_ent)[kEnt] = s_lds.ent[wid];
-    uint32_t *s_list = s_lds.list[wid];
-    const char *ent_base = (const char *)&s_lds.ent[0][0][0];
-    const uint32_t wave_off = (uint32_t)(wid * (LSR_WAVE + 1) * kEnt * 16);
-    const uint32_t my_off = wave_off + (uint32_t)(lane * kEnt * 16);
-    const uint32_t null_off = wave_off + (uint32_t)(LSR_WAVE * kEnt * 16);
-    if (lane < 4) s_list[LSR_WAVE + lane] = null_off;
-    if (lane == 0) {
-        s_ent[LSR_WAVE][0] = make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
-        s_ent[LSR_WAVE][1] = make_float4(0.0f, 0.0f, 0.0f, -kInv255);
-#pragma unroll
-        for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    const uint32_t num_items = 8u * p.num_items;          // eight sub-block items per half-tile item
-    const int coff = p.has_color ? 3 : 0;
-    const size_t HW = (size_t)p.H * p.W;
+template <int NCHP>
+__device__ __forceinline__ void render_subblock_item(const RenderFwdParams &p, const SmallWave<NCHP> &w_, uint32_t item, int sub) {
+    constexpr int kEnt = SmallWave<NCHP>::kEnt;
+    const int lane = w_.lane, coff = w_.coff;
+    const size_t HW = w_.HW;
+    float4 (*s_ent)[kEnt] = w_.s_ent;
+    uint32_t *s_list = w_.s_flat;
+    const char *ent_base = w_.ent_base;
+    const uint32_t wave_off = w_.wave_off, my_off = w_.my_off, null_off = w_.null_off;
     const int slot = lane >> 4, lx = lane & 3, ly = (lane >> 2) & 3;   // 16-lane row -> entry slot of a step; lane -> pixel of the sub-block
     const uint32_t *my_list = s_list + slot;
-
     // value of x in this lane's pixel of row 0, 1, 2, 3 — in every row
     auto rows_of = [](float x, float &x0, float &x1, float &x2, float &x3) {
         const uint32_t u = __float_as_uint(x);
@@ -609,6 +564,202 @@ k_render_fwd_quad(RenderFwdParams p) {
         return __uint_as_float(b[0]) + __uint_as_float(b[1]);
     };
 
+    const uint32_t vt = item & kItemTileMask, half = item >> kItemHalfShift;
+    const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
+    const int tx0 = (tile % p.gx) * LSR_TILE + 4 * (sub & 3), ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)half + 4 * (sub >> 2);
+    const size_t vG = (size_t)v * p.G;
+    const uint32_t tstart = p.tile_start[vt], tn = p.tile_start[vt + 1] - tstart;
+    const uint32_t hn = p.half_count[2 * (size_t)vt + half];
+    const uint32_t *hlist = p.half_list + 2 * (size_t)tstart + (size_t)half * tn;
+
+    const int px = tx0 + lx, py = ty0 + ly;
+    const bool inside = px < p.W && py < p.H;
+    float pxx = inside ? (float)px : __builtin_nanf("");   // a finished (or outside) pixel gets x = NaN: never kept again
+    const float pyf = (float)py;
+    float T = 1.0f, D = 0.0f;                              // T: the pixel's transmittance, the same in all four rows; D, acc: this row's partial sums
+    float acc[NCHP];
+#pragma unroll
+    for (int c = 0; c < NCHP; ++c) acc[c] = 0.0f;
+    uint32_t stop_pos = 0;
+    float kmax = kAlphaMax255;
+    asm volatile("" : "+v"(kmax));
+    uint64_t done = __ballot(!inside);
+
+    struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t w; };
+    const uint32_t last = hn - 1u;
+    auto load_ent = [&](uint32_t e) -> uint32_t { return hlist[min(e, last)]; };
+    auto load_rec = [&](uint32_t w) {
+        StageRec r;
+        r.w = w;
+        const float4 *R = p.rec + (vG + (w & p.ip.index_mask)) * (size_t)p.rec_f4;
+        r.a = R[0]; r.b = R[1];
+#pragma unroll
+        for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];
+        return r;
+    };
+    uint32_t w_ahead = 0;
+    StageRec nxt;
+    nxt.w = 0;
+    nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int c4 = 0; c4 < NCHP / 4; ++c4) nxt.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (hn > 0) {
+        w_ahead = load_ent(lane);
+        nxt = load_rec(w_ahead);
+        w_ahead = load_ent(LSR_WAVE + lane);
+    }
+    for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
+        if (done == ~0ull) break;
+        const StageRec cur = nxt;
+        nxt = load_rec(w_ahead);
+        w_ahead = load_ent(base + 2 * LSR_WAVE + lane);
+        s_list[lane] = null_off;
+        if (lane < 4) s_list[LSR_WAVE + lane] = null_off;       // the padding of the last group of four (row items use these words)
+        const uint32_t e = base + lane;
+        const bool m = e < hn && (((((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) >> sub) & 1u);
+        if (m) {
+            const float4 a = cur.a, b = cur.b;
+            const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
+            s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
+            s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z * kInv255, -kInv255);
+#pragma unroll
+            for (int c4 = 0; c4 < NCHP / 4; ++c4)
+                s_ent[lane][2 + c4] = make_float4(cur.pay[c4].x * kInv255, cur.pay[c4].y * kInv255, cur.pay[c4].z * kInv255, cur.pay[c4].w * kInv255);
+        }
+        const uint64_t bal = __ballot(m);
+        const uint32_t nk = (uint32_t)__builtin_popcountll(bal);
+        if (m) {
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            s_list[at] = my_off;
+        }
+        wave_lds_fence();
+        for (uint32_t i = 0; i < nk; i += 4) {
+            if (done == ~0ull) break;
+            const uint32_t off = my_list[i];             // row r takes entry i + r of the list (null entries beyond its end)
+            const float4 *E = (const float4 *)(ent_base + off);
+            const float4 a = E[0], b = E[1];
+            float pay[NCHP];
+#pragma unroll
+            for (int c4 = 0; c4 < NCHP / 4; ++c4) {
+                const float4 t = E[2 + c4];
+                pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
+            }
+            // e' = dx (a2 dx + b2 dy) + (c2 dy^2 + l2o'): the operation sequence of the other kernels
+            const float d = a.x - pxx;
+            const float dy = a.y - pyf;
+            const float t = b.x * dy;
+            const float s = __builtin_fmaf(a.w * dy, dy, b.y);
+            const float p1 = __builtin_fmaf(a.z, d, t);
+            const float ex = __builtin_fmaf(p1, d, s);
+            const float al = fminf(kmax, fast_exp2(ex));                       // 255 alpha
+            const float alz = __float_as_uint(ex) <= __float_as_uint(b.y) ? al : 0.0f;   // 0: the entry does not reach the pixel
+            float a4[4];
+            rows_of(alz, a4[0], a4[1], a4[2], a4[3]);
+            // The four steps of the recurrence, every row for its pixel.  A pixel that is alive has T >= T_EPS (so does a
+            // finished one: its T is the value before the entry that stopped it, and its 255 alpha is 0 from then on), so
+            // a step with 255 alpha = 0 has room and changes nothing.  Fast path: nobody runs out of room in these four
+            // steps — no bookkeeping beyond one mask AND per step.
+            const float T0 = T;
+            uint64_t allroom = ~0ull;
+            float w4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float aT = a4[k] * T;                                   // 255 alpha T
+                const float tT = __builtin_fmaf(aT, -kInv255, T);             // T (1 - alpha)
+                const uint64_t room = __ballot(tT >= LSR_T_EPS);
+                allroom &= room;
+                w4[k] = __builtin_amdgcn_inverse_ballot_w64(room) ? aT : 0.0f;
+                T = __builtin_fmaf(-kInv255, w4[k], T);                       // T -= w' / 255
+            }
+            if (allroom != ~0ull) {
+                // some pixel stops inside this group of four (at most once per pixel and item): redo the steps from T0,
+                // a stopped pixel keeping its T and contributing nothing afterwards
+                T = T0;
+                uint64_t alive = ~done, stop = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float aT = a4[k] * T;
+                    const float tT = __builtin_fmaf(aT, -kInv255, T);
+                    const uint64_t room = __ballot(tT >= LSR_T_EPS);
+                    const uint64_t stopped = alive & ~room;
+                    w4[k] = __builtin_amdgcn_inverse_ballot_w64(alive & room) ? aT : 0.0f;
+                    T = __builtin_fmaf(-kInv255, w4[k], T);
+                    alive &= room;
+                    if (stopped) {
+                        const uint32_t offk = s_list[i + k];
+                        const uint32_t pos = base + 1u + (offk - wave_off) / (uint32_t)(kEnt * 16);
+                        stop_pos = __builtin_amdgcn_inverse_ballot_w64(stopped) ? pos : stop_pos;
+                        stop |= stopped;
+                    }
+                }
+                pxx = __builtin_amdgcn_inverse_ballot_w64(stop) ? __builtin_nanf("") : pxx;
+                done |= stop;
+            }
+            const float w = slot == 0 ? w4[0] : (slot == 1 ? w4[1] : (slot == 2 ? w4[2] : w4[3]));
+#pragma unroll
+            for (int c = 0; c < NCHP; ++c) acc[c] = __builtin_fmaf(pay[c], w, acc[c]);
+            D = __builtin_fmaf(b.z, w, D);                                    // depth += (z / 255) w'
+        }
+        wave_lds_fence();
+    }
+    // the rows' partial sums -> the pixel's sums (the same fixed order in every row)
+    D = rows_sum(D);
+#pragma unroll
+    for (int c = 0; c < NCHP; ++c) acc[c] = rows_sum(acc[c]);
+    typedef const float __attribute__((address_space(4))) *kfloat_ptr;
+    const kfloat_ptr vw = (kfloat_ptr)(p.views + (size_t)v * LSR_VIEW_FLOATS);
+    if (inside && slot == 0) {
+        const size_t pix = (size_t)py * p.W + (size_t)px;
+        const size_t vp = (size_t)v * HW + pix;
+        p.final_T[vp] = T;
+        p.n_contrib[vp] = stop_pos ? stop_pos - 1u : hn;
+        p.out_mask[vp] = 1.0f - T;
+        p.out_depth[vp] = D;
+        if (p.has_color) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(T, vw[37 + c], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NCHP; ++c)
+            if (c >= coff && c - coff < p.C)
+                p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[c];
+    }
+}
+
+// The launch for small view batches: the p.quad_items costliest half-tile items are rendered as eight SUB-BLOCK items
+// each, the others as two ROW items each.  The launcher asks for all or none (see there); the mix is an experiment knob.
+template <int NCHP, int WPB>
+__global__ void __launch_bounds__(LSR_WAVE * WPB)
+k_render_fwd_small(RenderFwdParams p) {
+    constexpr int kEnt = SmallWave<NCHP>::kEnt;
+    struct Lds {
+        float4 ent[WPB][LSR_WAVE + 1][kEnt];
+        uint32_t list[WPB][4 * (LSR_WAVE + 1)];
+    };
+    __shared__ Lds s_lds;
+    SmallWave<NCHP> w;
+    w.lane = threadIdx.x & (LSR_WAVE - 1);
+    const int lane = w.lane;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / LSR_WAVE);
+    w.s_ent = s_lds.ent[wid];
+    w.s_flat = s_lds.list[wid];
+    w.ent_base = (const char *)&s_lds.ent[0][0][0];
+    w.wave_off = (uint32_t)(wid * (LSR_WAVE + 1) * kEnt * 16);
+    w.my_off = w.wave_off + (uint32_t)(lane * kEnt * 16);
+    w.null_off = w.wave_off + (uint32_t)(LSR_WAVE * kEnt * 16);
+    w.coff = p.has_color ? 3 : 0;
+    w.HW = (size_t)p.H * p.W;
+    if (lane < 4) w.s_flat[lane * (LSR_WAVE + 1) + LSR_WAVE] = w.null_off;     // the row items' four list terminators
+    if (lane == 0) {
+        w.s_ent[LSR_WAVE][0] = make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
+        w.s_ent[LSR_WAVE][1] = make_float4(0.0f, 0.0f, 0.0f, -kInv255);
+#pragma unroll
+        for (int c4 = 0; c4 < NCHP / 4; ++c4) w.s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    const uint32_t quad_end = 8u * p.quad_items;
+    const uint32_t num_items = quad_end + 2u * (p.num_items - p.quad_items);
+
     const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = (uint32_t)p.num_cus * (uint32_t)p.waves_per_cu;
     const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);
     const uint32_t bin = (blockIdx.x % (uint32_t)p.num_cus) * 4u + (vwave & 3u);
@@ -628,167 +779,11 @@ k_render_fwd_quad(RenderFwdParams p) {
             if (qi >= num_items) break;
         }
         qi = __builtin_amdgcn_readfirstlane(qi);
-        const uint32_t item = p.items[qi >> 3];
-        const int sub = (int)(qi & 7u);                   // sub-block of the half this wave renders: bit `sub` of the entries' masks
-        const uint32_t vt = item & kItemTileMask, half = item >> kItemHalfShift;
-        const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
-        const int tx0 = (tile % p.gx) * LSR_TILE + 4 * (sub & 3), ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)half + 4 * (sub >> 2);
-        const size_t vG = (size_t)v * p.G;
-        const uint32_t tstart = p.tile_start[vt], tn = p.tile_start[vt + 1] - tstart;
-        const uint32_t hn = p.half_count[2 * (size_t)vt + half];
-        const uint32_t *hlist = p.half_list + 2 * (size_t)tstart + (size_t)half * tn;
-
-        const int px = tx0 + lx, py = ty0 + ly;
-        const bool inside = px < p.W && py < p.H;
-        float pxx = inside ? (float)px : __builtin_nanf("");   // a finished (or outside) pixel gets x = NaN: never kept again
-        const float pyf = (float)py;
-        float T = 1.0f, D = 0.0f;                              // T: the pixel's transmittance, the same in all four rows; D, acc: this row's partial sums
-        float acc[NCHP];
-#pragma unroll
-        for (int c = 0; c < NCHP; ++c) acc[c] = 0.0f;
-        uint32_t stop_pos = 0;
-        float kmax = kAlphaMax255;
-        asm volatile("" : "+v"(kmax));
-        uint64_t done = __ballot(!inside);
-
-        struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t w; };
-        const uint32_t last = hn - 1u;
-        auto load_ent = [&](uint32_t e) -> uint32_t { return hlist[min(e, last)]; };
-        auto load_rec = [&](uint32_t w) {
-            StageRec r;
-            r.w = w;
-            const float4 *R = p.rec + (vG + (w & p.ip.index_mask)) * (size_t)p.rec_f4;
-            r.a = R[0]; r.b = R[1];
-#pragma unroll
-            for (int c4 = 0; c4 < NCHP / 4; ++c4) r.pay[c4] = R[2 + c4];
-            return r;
-        };
-        uint32_t w_ahead = 0;
-        StageRec nxt;
-        nxt.w = 0;
-        nxt.a = nxt.b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-        for (int c4 = 0; c4 < NCHP / 4; ++c4) nxt.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (hn > 0) {
-            w_ahead = load_ent(lane);
-            nxt = load_rec(w_ahead);
-            w_ahead = load_ent(LSR_WAVE + lane);
-        }
-        for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
-            if (done == ~0ull) break;
-            const StageRec cur = nxt;
-            nxt = load_rec(w_ahead);
-            w_ahead = load_ent(base + 2 * LSR_WAVE + lane);
-            s_list[lane] = null_off;
-            const uint32_t e = base + lane;
-            const bool m = e < hn && (((((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) >> sub) & 1u);
-            if (m) {
-                const float4 a = cur.a, b = cur.b;
-                const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
-                s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
-                s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z * kInv255, -kInv255);
-#pragma unroll
-                for (int c4 = 0; c4 < NCHP / 4; ++c4)
-                    s_ent[lane][2 + c4] = make_float4(cur.pay[c4].x * kInv255, cur.pay[c4].y * kInv255, cur.pay[c4].z * kInv255, cur.pay[c4].w * kInv255);
-            }
-            const uint64_t bal = __ballot(m);
-            const uint32_t nk = (uint32_t)__builtin_popcountll(bal);
-            if (m) {
-                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                s_list[at] = my_off;
-            }
-            wave_lds_fence();
-            for (uint32_t i = 0; i < nk; i += 4) {
-                if (done == ~0ull) break;
-                const uint32_t off = my_list[i];             // row r takes entry i + r of the list (null entries beyond its end)
-                const float4 *E = (const float4 *)(ent_base + off);
-                const float4 a = E[0], b = E[1];
-                float pay[NCHP];
-#pragma unroll
-                for (int c4 = 0; c4 < NCHP / 4; ++c4) {
-                    const float4 t = E[2 + c4];
-                    pay[4 * c4] = t.x; pay[4 * c4 + 1] = t.y; pay[4 * c4 + 2] = t.z; pay[4 * c4 + 3] = t.w;
-                }
-                // e' = dx (a2 dx + b2 dy) + (c2 dy^2 + l2o'): the operation sequence of the other kernels
-                const float d = a.x - pxx;
-                const float dy = a.y - pyf;
-                const float t = b.x * dy;
-                const float s = __builtin_fmaf(a.w * dy, dy, b.y);
-                const float p1 = __builtin_fmaf(a.z, d, t);
-                const float ex = __builtin_fmaf(p1, d, s);
-                const float al = fminf(kmax, fast_exp2(ex));                       // 255 alpha
-                const float alz = __float_as_uint(ex) <= __float_as_uint(b.y) ? al : 0.0f;   // 0: the entry does not reach the pixel
-                float a4[4];
-                rows_of(alz, a4[0], a4[1], a4[2], a4[3]);
-                // The four steps of the recurrence, every row for its pixel.  A pixel that is alive has T >= T_EPS (so does a
-                // finished one: its T is the value before the entry that stopped it, and its 255 alpha is 0 from then on), so
-                // a step with 255 alpha = 0 has room and changes nothing.  Fast path: nobody runs out of room in these four
-                // steps — no bookkeeping beyond one mask AND per step.
-                const float T0 = T;
-                uint64_t allroom = ~0ull;
-                float w4[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float aT = a4[k] * T;                                   // 255 alpha T
-                    const float tT = __builtin_fmaf(aT, -kInv255, T);             // T (1 - alpha)
-                    const uint64_t room = __ballot(tT >= LSR_T_EPS);
-                    allroom &= room;
-                    w4[k] = __builtin_amdgcn_inverse_ballot_w64(room) ? aT : 0.0f;
-                    T = __builtin_fmaf(-kInv255, w4[k], T);                       // T -= w' / 255
-                }
-                if (allroom != ~0ull) {
-                    // some pixel stops inside this group of four (at most once per pixel and item): redo the steps from T0,
-                    // a stopped pixel keeping its T and contributing nothing afterwards
-                    T = T0;
-                    uint64_t alive = ~done, stop = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float aT = a4[k] * T;
-                        const float tT = __builtin_fmaf(aT, -kInv255, T);
-                        const uint64_t room = __ballot(tT >= LSR_T_EPS);
-                        const uint64_t stopped = alive & ~room;
-                        w4[k] = __builtin_amdgcn_inverse_ballot_w64(alive & room) ? aT : 0.0f;
-                        T = __builtin_fmaf(-kInv255, w4[k], T);
-                        alive &= room;
-                        if (stopped) {
-                            const uint32_t offk = s_list[i + k];
-                            const uint32_t pos = base + 1u + (offk - wave_off) / (uint32_t)(kEnt * 16);
-                            stop_pos = __builtin_amdgcn_inverse_ballot_w64(stopped) ? pos : stop_pos;
-                            stop |= stopped;
-                        }
-                    }
-                    pxx = __builtin_amdgcn_inverse_ballot_w64(stop) ? __builtin_nanf("") : pxx;
-                    done |= stop;
-                }
-                const float w = slot == 0 ? w4[0] : (slot == 1 ? w4[1] : (slot == 2 ? w4[2] : w4[3]));
-#pragma unroll
-                for (int c = 0; c < NCHP; ++c) acc[c] = __builtin_fmaf(pay[c], w, acc[c]);
-                D = __builtin_fmaf(b.z, w, D);                                    // depth += (z / 255) w'
-            }
-            wave_lds_fence();
-        }
-        // the rows' partial sums -> the pixel's sums (the same fixed order in every row)
-        D = rows_sum(D);
-#pragma unroll
-        for (int c = 0; c < NCHP; ++c) acc[c] = rows_sum(acc[c]);
-        typedef const float __attribute__((address_space(4))) *kfloat_ptr;
-        const kfloat_ptr vw = (kfloat_ptr)(p.views + (size_t)v * LSR_VIEW_FLOATS);
-        if (inside && slot == 0) {
-            const size_t pix = (size_t)py * p.W + (size_t)px;
-            const size_t vp = (size_t)v * HW + pix;
-            p.final_T[vp] = T;
-            p.n_contrib[vp] = stop_pos ? stop_pos - 1u : hn;
-            p.out_mask[vp] = 1.0f - T;
-            p.out_depth[vp] = D;
-            if (p.has_color) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    p.out_color[((size_t)v * 3 + c) * HW + pix] = __builtin_fmaf(T, vw[37 + c], acc[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < NCHP; ++c)
-                if (c >= coff && c - coff < p.C)
-                    p.out_feat[((size_t)v * p.C + (c - coff)) * HW + pix] = acc[c];
+        if (qi < quad_end) {
+            render_subblock_item<NCHP>(p, w, p.items[qi >> 3], (int)(qi & 7u));
+        } else {
+            const uint32_t r = qi - quad_end;
+            render_row_item<NCHP>(p, w, p.items[p.quad_items + (r >> 1)], (int)(r & 1u));
         }
     }
 }
@@ -819,6 +814,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));
 
     p.trace = nullptr;
+    p.quad_items = 0;
 #ifdef LSR_ENABLE_TRACE
     const int64_t max_items = 2 * (int64_t)p.T * d.num_views;
     const char *trace_path = getenv("LSR_TRACE");
@@ -835,25 +831,23 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
         p.waves_per_cu = (WPC);                                                                            \
         hipLaunchKernelGGL((k_render_fwd<N, WPB>), dim3(p.num_cus * ((WPC) / (WPB))), dim3(LSR_WAVE * WPB), 0, s, p); \
     } while (0)
-    // Row items for small view batches (k_render_fwd_rows): when two waves per half tile still fit the wave slots the
-    // two-pixel launch would leave empty.  LSR_FWD_ROWS = 0 / 1 forces the choice.
-    // Sub-block items for a single view (k_render_fwd_quad): eight waves per half tile while they fit the wave slots.
-    // LSR_FWD_QUAD = 0 / 1 forces the choice.
-    const int quad_knob = env_int("LSR_FWD_QUAD", -1);
-    const bool quad = (nchp == 4 || nchp == 8) && (quad_knob >= 0 ? quad_knob != 0 : 8ull * p.num_items <= (uint64_t)p.num_cus * 24u);
-    if (quad) {
+    // Small view batches (k_render_fwd_small): ROW items when two per half-tile item still fit the wave slots the two-pixel
+    // launch would leave empty (a few views), SUB-BLOCK items when even eight per half-tile item fit (one view).
+    // LSR_FWD_ROWS = 0 / 1 forces the choice of the kernel, LSR_FWD_QUAD = 0 / 1 no / only sub-block items.
+    const int rows_knob = env_int("LSR_FWD_ROWS", -1), quad_knob = env_int("LSR_FWD_QUAD", -1);
+    const uint64_t slots = (uint64_t)p.num_cus * 24u;
+    const bool small = (nchp == 4 || nchp == 8) && (quad_knob == 1 || (rows_knob >= 0 ? rows_knob != 0 : 2ull * p.num_items <= slots));
+    if (small) {
         p.waves_per_cu = 24;
-        if (nchp == 4) hipLaunchKernelGGL((k_render_fwd_quad<4, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
-        else hipLaunchKernelGGL((k_render_fwd_quad<8, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
-        prof_end(kStRenderFwd, s);
-        return hipGetLastError();
-    }
-    const int rows_knob = env_int("LSR_FWD_ROWS", -1);
-    const bool rows = (nchp == 4 || nchp == 8) && (rows_knob >= 0 ? rows_knob != 0 : 2ull * p.num_items <= (uint64_t)p.num_cus * 24u);
-    if (rows) {
-        p.waves_per_cu = 24;
-        if (nchp == 4) hipLaunchKernelGGL((k_render_fwd_rows<4, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
-        else hipLaunchKernelGGL((k_render_fwd_rows<8, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+        // Sub-block items for ALL items or none.  (Measured: the costliest (slots - 2 items) / 6 items as sub-block items next
+        // to row items for the rest fill every slot, and with six waves per SIMD the sub-block items — the longest lists —
+        // take twice as long as alone: V = 2 0.085 against 0.068 ms for row items only, V = 4 0.088 / 0.078, configs[3]
+        // 0.160 / 0.136.  LSR_FWD_QUAD_ITEMS = n forces n leading items for experiments.)
+        const int forced = env_int("LSR_FWD_QUAD_ITEMS", -1);
+        p.quad_items = quad_knob == 0 ? 0u : ((quad_knob == 1 || 8ull * p.num_items <= slots) ? p.num_items : 0u);
+        if (forced >= 0) p.quad_items = std::min<uint32_t>(p.num_items, (uint32_t)forced);
+        if (nchp == 4) hipLaunchKernelGGL((k_render_fwd_small<4, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+        else hipLaunchKernelGGL((k_render_fwd_small<8, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
         prof_end(kStRenderFwd, s);
         return hipGetLastError();
     }

@@ -212,7 +212,7 @@ print("HASH", h.hexdigest())
     dict(G=300_000, size=256, views=1, color_sh_degree=None, feature_channels=4),                    # the latency workload itself
 ])
 def test_subblock_items_forward_matches_the_serial_kernels(hip_device, case):
-    """k_render_fwd_quad (one wave per 4x4 sub-block, four list entries per step across the wave's 16-lane rows; chosen for
+    """The sub-block items of k_render_fwd_small (one wave per 4x4 sub-block, four list entries per step across the wave's 16-lane rows; chosen for
     single-view-sized calls) runs the transmittance recurrence in exactly the serial kernels' order: mask (1 - T) and the
     per-pixel list prefix the backward walks must be BITWISE those of the half-tile kernel; colour, features and depth are
     per-row partial sums added once per item and may differ in the last bits only."""
