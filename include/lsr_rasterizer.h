@@ -275,8 +275,9 @@ const char *lsr_profile_stage_name(int stage);
 int lsr_profile_read(double *ms_out, int64_t *launches_out);
 
 /* ---- development aid (kernel A/B experiments, tools/): overrides one of the library's LSR_* environment knobs
- * (launch-shape variants, LSR_SH_PLACEMENT, LSR_FOLD_SCAN, ...) for the rest of the process.  Knobs select between
- * implementations that produce identical results; nothing in the product path calls this. */
+ * (launch-shape variants, LSR_FOLD_SCAN, LSR_FWD_ROWS, ...: INTEGRATION.md section 4) for the rest of the process.  Knobs
+ * select between implementations that produce identical results (LSR_FWD_QUAD: identical transmittance / mask / list
+ * prefixes, colour sums in a different order); nothing in the product path calls this. */
 int lsr_debug_set_knob(const char *name, int value);
 
 /* ---- arithmetic convention of the projection stage (ABI v7).  0 (default): every float operation of the published
