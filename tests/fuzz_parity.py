@@ -6,7 +6,8 @@ suite's bars.  The shapes the suite pins by hand are a dozen; this draws them fr
 (Gaussian counts around the 64-wide blocks, image sides around the 16-pixel tiles, 1..6 views, colour off / SH degree
 0..4, 0..32 feature channels with latent SH degree 0..2, tiny and huge splats, both projection conventions; a fifth of
 the draws go through the scene-level inputs of the decoder path — in-kernel scene scale, 3x3 covariances, stored-layout
-colour SH, latent SH evaluated in-kernel, shared by all views (the fused projection + SH kernel) or per view).
+colour SH, latent SH evaluated in-kernel, shared by all views (the fused projection + SH kernel) or per view; an eighth
+compare the no-sync (latency) forward bit for bit with the synchronous one).
 
     python -m tests.fuzz_parity --seconds 240 --seed 1 [--out gpurun_out/fuzz_parity.json]
 
@@ -66,7 +67,7 @@ def classify(msg: str) -> str:
     if "n_considered mismatch fraction" in msg:   # every mismatching pixel was a fragile one (the assertion before it): a budget, lifted
         return "budget"
     exact = ("radii", "tile rectangles", "depth bits", "pixel means", "conic", "tile counts", "tile starts", "sorted tile lists", "n_considered", "run.P")
-    if any(k in msg for k in exact) or "Arrays are not equal" in msg:
+    if any(k in msg for k in exact) or "Arrays are not equal" in msg or "no-sync forward differs" in msg or "last_forward_status" in msg:
         return "exact"
     if any(k in msg for k in ("off by", "off the", "moved more", "next to a fragile", "within the")):
         return "bar"
@@ -87,6 +88,21 @@ def run_case(dev, case: dict, mode: str, contracted: bool):
             while cfg["feature_channels"] * (cfg["feature_sh_degree"] + 1) ** 2 > 120:   # the fused latent-SH contract (lsr_rasterizer.h); beyond it the
                 cfg["feature_sh_degree"] -= 1                                              # decoder evaluates the harmonics in torch, like the reference
             tp.test_fused_scene_inputs_match_oracle(dev, cfg, mode == "fused_shared")
+        elif mode == "nosync":   # the latency path (device-side pair count, later sort tiers in one launch) against the synchronous forward
+            from latentsplat_amd.rasterizer import last_forward_status, rasterize_views
+            sc, H, W = tp._scene(case)
+            bi = util.boundary_inputs(sc, H, W, bg=(0.1, 0.2, 0.3))
+            t = {k: (None if bi[k] is None else bi[k].to(dev)) for k in ("means", "cov6", "opac", "shs", "features")}
+            call = lambda **kw: rasterize_views(util.view_table(bi, dev), H, W, bi["sh_degree"], t["means"], t["cov6"], t["opac"], shs=t["shs"], features=t["features"], **kw)
+            with torch.no_grad():
+                ref = call()
+                st = last_forward_status()
+                hint = random.Random(case["seed"]).choice([64, 1024, max(1, st["max_tile_pairs"]), 16384])
+                out = call(pair_capacity=max(1, int(1.25 * st["num_pairs"]) + 1), max_tile_hint=hint)
+                assert last_forward_status() == st, (last_forward_status(), st)
+            for a, b in zip(out, ref):
+                assert (a is None) == (b is None)
+                assert a is None or torch.equal(a, b), "no-sync forward differs from the synchronous forward"
         elif mode == "forward":
             sc, H, W = tp._scene(case)
             bi = util.boundary_inputs(sc, H, W, bg=(0.2, 0.4, 0.6))
@@ -108,7 +124,7 @@ def sweep(dev, seed: int, seconds: float, max_cases: int = 0, only: int = -1) ->
     with lifted_budgets():
         while (time.time() - t0 < seconds and (not max_cases or done < max_cases)) or (only >= 0 and n <= only):
             case = draw(rng)
-            mode = rng.choice(["forward", "forward", "forward", "backward", "backward_aux", "fused_shared", "fused_per_view"])
+            mode = rng.choice(["forward", "forward", "forward", "backward", "backward_aux", "fused_shared", "fused_per_view", "nosync"])
             contracted = mode == "forward" and rng.random() < 0.25
             if mode != "forward":   # the gradient oracle is the slow part: keep its cases small
                 case["G"] = min(case["G"], 4097)
