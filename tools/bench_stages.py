@@ -19,14 +19,16 @@ from latentsplat_amd.rasterizer import rasterize_views  # noqa: E402
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else ""
-    V = 16
+    V, G = 16, 300_000
     for a in sys.argv:
         if a.startswith("--views="):
             V = int(a.split("=")[1])
+        if a.startswith("--gaussians="):
+            G = int(a.split("=")[1])
     dev = torch.device("cuda", 0)
     _lib.load()
-    out = {"tag": tag, "views": V}
-    inp = bench.build_inputs(300_000, V, 256, dev, 1234)
+    out = {"tag": tag, "views": V, "gaussians": G}
+    inp = bench.build_inputs(G, V, 256, dev, 1234)
     gf = torch.randn((V, 4, 256, 256), device=dev)
 
     def step():
