@@ -58,6 +58,8 @@ struct RenderBwdParams {
     const uint32_t *n_contrib;
     const float *g_color, *g_feat, *g_mask, *g_depth;  // dL/d outputs (any may be NULL)
     const float *f_color, *f_feat, *f_depth;           // images rendered by the matching forward
+    int parts_log2;     // small view batches: every half-tile item is walked by 2^parts_log2 waves, each emitting the
+                        // gradients of its share of the list's 64-entry batches (see the item loop)
     float *rec;         // [V*G][rec_floats] packed gradient records (zeroed by the caller)
     long long *rec_fixed;   // deterministic mode: the same records as 2^30 fixed point (zeroed by the caller), else NULL
     int rec_floats;
@@ -111,7 +113,9 @@ __device__ __forceinline__ void atomic_add_f32(float *addr, float v) { unsafeAto
 // WPB = waves per workgroup, WGS = workgroups per compute unit: as many resident waves as the per-wave LDS slice
 // and the register budget allow (the kernel is bound by instruction issue and the latencies of its dependent
 // chain: DESIGN.md).
-template <int NCHP, bool DEPTH_GRAD, int WPB, int WGS>
+// SPLIT: the list-splitting instance for launches that cannot fill the wave slots (see the item loop); the plain instance
+// carries none of its tests.
+template <int NCHP, bool DEPTH_GRAD, int WPB, int WGS, bool SPLIT>
 __global__ void __launch_bounds__(LSR_WAVE * WPB)
 k_render_bwd(RenderBwdParams p) {
     // float4 per staged entry: odd (conflict-free staging stores) except for the 8-channel payload, whose
@@ -150,7 +154,8 @@ k_render_bwd(RenderBwdParams p) {
         float *A = &s_acc[0][0];
         for (int i = lane; i < (LSR_WAVE + 1) * RT; i += LSR_WAVE) A[i] = 0.0f;
     }
-    const uint32_t num_items = p.header[kHdrNumItems];
+    const int parts_log2 = SPLIT ? p.parts_log2 : 0;
+    const uint32_t num_items = p.header[kHdrNumItems] << parts_log2;
     const int coff = p.has_color ? 3 : 0;
     const size_t HW = (size_t)p.H * p.W;
     // lane group -> sub-block (gcol, grow) of the half; lane -> its two pixels (lx, ly), (lx + 1, ly) (as in the forward)
@@ -180,7 +185,8 @@ k_render_bwd(RenderBwdParams p) {
             if (qi >= num_items) break;
         }
         qi = __builtin_amdgcn_readfirstlane(qi);
-        const uint32_t item = p.items[qi];
+        const uint32_t item = p.items[qi >> parts_log2];
+        const uint32_t part = qi & ((1u << parts_log2) - 1u);
         const uint32_t vt = item & kItemTileMask, half = item >> kItemHalfShift;
         const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
         const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)half;
@@ -251,6 +257,19 @@ k_render_bwd(RenderBwdParams p) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) maxlast = max(maxlast, (uint32_t)__shfl_xor((int)maxlast, off));
         maxlast = __builtin_amdgcn_readfirstlane(maxlast);
+        // List splitting for launches that cannot fill the wave slots (a few views): part k of 2^parts_log2 EMITS the
+        // gradients of batches [b0, b1) of the list only.  The per-pixel state in front of batch b0 — T and R — is a function
+        // of the entries before it, so the wave first walks batches [0, b0) updating just T and R (a quarter of an emitting
+        // step's instructions: no reciprocal, no moments, no cross-lane reduction, no table, no flush), with the operations of
+        // the emitting walk — every entry's gradient is the unsplit kernel's bit for bit.
+        uint32_t emit_from = 0, walk_end = maxlast;
+        if (SPLIT) {
+            const uint32_t nb = (maxlast + LSR_WAVE - 1) / LSR_WAVE;
+            const uint32_t b0 = (part * nb) >> parts_log2, b1 = ((part + 1u) * nb) >> parts_log2;
+            if (b0 == b1) continue;          // a list shorter than the number of parts: this part has no batch
+            emit_from = b0 * LSR_WAVE;
+            walk_end = min(maxlast, b1 * LSR_WAVE);
+        }
 
         // software-pipelined staging as in the forward: records of batch b+1 and list entries of
         // batch b+2 are in flight while batch b is processed
@@ -280,7 +299,8 @@ k_render_bwd(RenderBwdParams p) {
             w_ahead = load_ent(LSR_WAVE + lane);
         }
 
-        for (uint32_t cbase = 0; cbase < maxlast; cbase += LSR_WAVE) {
+        for (uint32_t cbase = 0; cbase < walk_end; cbase += LSR_WAVE) {
+            const bool emit = !SPLIT || cbase >= emit_from;   // wave-uniform
             const StageRec cur = nxt;
             nxt = load_rec(w_ahead);
             w_ahead = load_ent(cbase + 2 * LSR_WAVE + lane);
@@ -318,8 +338,10 @@ k_render_bwd(RenderBwdParams p) {
             for (int j = 0; j < 8; ++j) {
                 if (at[j] == 0xFFFFu) continue;
                 uint32_t rank = 0;
+                if (emit) {
 #pragma unroll
-                for (int jj = 0; jj < j; ++jj) rank += (uint32_t)(at[jj] == at[j]);
+                    for (int jj = 0; jj < j; ++jj) rank += (uint32_t)(at[jj] == at[j]);
+                }
                 s_list[j][at[j]] = (uint16_t)((uint32_t)lane | (rank << 8));
             }
             wave_lds_fence_bwd();
@@ -332,7 +354,11 @@ k_render_bwd(RenderBwdParams p) {
                 float2_b *row = (float2_b *)&s_acc[slot][tcol];
                 float2_b acc_old[NGRP];                          // this lane's pair(s) of the entry's table row, read early
 #pragma unroll
-                for (int gi = 0; gi < NGRP; ++gi) acc_old[gi] = row[8 * gi];
+                for (int gi = 0; gi < NGRP; ++gi) acc_old[gi] = float2_b{0.0f, 0.0f};
+                if (emit) {
+#pragma unroll
+                    for (int gi = 0; gi < NGRP; ++gi) acc_old[gi] = row[8 * gi];
+                }
                 float4_b a = E[0], b = E[1], t4[NCHP / 4];
 #pragma unroll
                 for (int c4 = 0; c4 < NCHP / 4; ++c4) t4[c4] = E[2 + c4];
@@ -378,6 +404,7 @@ k_render_bwd(RenderBwdParams p) {
                 if (DEPTH_GRAD) dsum = __builtin_elementwise_fma(float2_b{b.z, b.z}, ddep2, dsum);
                 R2 = __builtin_elementwise_fma(-w, dsum, R2);    // what is left behind this entry
                 T2 = __builtin_elementwise_fma(w, float2_b{-kInv255, -kInv255}, Tk);
+                if (!emit) continue;                             // another part's batch: only the state moves on
                 // dL/dalpha / 255 = T (g . c) / 255 - R / (255 (1 - alpha))
                 const float2_b dL_dalpha = __builtin_elementwise_fma(Tk, dsum, -(R2 * rcp1m));
                 const float2_b u = av * dL_dalpha;               // opacity exp(power) dL/dalpha: straight through the 0.99 clamp (A.6)
@@ -416,7 +443,7 @@ k_render_bwd(RenderBwdParams p) {
             // ---- flush: one global record-add per staged entry (every list entry reaches one of the half's sub-blocks) ----
 #pragma unroll 1
             for (int e0 = 0; e0 < LSR_WAVE; e0 += 4) {
-                if (!((staged >> e0) & 0xFull)) continue;   // wave-uniform
+                if (!emit || !((staged >> e0) & 0xFull)) continue;   // wave-uniform
                 const int e = e0 + fgrp;
                 const bool hit = (staged >> e) & 1ull;
                 const uint32_t g = s_gid[e];
@@ -444,8 +471,17 @@ __global__ void __launch_bounds__(256) k_fixed_to_float(const long long *__restr
 }
 
 template <int NCHP, bool DG, int WPB, int WGS>
-static void launch_variant(const RenderBwdParams &p, hipStream_t s) {
-    hipLaunchKernelGGL((k_render_bwd<NCHP, DG, WPB, WGS>), dim3(p.num_cus * WGS), dim3(LSR_WAVE * WPB), 0, s, p);
+static void launch_variant(RenderBwdParams p, uint64_t items, hipStream_t s) {
+    // list splitting: as many waves per half-tile item (a power of two, at most 8) as the launch's wave slots hold.
+    // LSR_BWD_PARTS = log2 of the number of parts forces it (0: never split).
+    const uint64_t slots = (uint64_t)p.num_cus * WPB * WGS;
+    const int forced = env_int("LSR_BWD_PARTS", -1);
+    int pl = 0;
+    if (forced >= 0) pl = forced > 3 ? 3 : forced;
+    else while (pl < 3 && (items << (pl + 1)) <= slots) ++pl;
+    p.parts_log2 = pl;
+    if (pl) hipLaunchKernelGGL((k_render_bwd<NCHP, DG, WPB, WGS, true>), dim3(p.num_cus * WGS), dim3(LSR_WAVE * WPB), 0, s, p);
+    else hipLaunchKernelGGL((k_render_bwd<NCHP, DG, WPB, WGS, false>), dim3(p.num_cus * WGS), dim3(LSR_WAVE * WPB), 0, s, p);
 }
 
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
@@ -470,7 +506,7 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     p.final_T = (const float *)(img + I.final_T); p.n_contrib = (const uint32_t *)(img + I.n_contrib);
     p.g_color = gout.color; p.g_feat = gout.feature; p.g_mask = gout.mask; p.g_depth = gout.depth;
     p.f_color = fwd.color; p.f_feat = fwd.feature; p.f_depth = fwd.depth;
-    p.rec = (float *)(grad + R.rec); p.rec_floats = R.rec_floats;
+    p.rec = (float *)(grad + R.rec); p.rec_floats = R.rec_floats; p.parts_log2 = 0;
     const bool det = deterministic_backward();
     p.rec_fixed = det ? (long long *)(grad + R.fixed) : nullptr;
     p.queue = (uint32_t *)(grad + R.fixed - 256);   // the zeroed slack behind the float records
@@ -479,20 +515,21 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));
     const bool dg = gout.depth != nullptr;
     prof_begin(kStRenderBwd, s);
+    const uint64_t items = 2ull * (uint64_t)d.num_views * (uint64_t)p.T;   // upper bound of the header's item count
 #define LSR_RB(N, WPB, WGS)                                      \
     do {                                                         \
-        if (dg) launch_variant<N, true, WPB, WGS>(p, s);         \
-        else launch_variant<N, false, WPB, WGS>(p, s);           \
+        if (dg) launch_variant<N, true, WPB, WGS>(p, items, s);  \
+        else launch_variant<N, false, WPB, WGS>(p, items, s);    \
     } while (0)
     // LSR_BWD_VARIANT (development knob, read once) selects the alternatives measured in DESIGN.md
     const int variant = env_int("LSR_BWD_VARIANT", 0);
-    if (nchp == 4 && !dg) { if (variant == 1) launch_variant<4, false, 10, 2>(p, s); else if (variant == 2) launch_variant<4, false, 12, 1>(p, s); else launch_variant<4, false, 16, 1>(p, s); }
+    if (nchp == 4 && !dg) { if (variant == 1) launch_variant<4, false, 10, 2>(p, items, s); else if (variant == 2) launch_variant<4, false, 12, 1>(p, items, s); else launch_variant<4, false, 16, 1>(p, items, s); }
     else if (nchp == 4) LSR_RB(4, 16, 1);
     // packed table rows: 16 waves per CU fit with 64-byte staged entries.  (Round 4: this instance shows 34 % LDS bank-conflict
     // cycles — eight lane groups reading eight 64-byte records start in one of only four bank groups — but the odd
     // 80-byte stride costs a wave: 15 waves 0.969-0.977 ms, 14 waves 1.02 against 0.945-0.954 at configs[4].)
-    else if (nchp == 8 && !dg) launch_variant<8, false, 16, 1>(p, s);
-    else if (nchp == 8) launch_variant<8, true, 12, 1>(p, s);
+    else if (nchp == 8 && !dg) launch_variant<8, false, 16, 1>(p, items, s);
+    else if (nchp == 8) launch_variant<8, true, 12, 1>(p, items, s);
     else if (nchp == 12) LSR_RB(12, 8, 1);
     else LSR_RB(36, 4, 1);
 #undef LSR_RB

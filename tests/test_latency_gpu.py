@@ -147,7 +147,8 @@ def test_launch_structure_knobs_do_not_change_results(hip_device):
     LSR_FOLD_SCAN), how the host waits for the pair count (polling the mapped words or sleeping on the event:
     LSR_HOST_POLL), the order in which the per-tile sort visits the tiles (LSR_SORT_LPT) and whether the forward
     compositing kernel renders a half tile with one wave (two pixels per lane) or with two waves (one row of sub-blocks
-    each, one pixel per lane: LSR_FWD_ROWS, chosen by the item count otherwise) only change WHEN and WHERE kernels run: images, the per-pixel workspaces the backward reads and the gradients must be bitwise identical (knobs
+    each, one pixel per lane: LSR_FWD_ROWS, chosen by the item count otherwise) and between how many waves the backward splits
+    a half-tile list (LSR_BWD_PARTS) only change WHEN and WHERE kernels run: images, the per-pixel workspaces the backward reads and the gradients must be bitwise identical (knobs
     are read once per process, hence subprocesses), in the synchronous and the no-sync forward, under back-to-back
     calls and inside a captured hipGraph."""
     import os
@@ -196,7 +197,10 @@ print("HASH", h.hexdigest())
     variants = {"default": {}, "scan_kernel": dict(LSR_FOLD_SCAN="0"), "event_wait": dict(LSR_HOST_POLL="0"),
                 "scan_kernel_event_wait": dict(LSR_FOLD_SCAN="0", LSR_HOST_POLL="0"),
                 "sort_natural_order": dict(LSR_SORT_LPT="0"),
-                "fwd_row_items": dict(LSR_FWD_ROWS="1"), "fwd_half_tile_items": dict(LSR_FWD_ROWS="0")}
+                "fwd_row_items": dict(LSR_FWD_ROWS="1"), "fwd_half_tile_items": dict(LSR_FWD_ROWS="0"),
+                # the backward of this small shape splits every half-tile list between four waves (each walks the entries in
+                # front of its share for the per-pixel state only): the same gradient records as one wave per list
+                "bwd_unsplit_lists": dict(LSR_BWD_PARTS="0"), "bwd_eight_parts": dict(LSR_BWD_PARTS="3")}
     for name, extra in variants.items():
         env = dict(os.environ, LSR_FWD_QUAD="0", **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
