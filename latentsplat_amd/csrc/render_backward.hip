@@ -28,6 +28,7 @@
 // the eight groups' records into a per-batch table (row = staged entry).  When the batch is done the rows
 // are flushed with coalesced global atomics, one 64-byte record per 16 lanes: one global record-add per
 // entry of a half list (0.94 per (Gaussian, tile) pair).
+// Launches that cannot fill the wave slots (a few views) split every list between 2 / 4 / 8 waves (SPLIT instance).
 // Spec: SURVEY.md Appendix A.6.
 #include "lsr_blend.h"
 
