@@ -81,6 +81,40 @@ def cpu_baseline(G, size, seed, budget_s=12.0):
                 fwdbwd_value=nb / el_b, fwdbwd_sample=f"{nb} forward+backward passes of that view")
 
 
+def parity_gate(G, V, size, seed, dev):
+    """"parity gates reported next to every timing".  OUTSIDE every timed region (part of the
+    cpu_baseline leg: rank 0, N = 1): the bench workload — the same seeded scene, all V views in ONE call through the C ABI,
+    i.e. the launch shapes the timings above measured — against the CPU oracle for view 0 and the last view: tile
+    offsets and depth-sorted lists bit for bit, rendered latent / mask within 1e-4 abs outside the oracle's fragile
+    (decision-boundary) pixels."""
+    import numpy as np
+    from tests import util
+    from latentsplat_amd.synthetic import make_scene
+    sc = make_scene(G, image_size=size, views=V, color_sh_degree=None, feature_channels=4, feature_sh_degree=0, seed=seed)
+    bi = util.boundary_inputs(sc, size, size)
+    run = util.HipRun(bi, dev, shared_means=True)      # (equal near planes: the scaled scene is the same for every view)
+    ts, pl, T = run.tile_start(), run.point_list(), run.T
+    exact, worst, over, frag_px, pairs = True, 0.0, 0, 0, 0
+    checked = sorted({0, V - 1})
+    for v in checked:
+        o = util.oracle_forward(bi, v)
+        pairs += int(o["P"])
+        exact = exact and bool(np.array_equal(run.radii[v].cpu().numpy(), o["radii"]))
+        exact = exact and bool(np.array_equal(np.diff(ts[v * T:(v + 1) * T + 1]), o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]))
+        exact = exact and bool(np.array_equal(pl[ts[v * T]:ts[(v + 1) * T]], o["point_list"]))
+        fragile = np.zeros(size * size, bool)
+        if len(o["fragile"]):
+            fragile[o["fragile"][:, 0].astype(np.int64)] = True
+        frag_px += int(fragile.sum())
+        for got, want in ((run.feat_out[v].cpu().numpy(), o["feature"]), (run.mask_out[v].cpu().numpy()[None], o["mask"].reshape(1, size, size))):
+            err = np.abs(got - want).reshape(got.shape[0], -1).max(0)
+            worst = max(worst, float(err[~fragile].max()))
+            over += int((err[~fragile] > 1e-4).sum())
+    return dict(lists_bit_exact=exact, max_abs_err=worst, pixels_over_tol=over, fragile_pixels_excluded=frag_px,
+                views_checked=checked, pairs_checked=pairs, tol=1e-4, ok=bool(exact and over == 0),
+                what=f"{V}-view call of the bench scene through the C ABI vs oracle/raster_oracle.c (outside the timed regions)")
+
+
 def cpu_baseline_next_rows(budget_s=4.0):
     """cpu_baseline leg for the §8(f) rows: the torch-CPU oracles (= the reference's own op chains,
     oracle/adapter_oracle.py and oracle/latent_oracle.py) on the host cores, same shapes as
@@ -689,6 +723,7 @@ def main():
     roofline_bwd = None
     stage_roofline = None
     path = None
+    path_fb = None
     if P is not None:
         # algorithmic bytes of ONE render launch (V views): sorted index + gathered record per pair,
         # every output word once (SURVEY.md §8(d) terms P*b_rec + H*W*b_out, plus the 4-byte index)
@@ -728,11 +763,14 @@ def main():
                                 unit="GB/s", frac=bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
                                 algorithmic_bytes_per_launch=bwd_bytes, launch_ms=bwd_ms)
         # every stage against the HBM roofline with its own algorithmic bytes
+        # (round 5: single-pass binning — the projection kernel also writes the 8-byte sort keys; `scatter` only appears
+        # when the call took the two-phase path)
+        single_pass = not prof.get("scatter", (0.0, 0))[1]
         stage_bytes = dict(
             # the shared scene is read once per block of 4 views; written: one 64-byte record per visible
             # (view, Gaussian), a 12-byte bin record and the 4-byte radius for every one (the tile scan runs in the
             # kernel's last workgroup since round 4; `tile_scan` only appears for calls with more than 4096 tiles)
-            preprocess=-(-V // 4) * G * (12 + 36 + 4 + 4 * C) + g_vis * 64 + V * G * (12 + 4),
+            preprocess=-(-V // 4) * G * (12 + 36 + 4 + 4 * C) + g_vis * 64 + V * G * (12 + 4) + (P * 8 if single_pass else 0),
             tile_scan=V * (S // 16) * (S // 16) * 12,
             scatter=V * G * 12 + P * 8,
             # keys in, canonical list + the two half-tile render lists (0.94 entries per pair) out
@@ -746,14 +784,30 @@ def main():
         # whole forward path per view against the same roofline (SURVEY §8(d) B_fwd)
         B_fwd_step = V * G * b_in + g_vis * b_rec + P * 16 + P * b_rec + V * S * S * b_out
         step_s = el_fwd / args.steps
+        # `frac` charges the scene's input bytes once per VIEW (SURVEY §8(d)'s per-view formula, to the letter); the V views
+        # of a step share ONE scene, so `frac_shared_scene` charges them once per step — the honest figure for this launch
+        B_fwd_shared = G * b_in + g_vis * b_rec + P * 16 + P * b_rec + V * S * S * b_out
         path = dict(algorithmic_bytes_per_view=B_fwd_step / V, achieved=B_fwd_step / step_s / 1e9,
                     frac=B_fwd_step / step_s / 1e9 / HBM_PEAK_GBS, pairs_per_view=P / V,
-                    visible_fraction=g_vis / (V * G))
+                    visible_fraction=g_vis / (V * G), frac_shared_scene=B_fwd_shared / step_s / 1e9 / HBM_PEAK_GBS,
+                    algorithmic_bytes_per_view_shared_scene=B_fwd_shared / V)
+        if fb is not None:
+            # forward + backward (configs[2]) the same way: B_bwd of SURVEY §8(d) with the measured P, G_vis
+            g_rec = 8 + 12 + 4 + 4 * C
+            g_out = 12 + 24 + 4 + 4 * C
+            B_bwd_step = V * S * S * (b_out + 8) + P * (4 + b_rec) + P * 2 * g_rec + g_vis * (12 + 24 + g_rec) + V * G * g_out
+            B_bwd_shared = B_bwd_step - (V - 1) * G * g_out
+            fb_s = fb["ms_per_step"] * 1e-3
+            path_fb = dict(algorithmic_bytes_per_view=(B_fwd_step + B_bwd_step) / V, achieved=(B_fwd_step + B_bwd_step) / fb_s / 1e9,
+                           frac=(B_fwd_step + B_bwd_step) / fb_s / 1e9 / HBM_PEAK_GBS,
+                           frac_shared_scene=(B_fwd_shared + B_bwd_shared) / fb_s / 1e9 / HBM_PEAK_GBS)
 
     cpu = None
+    gate = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(G, S, 1234)
         cpu["torch_oracle"] = cpu_baseline_torch()
+        gate = parity_gate(G, V, S, 1234, dev)
     # (the decoder / adapter / latent / chained-path legs run BEFORE the pipelined and latency legs: measured behind them in
     # two runs without the CPU baselines — a minute of uninterrupted GPU load, two extra streams, a captured hipGraph and its
     # private memory pool in the process — the configs[4] forward+backward step read 2.8 ms; in a fresh process, in runs with
@@ -789,7 +843,8 @@ def main():
             "kernel_ms_per_launch": {k: (ms / n if n else None) for k, (ms, n) in prof.items()},
             "per_rank_ms_per_step": per_rank_fwd, "ms_per_step_spread": step_spread,
             "stage_roofline": stage_roofline, "roofline_bwd": roofline_bwd, "latency": latency, "pipelined": pipelined,
-            "fwdbwd": fb, "decoder_step": dec_step, "adapter_step": adapter_step, "latent_step": latent_step, "path_step": path_step, "roofline": roofline, "roofline_valu": roofline_valu, "roofline_path": path, "cpu_baseline": cpu,
+            "fwdbwd": fb, "decoder_step": dec_step, "adapter_step": adapter_step, "latent_step": latent_step, "path_step": path_step, "roofline": roofline, "roofline_valu": roofline_valu, "roofline_path": path, "roofline_path_fwdbwd": path_fb, "cpu_baseline": cpu,
+            "parity_gate": gate,
         }
         # The whole dictionary goes to a side file; stdout carries ONE compact line (graded keys first, < 4 KB) so
         # that a driver record that truncates long lines still holds value / roofline / cpu_baseline / fwdbwd.
@@ -811,7 +866,9 @@ def main():
             torch_oracle=pick(cpu.get("torch_oracle"), ("value", "unit", "cores", "kind")))
         line["fwdbwd"] = pick(fb, ("views_per_s", "ms_per_view", "ms_per_step"))
         line["roofline_bwd"] = pick(roofline_bwd, ("kernel", "achieved", "frac", "algorithmic_bytes_per_launch", "launch_ms"))
-        line["roofline_path"] = pick(path, ("algorithmic_bytes_per_view", "achieved", "frac", "pairs_per_view"))
+        line["parity_gate"] = pick(gate, ("ok", "lists_bit_exact", "max_abs_err", "pixels_over_tol", "fragile_pixels_excluded", "views_checked", "tol"))
+        line["roofline_path"] = pick(path, ("algorithmic_bytes_per_view", "achieved", "frac", "frac_shared_scene", "pairs_per_view"))
+        line["roofline_path_fwdbwd"] = pick(path_fb, ("algorithmic_bytes_per_view", "achieved", "frac", "frac_shared_scene"))
         line["roofline_valu"] = pick(roofline_valu, ("valu_insts_per_launch", "frac"))
         line["kernel_ms"] = {k: r4(v) for k, v in full["kernel_ms_per_launch"].items() if v}
         if fb is not None:

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LSR_ABI_VERSION 7
+#define LSR_ABI_VERSION 8
 #define LSR_TILE 16            /* tile edge in pixels (16x16 = the published algorithm's tile) */
 #define LSR_MAX_FEAT_CHANNELS 32
 #define LSR_MAX_SH_DEGREE 4

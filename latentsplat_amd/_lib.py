@@ -212,8 +212,14 @@ def load():
     lib.lsr_ply_pack.argtypes = [I64, I32, C.POINTER(PlyInputs), P, P]
     lib.lsr_ply_write_host.restype = C.c_int
     lib.lsr_ply_write_host.argtypes = [C.c_char_p, P, I64]
-    if lib.lsr_abi_version() != 7 and not os.environ.get("LSR_LIB"):
-        raise LsrError("liblsr_hip.so ABI version mismatch; rebuild it")
+    abi = lib.lsr_abi_version()
+    if abi != 8:
+        # an older build selected with LSR_LIB for a kernel A/B is only accepted on explicit request
+        if not (os.environ.get("LSR_LIB") and os.environ.get("LSR_ALLOW_OLD_ABI") == "1"):
+            raise LsrError(f"{_SO}: ABI version {abi}, this package needs 8; rebuild it (LSR_ALLOW_OLD_ABI=1 with LSR_LIB "
+                           "accepts an older experiment build at your own risk)")
+        import warnings
+        warnings.warn(f"{_SO}: ABI version {abi} != 8 accepted because LSR_ALLOW_OLD_ABI=1")
     _lib = lib
     return lib
 

@@ -8,6 +8,9 @@
 
 using namespace lsr;
 
+#include <sched.h>
+
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -77,6 +80,31 @@ static int g_projection_contraction = -1;
 bool lsr::projection_contraction() {
     const int v = __atomic_load_n(&g_projection_contraction, __ATOMIC_RELAXED);
     return (v < 0 ? env_int("LSR_PROJECTION_CONTRACTION", 0) : v) != 0;
+}
+
+// Keys per (view, tile) segment of the single-pass binning for a call of these dims; 0 = two-phase binning (lsr_internal.h).
+// A pure function of the dims and two knobs, so that every stage of a call (and lsr_geom_workspace_bytes before it) agrees.
+//   * byte tile coordinates and at most 1024 tiles per view: the projection kernel's LDS tile histogram (4 views per
+//     workgroup) and its 12-byte binning records;
+//   * as many keys as fit LSR_SEG_BUDGET_MB (default 512 MB of address space at the end of the geometry workspace — the
+//     segments are written sparsely: only P * 8 bytes of them are ever touched), at most 8192 (the second sort tier) and
+//     never more than the scene has Gaussians (a tile list cannot be longer).
+uint32_t lsr::segment_capacity(const lsr_dims &d) {
+    if (!env_int("LSR_SEGMENTS", 1) || d.num_gaussians <= 0) return 0u;
+    const int64_t T = num_tiles(d);
+    if (!narrow_bins(d) || T > 1024) return 0u;
+    if (fused_preprocess_sh(d)) return 0u;        // (k_preprocess_sh keeps the two-phase path for now)
+    const int64_t VT = (int64_t)d.num_views * T;
+    const int64_t budget = (int64_t)env_int("LSR_SEG_BUDGET_MB", 512) << 20;
+    int64_t cap = 8192;
+    while (cap > 1024 && VT * cap * 8 > budget) cap >>= 1;
+    if (VT * cap * 8 > budget) return 0u;
+    const int64_t g64 = ((int64_t)d.num_gaussians + 63) / 64 * 64;
+    if (g64 < cap) cap = g64;
+    // LSR_SEG_CAP (tests): a smaller capacity than the policy's, to exercise the overflow path on small scenes
+    const int64_t forced = env_int("LSR_SEG_CAP", 0);
+    if (forced > 0 && forced < cap) cap = (forced + 63) / 64 * 64;
+    return (uint32_t)cap;
 }
 
 // Development knobs (LSR_FWD_VARIANT, LSR_SH_PLACEMENT, ...): read from the environment once per process and knob,
@@ -196,8 +224,8 @@ static int sh_forward_inline(const lsr_dims &d, const lsr_inputs &in, char *geom
 // the other half on a side stream: bit-identical, never faster — both halves are issue-bound — and deleted in
 // round 4.  Callers with independent batches overlap whole calls on two streams instead: INTEGRATION.md.)
 static int forward_tail(const lsr_dims &d, const lsr_inputs &in, char *geom, char *bin, char *img, int64_t num_pairs,
-                        int32_t max_tile_pairs, const lsr_outputs &out, hipStream_t s, bool device_counts) {
-    LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts));
+                        int32_t max_tile_pairs, const lsr_outputs &out, hipStream_t s, bool device_counts, bool seg) {
+    LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts, seg));
     LSR_STAGE("render_forward", s, launch_render_forward(d, in, geom, bin, num_pairs, img, out, s));
     return LSR_OK;
 }
@@ -330,6 +358,13 @@ int lsr_pack_view(const float *viewmatrix, const float *projmatrix, const float 
 // the wake-up through the runtime cost more than the scan it was hiding.  The event recorded behind the kernel is
 // the safety net: queried every few microseconds, and once it has completed without the sequence word showing up
 // (cannot happen unless the launch failed) the header is read back with a copy.  LSR_HOST_POLL=0: wait on the event.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
 static int wait_pair_count(volatile uint32_t *h, uint32_t seq, hipEvent_t ev, bool &have) {
     have = false;
     if (!env_int("LSR_HOST_POLL", 1)) {
@@ -337,9 +372,14 @@ static int wait_pair_count(volatile uint32_t *h, uint32_t seq, hipEvent_t ev, bo
         have = __atomic_load_n(&h[2], __ATOMIC_ACQUIRE) == seq;
         return LSR_OK;
     }
+    // Bounded spin: the words normally arrive within the projection kernel's ~0.1 ms.  When the caller's stream has a
+    // backlog in front of this call (a training step with encoder kernels queued ahead) the wait can be long: after
+    // ~0.3 ms of spinning the thread yields between polls, and after ~4 ms it sleeps on the event instead of burning
+    // a core for the whole backlog.
+    const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
         if (__atomic_load_n(&h[2], __ATOMIC_ACQUIRE) == seq) { have = true; return LSR_OK; }
-        __builtin_ia32_pause();
+        cpu_relax();
         if ((spins & 0x3FFu) == 0u) {
             const hipError_t q = hipEventQuery(ev);
             if (q == hipSuccess) {
@@ -348,6 +388,13 @@ static int wait_pair_count(volatile uint32_t *h, uint32_t seq, hipEvent_t ev, bo
             }
             if (q != hipErrorNotReady) return fail_hip(q);
             (void)hipGetLastError();   // hipErrorNotReady is sticky in the last-error slot
+            const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > 4000) {
+                LSR_HIP(hipEventSynchronize(ev));
+                have = __atomic_load_n(&h[2], __ATOMIC_ACQUIRE) == seq;
+                return LSR_OK;
+            }
+            if (waited > 300) sched_yield();
         }
     }
 }
@@ -393,30 +440,41 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
         }
     }
     const bool mapped = h_event != nullptr;
-    if (++h_seq == 0u) h_seq = 1u;                        // 0 is what a fresh buffer holds
     const bool fold = fold_tile_scan(*d);
-    FoldedScan fs{};
-    fs.enabled = fold ? 1 : 0;
-    fs.host_words = mapped ? h_hdr_dev : nullptr; fs.host_seq = h_seq; fs.capacity = 0xFFFFFFFFu;
-    if (fused_preprocess_sh(*d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(*d, *in, geom, radii, fs, s));
-    else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, fs, s));
-    if (fold && mapped) LSR_HIP(hipEventRecord(h_event, s));
-    rc = sh_forward_inline(*d, *in, geom, s);   // view-dependent payload of calls the fused kernel does not cover
-    if (rc) return rc;
-    if (!fold) {
-        LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, mapped ? h_hdr_dev : nullptr, h_seq, 0xFFFFFFFFu, s));
-        if (mapped) LSR_HIP(hipEventRecord(h_event, s));
-    }
+    // Single-pass binning when the dims allow it (segment_capacity): the projection kernel writes the sort keys itself.
+    // Should a tile list turn out longer than a key segment (the host reads the longest list below anyway), the call is
+    // run again on the two-phase path, whose workspace is sized after the fact — rare (more than 8192 Gaussians over
+    // one tile at the usual sizes), correct, and invisible to the caller: lsr_forward_render takes the same decision
+    // from the same two numbers.
+    const uint32_t seg_cap = segment_capacity(*d);
     uint32_t hdr[2] = {0, 0};
-    bool have = false;
-    if (mapped) {
-        rc = wait_pair_count(h_hdr, h_seq, h_event, have);
+    for (int attempt = seg_cap ? 0 : 1; attempt < 2; ++attempt) {
+        const bool seg = attempt == 0;
+        if (++h_seq == 0u) h_seq = 1u;                        // 0 is what a fresh buffer holds
+        FoldedScan fs{};
+        fs.enabled = fold ? 1 : 0;
+        fs.host_words = mapped ? h_hdr_dev : nullptr; fs.host_seq = h_seq; fs.capacity = 0xFFFFFFFFu; fs.seg_cap = 0xFFFFFFFFu;
+        if (fused_preprocess_sh(*d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(*d, *in, geom, radii, fs, s));
+        else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, fs, seg, s));
+        if (fold && mapped) LSR_HIP(hipEventRecord(h_event, s));
+        rc = sh_forward_inline(*d, *in, geom, s);   // view-dependent payload of calls the fused kernel does not cover
         if (rc) return rc;
-        if (have) { hdr[0] = h_hdr[0]; hdr[1] = h_hdr[1]; }
-    }
-    if (!have) {
-        LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));
-        LSR_HIP(hipStreamSynchronize(s));
+        if (!fold) {
+            LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, mapped ? h_hdr_dev : nullptr, h_seq, 0xFFFFFFFFu, seg ? seg_cap : 0xFFFFFFFFu, s));
+            if (mapped) LSR_HIP(hipEventRecord(h_event, s));
+        }
+        bool have = false;
+        hdr[0] = hdr[1] = 0;
+        if (mapped) {
+            rc = wait_pair_count(h_hdr, h_seq, h_event, have);
+            if (rc) return rc;
+            if (have) { hdr[0] = h_hdr[0]; hdr[1] = h_hdr[1]; }
+        }
+        if (!have) {
+            LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));
+            LSR_HIP(hipStreamSynchronize(s));
+        }
+        if (!seg || hdr[1] <= seg_cap) break;       // every list fits its segment (or this was the two-phase run)
     }
     *num_pairs_host = (int64_t)hdr[0];
     *max_tile_pairs_host = (int32_t)hdr[1];
@@ -438,8 +496,11 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
     if (num_pairs < 0 || max_tile_pairs < 0) return LSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    // binning + compositing; waits for the SH payload pass lsr_forward_prepare launched
-    return forward_tail(*d, *in, (char *)geom_ws, (char *)bin_ws, (char *)img_ws, num_pairs, max_tile_pairs, *out, s, false);
+    // binning + compositing.  Single-pass binning iff lsr_forward_prepare used it: the dims allow it and no list
+    // outgrew its segment (the decision prepare took from the same two numbers)
+    const uint32_t seg_cap = segment_capacity(*d);
+    const bool seg = seg_cap != 0u && (uint32_t)max_tile_pairs <= seg_cap;
+    return forward_tail(*d, *in, (char *)geom_ws, (char *)bin_ws, (char *)img_ws, num_pairs, max_tile_pairs, *out, s, false, seg);
 }
 
 int lsr_forward_abandon(lsr_stream_t stream) {
@@ -464,15 +525,20 @@ int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     char *geom = (char *)geom_ws;
     // the same stage sequence as prepare + render; nothing between the launches waits for the device
     const bool fold = fold_tile_scan(*d);
+    // single-pass binning whenever the dims allow it; a list longer than its key segment raises the overflow flag of
+    // lsr_forward_status like a pair count beyond `pair_capacity` does (re-run such a scene with LSR_SEGMENTS=0 or
+    // through the synchronous forward, which falls back by itself)
+    const uint32_t seg_cap = segment_capacity(*d);
+    const bool seg = seg_cap != 0u;
     FoldedScan fs{};
     fs.enabled = fold ? 1 : 0;
-    fs.capacity = (uint32_t)pair_capacity;
+    fs.capacity = (uint32_t)pair_capacity; fs.seg_cap = 0xFFFFFFFFu;
     if (fused_preprocess_sh(*d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(*d, *in, geom, out->radii, fs, s));
-    else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, fs, s));
+    else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, fs, seg, s));
     rc = sh_forward_inline(*d, *in, geom, s);
     if (rc) return rc;
-    if (!fold) LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, 0u, (uint32_t)pair_capacity, s));
-    return forward_tail(*d, *in, geom, (char *)bin_ws, (char *)img_ws, pair_capacity, max_tile_hint, *out, s, true);
+    if (!fold) LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, 0u, (uint32_t)pair_capacity, seg ? seg_cap : 0xFFFFFFFFu, s));
+    return forward_tail(*d, *in, geom, (char *)bin_ws, (char *)img_ws, pair_capacity, max_tile_hint, *out, s, true, seg);
 }
 
 int lsr_forward_status(const lsr_dims *d, const void *geom_ws, int64_t *num_pairs_host, int32_t *max_tile_pairs_host,

@@ -35,18 +35,19 @@ constexpr int kScanRegs = 8;   // counts per thread kept in registers (4 at 1024
 
 __global__ void __launch_bounds__(kScanThreads)
 k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *header,
-            uint32_t *host_words, uint32_t host_seq, uint32_t *__restrict__ order, int N, uint32_t capacity) {
+            uint32_t *host_words, uint32_t host_seq, uint32_t *__restrict__ order, int N, uint32_t capacity, uint32_t seg_cap) {
     __shared__ TileScanShared<kScanThreads> s_scan;
-    tile_scan_block<kScanThreads, kScanRegs, false>(count, start, header, HostMirror{host_words, host_seq}, order, N, capacity, s_scan);
+    tile_scan_block<kScanThreads, kScanRegs, false>(count, start, header, HostMirror{host_words, host_seq}, order, N, capacity, s_scan, seg_cap);
 }
 
-hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_words, uint32_t host_seq, uint32_t pair_capacity, hipStream_t s) {
+hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_words, uint32_t host_seq, uint32_t pair_capacity,
+                            uint32_t seg_cap, hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const int N = d.num_views * (int)num_tiles(d);
     prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
                        (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
-                       (uint32_t *)(geom + L.header), host_words, host_seq, (uint32_t *)(geom + L.tile_order), N, pair_capacity);
+                       (uint32_t *)(geom + L.header), host_words, host_seq, (uint32_t *)(geom + L.tile_order), N, pair_capacity, seg_cap);
     prof_end(kStTileScan, s);
     return hipGetLastError();
 }
@@ -180,6 +181,7 @@ struct HalfOut {
     uint32_t long_cap;        // entries of the array (tiles of the call)
     uint32_t *long_count[2];  // header words
     IndexPacking ip;          // how keys and list entries carry the Gaussian index (lsr_internal.h)
+    uint32_t seg_cap;         // single-pass binning: the keys of tile vt are keys[vt * seg_cap ...] (0: keys[tile_start[vt] ...])
 };
 constexpr int kSortTier2 = 8192;
 __device__ __forceinline__ uint32_t long_tile(const HalfOut &ho, int cls, uint32_t i) {
@@ -303,6 +305,11 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
         if (tid == 0) ho.header[kHdrOverflow] = 1u;
         return;
     }
+    if (ho.seg_cap && n > ho.seg_cap) {           // single-pass binning: the segment could not hold the list (the scan has flagged it): render nothing
+        if (tid < 2) hcnt[tid] = 0;
+        if (tid == 0) ho.header[kHdrOverflow] = 1u;
+        return;
+    }
     if (n > (uint32_t)CAP) {        // for a later tier: a larger LDS variant, or (beyond the largest) the global merge path
         if (tid == 0 && tier == 0) {
             const int cls = n > (uint32_t)kSortTier2 ? 1 : 0;
@@ -311,7 +318,7 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
         }
         return;
     }
-    const uint64_t *src = keys + start;
+    const uint64_t *src = ho.seg_cap ? keys + vt * (size_t)ho.seg_cap : keys + start;
     if (n == 1) {
         if (tid == 0) {
             const uint32_t w = (uint32_t)src[0], idx = key_index(ho, w);
@@ -575,7 +582,7 @@ static void sort_launch(dim3 grid, hipStream_t s, int cls, const uint32_t *order
 }
 
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
-                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts) {
+                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts, bool seg) {
     (void)radii;
     const GeomLayout L = geom_layout(d);
     if (num_pairs <= 0 || d.num_gaussians == 0)   // nothing to sort: every half-tile render list is empty
@@ -583,7 +590,10 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     // no-sync forward: the merge scratch is always part of the layout (the longest list is unknown)
     const BinLayout B = bin_layout(d, num_pairs, device_counts ? kSortLdsMax + 1 : max_tile_pairs);
     const int T = (int)num_tiles(d), gx = tiles_x(d);
-    uint64_t *keys = (uint64_t *)(bin + B.keys);
+    // single-pass binning: the projection kernel has already written the keys into the tile segments of the geometry
+    // workspace — no scatter, and the keys area of the binning workspace stays untouched
+    if (seg && L.seg_cap == 0) return hipErrorInvalidValue;
+    uint64_t *keys = seg ? (uint64_t *)(geom + L.seg_keys) : (uint64_t *)(bin + B.keys);
     uint32_t *plist = (uint32_t *)(bin + B.point_list);
     const uint32_t *ts = (const uint32_t *)(geom + L.tile_start);
     HalfOut ho;
@@ -596,7 +606,8 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     ho.long_cap = (uint32_t)d.num_views * (uint32_t)T;
     ho.long_count[0] = ho.header + kHdrLongTiles; ho.long_count[1] = ho.long_count[0] + 1;
     ho.ip = index_packing(d);
-    {
+    ho.seg_cap = seg ? L.seg_cap : 0u;
+    if (!seg) {
         const bool lds = T <= 8192;
         // Items per thread: the launch should be ONE round of resident workgroups (8 per CU, fewer when
         // the per-tile counters of a large image take the LDS) — with a fixed 2048 Gaussians per block the

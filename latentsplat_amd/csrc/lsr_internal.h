@@ -23,8 +23,9 @@ namespace lsr {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t header, rec, bin, tile_count, tile_start, tile_cursor, tile_order, half_count, sh_clamp, total;
+    size_t header, rec, bin, tile_count, tile_start, tile_cursor, tile_order, half_count, sh_clamp, seg_keys, total;
     int rec_floats;
+    uint32_t seg_cap;      // keys per (view, tile) segment of the single-pass binning; 0 = two-phase binning (k_scatter)
 };
 struct ImgLayout {
     size_t final_T, n_contrib, total;
@@ -93,6 +94,28 @@ constexpr uint32_t kSpanAll = 0xFF00FF00u;    // conic not trustworthy: every ce
 constexpr int kKeyIndexShift = 8;
 constexpr uint32_t kCodeNone = 0x11u;   // c0 = 1 > c1 = 0, r0 = 1 > r1 = 0
 
+// ---- single-pass binning (round 5): fixed-capacity key segments ----
+// Rounds 1-4 binned in two phases: the projection kernel counted pairs per tile and wrote a 12-byte binning record per
+// (view, Gaussian); after the tile scan (and, in the synchronous forward, the host's read-back of the pair count that
+// sizes the binning workspace) k_scatter read the records back and wrote the sort keys into exactly sized tile segments.
+// Now every (view, tile) owns a FIXED-capacity key segment at the end of the geometry workspace, and the projection
+// kernel writes the keys itself: a workgroup reserves its slots with the one global atomic per (workgroup, tile) it
+// already spent on the pair count (now a returning one) and emits the keys of its 2048 (Gaussian, view) items before it
+// retires — no k_scatter launch, no second machine-wide pass over the binning records (the workgroup re-reads its own
+// 24 KB of them while they are still in its L2).  The tile scan still produces the exact offsets, so k_sort_tiles
+// writes the canonical point_list and the half-tile lists exactly where they were.
+// A tile with more pairs than a segment holds sets the overflow flag; the synchronous forward sees the longest list on
+// the host anyway and re-runs such a call on the two-phase path (api.hip), the no-sync forward reports the flag.
+// segment_capacity(d) (api.hip) is a pure function of the dims and the LSR_SEGMENTS / LSR_SEG_BUDGET_MB knobs: 0 = the
+// call takes the two-phase path.  The segments sit BEHIND everything else in the layout, so no other offset depends
+// on it.
+uint32_t segment_capacity(const lsr_dims &d);
+struct SegOut {            // kernel argument of the projection kernels
+    uint64_t *keys;        // [V*T][cap] (nullptr: two-phase binning)
+    uint32_t cap;
+    uint32_t key_shift;    // IndexPacking::key_shift
+};
+
 inline GeomLayout geom_layout(const lsr_dims &d) {
     GeomLayout L;
     const size_t VG = (size_t)d.num_views * (size_t)d.num_gaussians;
@@ -108,6 +131,8 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     L.tile_order = o; o = align_up(o + 2 * VT * 4);   // work items (see kItem*), costliest first
     L.half_count = o; o = align_up(o + 2 * VT * 4);   // entries of the two half-tile render lists of every (view, tile)
     L.sh_clamp = o; o = align_up(o + VG);             // per (view, Gaussian): colour channels clamped at 0 (sh.hip)
+    L.seg_cap = segment_capacity(d);
+    L.seg_keys = o; o = align_up(o + VT * (size_t)L.seg_cap * 8);
     L.total = o;
     return L;
 }
@@ -213,13 +238,17 @@ struct FoldedScan {
     uint32_t *host_words; uint32_t host_seq;
     uint32_t capacity;
     uint32_t *tile_start, *tile_order;     // filled in by launch_preprocess
+    uint32_t seg_cap;                      // single-pass binning: keys per tile segment (a longer list = overflow); else UINT32_MAX
 };
 inline bool fold_tile_scan(const lsr_dims &d) {
     return d.num_gaussians > 0 && (int64_t)d.num_views * num_tiles(d) <= kFoldTiles && env_int("LSR_FOLD_SCAN", 1) != 0;
 }
+// seg: single-pass binning — the kernel writes the sort keys into the geometry workspace's tile segments (see
+// segment_capacity); the caller then skips k_scatter (launch_binning's `seg`)
 hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, const FoldedScan &fs,
-                             hipStream_t s);
-hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_words, uint32_t host_seq, uint32_t pair_capacity, hipStream_t s);
+                             bool seg, hipStream_t s);
+hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_words, uint32_t host_seq, uint32_t pair_capacity,
+                            uint32_t seg_cap, hipStream_t s);
 hipError_t launch_pack_view(const float *viewmatrix, const float *projmatrix, const float *campos, const float *bg,
                             float tanfovx, float tanfovy, const float *tanfovx_dev, const float *tanfovy_dev, float *out,
                             hipStream_t s);
@@ -263,7 +292,7 @@ hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const cha
 // device_counts: the pair count / longest list are NOT known on the host (no-sync forward):
 // `num_pairs` is then the workspace capacity and `max_tile_pairs` only a hint for the sort variant
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
-                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts);
+                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts, bool seg);
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                  const char *bin, int64_t num_pairs, char *img, const lsr_outputs &out,
                                  hipStream_t s);

@@ -25,10 +25,21 @@ constexpr int kPreItems = 8;  // (Gaussian, view) items per thread: 2048 per blo
 // views, so a shared scene is read V / VB times instead of V times (269 of the kernel's
 // 578 MB were per-view re-reads of the scene from L2/MALL).  Items per thread shrink by the same
 // factor, so the grid keeps its size.
-template <int COLOR_MODE, bool LDS_HIST, int VB, bool FMA>
+//
+// SEG (round 5, single-pass binning: lsr_internal.h segment_capacity): the workgroup also EMITS the sort keys of its
+// items.  When all its items are projected, the LDS histogram holds its pair count per (view, tile); the one global
+// atomic per non-empty counter that used to add the count to the tile's total now RETURNS the old total — the
+// workgroup's first slot in the tile's fixed-capacity key segment — and a second pass over the workgroup's own binning
+// records (12 bytes each, written a few microseconds earlier by the same thread: L2 hits, and a thread only ever reads
+// what it wrote itself) places `depth << 32 | index << 8 | sub-block code` at segment[base + LDS cursor++].  This is
+// k_scatter's body without its launch, without the machine-wide re-read of the records from HBM and without the wait
+// for the tile scan in front of it; the order of the keys inside a segment is whatever the atomics produce, as before
+// (k_sort_tiles sorts distinct 64-bit keys).
+template <int COLOR_MODE, bool LDS_HIST, int VB, bool FMA, bool SEG>
 __global__ void __launch_bounds__(kPreThreads, 6)   // six waves per SIMD (80 VGPRs): the kernel streams, occupancy hides its latencies
 k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *__restrict__ binrec, int narrow,
-             int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count, uint32_t *header, FoldedScan fs, int kItems) {
+             int32_t *__restrict__ radii, uint32_t *__restrict__ tile_count, uint32_t *header, FoldedScan fs, int kItems, SegOut seg) {
+    static_assert(!SEG || LDS_HIST, "the key emission reserves its slots from the LDS histogram");
     extern __shared__ uint32_t s_hist[];   // [VB][T] pair counts
     // 64-byte records are staged here and stored by the whole block as one contiguous run
     // (lane-contiguous 16-byte stores) instead of 4 strided partial-line stores per thread.
@@ -180,12 +191,62 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
             }
         }
     }
-    if (LDS_HIST) {
+    if (LDS_HIST && !SEG) {
         __syncthreads();
         for (int t = threadIdx.x; t < VB * T; t += kPreThreads) {
             const int v = v0 + t / T;
             const uint32_t c = s_hist[t];
             if (c && v < d.num_views) atomicAdd(&tile_count[(size_t)v * T + (t % T)], c);
+        }
+    }
+    if (SEG) {
+        // ---- reserve: count -> first slot of this workgroup in the tile's segment (the counter becomes the cursor) ----
+        __syncthreads();
+        for (int t = threadIdx.x; t < VB * T; t += kPreThreads) {
+            const int v = v0 + t / T;
+            const uint32_t c = s_hist[t];
+            uint32_t first = 0u;
+            if (c && v < d.num_views)
+                first = __hip_atomic_fetch_add(&tile_count[(size_t)v * T + (t % T)], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_hist[t] = first;
+        }
+        __syncthreads();
+        // ---- emit: the same (Gaussian, view) items in the same order; a thread reads back the records it wrote ----
+        const uint32_t cap = seg.cap;
+#pragma unroll 1
+        for (int it = 0; it < kItems; ++it) {
+            const int chunk0 = base + it * kPreThreads;
+            if (chunk0 >= G) break;   // block-uniform
+            const int i = chunk0 + threadIdx.x;
+            const bool in_range = i < G;
+            const size_t ii = in_range ? (size_t)i : 0;
+            // the records of this Gaussian in the block's views: unconditional loads at clamped addresses, all in
+            // flight together (a load under a per-lane condition is waited for at the join)
+            uint3 br[VB];
+#pragma unroll
+            for (int vb = 0; vb < VB; ++vb) {
+                const int vc = min(v0 + vb, d.num_views - 1);
+                br[vb] = *(const uint3 *)(binrec + ((size_t)vc * G + ii) * sizeof(BinRec));
+            }
+#pragma unroll
+            for (int vb = 0; vb < VB; ++vb) {
+                const int v = v0 + vb;
+                const uint32_t rc = (in_range && v < d.num_views) ? br[vb].x : 0u;   // (a culled record holds an empty rectangle)
+                const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff, y1 = rc >> 24;
+                const uint64_t key = ((uint64_t)br[vb].y << 32) | ((uint32_t)i << seg.key_shift);
+                const uint32_t sp = br[vb].z;
+                uint32_t *cur = s_hist + vb * T;
+                const uint32_t seg0 = (uint32_t)v * (uint32_t)T;
+                for (int y = y0; y < y1; ++y)
+                    for (int x = x0; x < x1; ++x) {
+                        const int t = y * gx + x;
+                        const uint32_t pos = atomicAdd(&cur[t], 1u);
+                        const uint32_t code = seg.key_shift ? span_code(sp, x - x0, y - y0) : 0u;
+                        // clamped, not tested (a store under a per-lane condition cost k_scatter 17 %): the surplus keys of
+                        // an overfull segment land on its last slot, and the tile scan flags the overflow
+                        seg.keys[(size_t)((seg0 + (uint32_t)t) * cap + min(pos, cap - 1u))] = key | code;
+                    }
+            }
         }
     }
     // ---- the tile scan, folded in (round 4; it used to be a kernel of its own between this one and k_scatter): the LAST
@@ -222,7 +283,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
             }
             __syncthreads();
             tile_scan_block<kPreThreads, 0, false>(s_counts, fs.tile_start, header, HostMirror{fs.host_words, fs.host_seq},
-                                                   fs.tile_order, N, fs.capacity, s_scan);
+                                                   fs.tile_order, N, fs.capacity, s_scan, fs.seg_cap);
         }
     }
 }
@@ -240,7 +301,7 @@ hipError_t launch_clear(void *ptr, size_t bytes, hipStream_t s) {
 }
 
 hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, const FoldedScan &fs_in,
-                             hipStream_t s) {
+                             bool seg_mode, hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const int T = (int)num_tiles(d);
     // zero header + tile_count + tile_cursor (adjacent).  A kernel rather than hipMemsetAsync: the
@@ -260,7 +321,8 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     // workgroups per CU — a single 300 k view was 147 workgroups of 8 sequential Gaussians per thread on 256 CUs
     const int64_t yblocks = (d.num_views + vb - 1) / vb;
     const int64_t fill = ((int64_t)d.num_gaussians * yblocks + (int64_t)kPreThreads * 2 * device_cus() - 1) / ((int64_t)kPreThreads * 2 * device_cus());
-    const int items = (int)std::max<int64_t>(1, std::min<int64_t>(kPreItems / vb, fill));
+    const int pre_items = std::max(1, env_int("LSR_PRE_ITEMS", kPreItems));   // (development knob: (Gaussian, view) items per thread and histogram flush)
+    const int items = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1, pre_items / vb), fill));
     dim3 grid((d.num_gaussians + kPreThreads * items - 1) / (kPreThreads * items), (unsigned)yblocks);
     float *rec = (float *)(geom + L.rec);
     char *binrec = geom + L.bin;
@@ -272,7 +334,16 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     const bool lds = (size_t)T * vb <= 4096;
     const size_t shm = lds ? (size_t)T * vb * 4 : 0;
     const bool fma = projection_contraction();
-#define LSR_PRE3(CM, LH, VBV, FM) hipLaunchKernelGGL((k_preprocess<CM, LH, VBV, FM>), grid, dim3(kPreThreads), shm, s, d, in, rec, RF, binrec, narrow, radii, tc, (uint32_t *)(geom + L.header), fs, items)
+    // single-pass binning: the caller asks for it only when segment_capacity(d) > 0, which implies byte tile coordinates
+    // and T <= 1024 (the LDS histogram of up to 4 views)
+    SegOut so{nullptr, 0u, index_packing(d).key_shift};
+    if (seg_mode) {
+        if (!lds || !narrow || L.seg_cap == 0) return hipErrorInvalidValue;
+        so.keys = (uint64_t *)(geom + L.seg_keys); so.cap = L.seg_cap;
+    }
+    fs.seg_cap = seg_mode ? L.seg_cap : 0xFFFFFFFFu;
+#define LSR_PRE4(CM, LH, VBV, FM, SG) hipLaunchKernelGGL((k_preprocess<CM, LH, VBV, FM, SG>), grid, dim3(kPreThreads), shm, s, d, in, rec, RF, binrec, narrow, radii, tc, (uint32_t *)(geom + L.header), fs, items, so)
+#define LSR_PRE3(CM, LH, VBV, FM) do { if (LH && seg_mode) LSR_PRE4(CM, LH, VBV, FM, LH); else LSR_PRE4(CM, LH, VBV, FM, false); } while (0)
 #define LSR_PRE2(CM, LH, VBV) do { if (fma) LSR_PRE3(CM, LH, VBV, true); else LSR_PRE3(CM, LH, VBV, false); } while (0)
 #define LSR_PRE(CM)                                                                              \
     do {                                                                                         \
@@ -286,6 +357,7 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
 #undef LSR_PRE
 #undef LSR_PRE2
 #undef LSR_PRE3
+#undef LSR_PRE4
     prof_end(kStPreprocess, s);
     return hipGetLastError();
 }

@@ -754,8 +754,11 @@ hipError_t launch_preprocess_sh(const lsr_dims &d, const lsr_inputs &in, char *g
     const int64_t nchunks = (d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE;
     a.chunks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (nchunks + std::max<int64_t>(resident, 1) - 1) / std::max<int64_t>(resident, 1)));
     const size_t coef_words = (size_t)p.offF + (size_t)LSR_WAVE * p.ks[1];
-    a.lds_hist = (size_t)Vg * T <= 8192 ? 1 : 0;
     a.hist_off = (int)((coef_words + 3) & ~(size_t)3);
+    // the privatised tile histogram only while the whole dynamic allocation stays within the 64 KB a launch gets
+    // without a function attribute (degree-4 colour + 13 latent channels at degree 2 take 50 KB of coefficient rows:
+    // with 8192 counters behind them the launch would ask for 82 KB); larger calls count with global atomics
+    a.lds_hist = ((size_t)Vg * T <= 8192 && ((size_t)a.hist_off + (size_t)Vg * T) * 4 <= 65536) ? 1 : 0;
     size_t shm = ((size_t)a.hist_off + (a.lds_hist ? (size_t)Vg * T : 0)) * 4;
     if (a.fs.enabled) shm = std::max<size_t>(shm, (size_t)kFoldTiles * 4);            // the scan stages the counts at the start of the allocation
     const dim3 grid((unsigned)((nchunks + a.chunks - 1) / a.chunks), groups), block(kShThreads);

@@ -1,0 +1,99 @@
+"""The EXACT launches bench.py times, against the oracle (VERDICT r4 "Next round" 4a).
+
+Every other oracle comparison at 4 payload channels runs one or two views, which the launcher routes to
+``k_render_fwd_small`` and to the list-splitting backward; the 16-view headline instances
+(``k_render_fwd<4, 12>``, the unsplit ``k_render_bwd<4, false, 16, 1, false>``, 4 views per workgroup in
+``k_preprocess`` with the single-pass binning of round 5) reached the oracle only through bitwise-equivalence hops.
+Here the bench's own inputs (``bench.build_inputs``: 16 views of one 300 000-Gaussian scene, scene-level inputs, the camera
+table built on the device) go through ``rasterize_views`` once, forward and backward, and
+  * the images of two views, their tile offsets and their depth-sorted lists (bit for bit),
+  * the view-SUMMED gradients of every scene-level input (upstream gradient on four of the sixteen views: the same
+    16-view launch, a quarter of the oracle time)
+are compared with the oracle at full size."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+G, V, S = 300_000, 16, 256
+IMAGE_VIEWS = (3, 12)
+GRAD_VIEWS = (0, 5, 10, 15)
+
+
+def test_bench_shape_16_views_against_oracle(hip_device):
+    import bench
+    from latentsplat_amd import _lib
+    from latentsplat_amd.rasterizer import LAST_STATS, rasterize_views
+    dev = hip_device
+    inp = bench.build_inputs(G, V, S, dev, 1234)
+    leaves = {k: inp[k].detach().clone().requires_grad_(True) for k in ("means", "cov", "opac", "features")}
+    _lib.profile_read(); _lib.profile_enable(True)
+    out = rasterize_views(inp["views"], S, S, 0, leaves["means"], leaves["cov"], leaves["opac"], features=leaves["features"])
+    gen = torch.Generator().manual_seed(31)
+    g_feat = torch.zeros((V, 4, S, S))
+    for v in GRAD_VIEWS:
+        g_feat[v] = torch.randn((4, S, S), generator=gen)
+    out[1].backward(g_feat.to(dev))
+    torch.cuda.synchronize(dev)
+    _lib.profile_enable(False)
+    launched = {k for k, (ms, n) in _lib.profile_read().items() if n}
+    assert {"preprocess", "sort_tiles", "render_forward", "render_backward", "preprocess_backward"} <= launched
+    P_total = LAST_STATS["num_pairs"]
+
+    # host statement of the same call with the SAME camera table (read back from the device)
+    views_cpu = inp["views"].cpu()
+    cpu = {k: inp[k].detach().cpu().clone().requires_grad_(True) for k in ("means", "cov", "opac", "features")}
+    n = lambda t: None if t is None else t.detach().contiguous().numpy()
+    lay_views = sorted(set(IMAGE_VIEWS) | set(GRAD_VIEWS))
+    frag, P_seen = [], 0
+    # canonical lists of the checked views straight from the workspaces of a C-ABI run of the same 16-view call
+    # (boundary-level inputs: per-view scaled means / covariances, what to_boundary computes)
+    for v in lay_views:
+        m, c6, op, _, _, ft = util.to_boundary(views_cpu, v, cpu["means"], cpu["cov"], cpu["opac"], None, None, cpu["features"], None, False)
+        vw = views_cpu[v]
+        view = util.orc.View(S, S, float(vw[35]), float(vw[36]), vw[37:40].numpy(), vw[0:16].numpy().reshape(4, 4),
+                             vw[16:32].numpy().reshape(4, 4), vw[32:35].numpy(), 0)
+        o = util.orc.forward(view, n(m), n(c6), n(op), None, None, n(ft))
+        assert o["P"] > G
+        P_seen += o["P"]
+        np.testing.assert_array_equal(out[4][v].cpu().numpy(), o["radii"], err_msg=f"radii[view {v}]")
+        if v in IMAGE_VIEWS:
+            util.assert_close_except_fragile(out[1][v].detach().cpu().numpy(), o["feature"], o, 1e-4, f"headline feature[view {v}]")
+            util.assert_close_except_fragile(out[2][v].detach().cpu().numpy(), o["mask"], o, 1e-4, f"headline mask[view {v}]")
+            dscale = max(1.0, float(np.abs(o["depth"]).max()))
+            zmax = float(o["gdepth"][o["radii"] > 0].max(initial=1.0))
+            util.assert_close_except_fragile(out[3][v].detach().cpu().numpy(), o["depth"], o, 1e-4 * dscale, f"headline depth[view {v}]",
+                                             flip_bound=2e-2 * max(dscale, zmax))
+        if v in GRAD_VIEWS:
+            frag.append(util.fragile_gaussians(o, S))
+            b = util.orc.backward(view, n(m), n(c6), n(op), None, None, n(ft), o, None, g_feat[v].numpy())
+            torch.autograd.backward([m, c6, op, ft], [torch.from_numpy(np.ascontiguousarray(b[k]))
+                                                      for k in ("means3D", "cov3D", "opacities", "features")])
+    assert P_seen < P_total          # (the other ten views' pairs are in the device count)
+    direct = np.unique(np.concatenate([f[0] for f in frag]))
+    behind = np.setdiff1d(np.unique(np.concatenate([f[1] for f in frag])), direct)
+    for k in ("means", "cov", "opac", "features"):
+        got, want = leaves[k].grad.cpu().numpy(), cpu[k].grad.numpy()
+        util.assert_grad_close_except_fragile(got.reshape(G, -1), want.reshape(G, -1), direct, behind, 1e-4,
+                                              f"headline (16 views) dL/d{k}", clean_tol=2e-5, row_tol=2e-3 if k == "cov" else 1e-4)
+
+
+def test_bench_shape_sorted_lists_bit_exact(hip_device):
+    """The same 16-view, shared-scene call through the C ABI: tile offsets and depth-sorted lists of two views bit for
+    bit (k_preprocess with four views per workgroup emitting the keys, the 4096-key first sort tier)."""
+    from latentsplat_amd.synthetic import make_scene
+    sc = make_scene(G, image_size=S, views=V, color_sh_degree=None, feature_channels=4, feature_sh_degree=0, seed=1234)
+    bi = util.boundary_inputs(sc, S, S)
+    # one scene shared by the views needs view-independent means: scale-invariant rendering scales them per view
+    # (1 / near), and the synthetic scene's near planes are equal, so view 0's scaled scene serves all sixteen
+    assert float((bi["means"] - bi["means"][:1]).abs().max()) == 0.0 and float((bi["cov6"] - bi["cov6"][:1]).abs().max()) == 0.0
+    run = util.HipRun(bi, hip_device, shared_means=True)
+    ts, pl, T = run.tile_start(), run.point_list(), run.T
+    for v in IMAGE_VIEWS:
+        o = util.oracle_forward(bi, v)
+        np.testing.assert_array_equal(run.radii[v].cpu().numpy(), o["radii"])
+        np.testing.assert_array_equal(np.diff(ts[v * T:(v + 1) * T + 1]), o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0])
+        np.testing.assert_array_equal(pl[ts[v * T]:ts[(v + 1) * T]], o["point_list"])
+        util.assert_close_except_fragile(run.feat_out[v].cpu().numpy(), o["feature"], o, 1e-4, f"headline abi feature[view {v}]")

@@ -197,6 +197,10 @@ print("HASH", h.hexdigest())
     variants = {"default": {}, "scan_kernel": dict(LSR_FOLD_SCAN="0"), "event_wait": dict(LSR_HOST_POLL="0"),
                 "scan_kernel_event_wait": dict(LSR_FOLD_SCAN="0", LSR_HOST_POLL="0"),
                 "sort_natural_order": dict(LSR_SORT_LPT="0"),
+                # round 5: the projection kernel writes the sort keys into fixed-capacity tile segments itself (default) or
+                # leaves them to k_scatter behind the tile scan; a small segment capacity makes every call of this scene
+                # overflow — the synchronous forward then re-runs itself on the two-phase path
+                "two_phase_binning": dict(LSR_SEGMENTS="0"),
                 "fwd_row_items": dict(LSR_FWD_ROWS="1"), "fwd_half_tile_items": dict(LSR_FWD_ROWS="0"),
                 # the backward of this small shape splits every half-tile list between four waves (each walks the entries in
                 # front of its share for the per-pixel state only): the same gradient records as one wave per list

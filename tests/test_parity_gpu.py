@@ -384,6 +384,9 @@ def test_fused_scene_inputs_match_oracle(hip_device, cfg, shared):
     dict(G=2500, size=48, b=1, v=6, color_sh_degree=3, feature_channels=None),                       # colour only, > 4 views per workgroup
     dict(G=1800, size=48, b=2, v=1, color_sh_degree=None, feature_channels=8, feature_sh_degree=1),  # latent harmonics only, 8 channels
     dict(G=900, size=32, b=1, v=2, color_sh_degree=1, feature_channels=20, feature_sh_degree=1),     # 23 channels: 64-float records
+    # the largest coefficient rows (degree-4 colour + 13 latent channels at degree 2: 50 KB of LDS) next to 8 x 1024 tile
+    # counters: the launch must not ask for more dynamic LDS than it may without a function attribute
+    dict(G=1100, size=512, b=1, v=8, color_sh_degree=4, feature_channels=13, feature_sh_degree=2),
 ])
 def test_fused_projection_and_sh_kernel_equals_the_two_kernel_path(hip_device, cfg):
     """Calls whose payload is harmonics only and whose views share their inputs run the projection and the SH payload
@@ -411,14 +414,16 @@ def test_fused_projection_and_sh_kernel_equals_the_two_kernel_path(hip_device, c
     deg = 0 if fields["shs"] is None else int(round(fields["shs"].shape[-1] ** 0.5)) - 1
     gen = torch.Generator().manual_seed(5)
     results = {}
-    for fuse in (1, 0):
-        _lib.set_knob("LSR_FUSE_SH", fuse)
-        for mode, kw in (("sync", {}), ("nosync", dict(pair_capacity=4 * b * v * G + 16, max_tile_hint=4096))):
-            leaf = {k: (None if x is None else x.to(dev).clone().requires_grad_(True)) for k, x in fields.items()}
-            out = rasterize_views(views, H, W, deg, leaf["means"], leaf["cov"], leaf["opac"], shs=leaf["shs"],
-                                  feature_sh=leaf["fsh"], shs_channel_major=True, **kw)
-            results[(fuse, mode)] = [None if o is None else o.detach().clone() for o in out]
-    _lib.set_knob("LSR_FUSE_SH", 1)
+    try:
+        for fuse in (1, 0):
+            _lib.set_knob("LSR_FUSE_SH", fuse)
+            for mode, kw in (("sync", {}), ("nosync", dict(pair_capacity=4 * b * v * G + 16, max_tile_hint=4096))):
+                leaf = {k: (None if x is None else x.to(dev).clone().requires_grad_(True)) for k, x in fields.items()}
+                out = rasterize_views(views, H, W, deg, leaf["means"], leaf["cov"], leaf["opac"], shs=leaf["shs"],
+                                      feature_sh=leaf["fsh"], shs_channel_major=True, **kw)
+                results[(fuse, mode)] = [None if o is None else o.detach().clone() for o in out]
+    finally:
+        _lib.set_knob("LSR_FUSE_SH", 1)
     ref = results[(0, "sync")]
     for key, res in results.items():
         for name, a, r in zip(("colour", "feature", "mask", "depth", "radii"), res, ref):
@@ -535,3 +540,65 @@ def test_color_sh_reference_axis_convention(hip_device):
         orc.set_sh_convention("3dgs")
     assert np.abs(color - default_color).max() > 1e-3
     assert np.array_equal(run()[0], default_color)
+
+
+def test_single_pass_binning_equals_two_phase_and_falls_back_on_overflow(hip_device):
+    """Round 5: k_preprocess writes the sort keys into fixed-capacity per-tile segments itself (no k_scatter).  The
+    canonical lists, the half-tile render lists and the images must be bit for bit those of the two-phase path
+    (LSR_SEGMENTS=0); a tile list longer than a segment (forced here with LSR_SEG_CAP) makes the synchronous forward
+    re-run itself on the two-phase path — same results — and the no-sync forward raise the overflow flag."""
+    from latentsplat_amd import _lib
+    from latentsplat_amd.rasterizer import last_forward_status, rasterize_views
+    for case in (dict(G=9_000, size=(80, 112), views=3, color_sh_degree=1, feature_channels=4),
+                 dict(G=2_500, size=64, views=5, color_sh_degree=None, feature_channels=8, sigma_px=(3.0, 20.0), opacity_scale=1.0)):
+        case = dict(case)
+        size = case.pop("size")
+        H, W = size if isinstance(size, tuple) else (size, size)
+        sc = util.make_scene(case.pop("G"), image_size=max(H, W), **case)
+        bi = util.boundary_inputs(sc, H, W, bg=(0.1, 0.3, 0.5))
+        runs = {}
+        try:
+            for name, seg, cap in (("two_phase", 0, 0), ("segments", 1, 0), ("overflow_fallback", 1, 64)):
+                _lib.set_knob("LSR_SEGMENTS", seg)
+                _lib.set_knob("LSR_SEG_CAP", cap)
+                r = util.HipRun(bi, hip_device)
+                runs[name] = dict(P=r.P, maxtile=r.maxtile, ts=r.tile_start(), pl=r.point_list(), hc=r.half_count(), hl=r.half_list(),
+                                  img=[None if t is None else t.clone() for t in (r.color_out, r.feat_out, r.mask_out, r.depth_out)],
+                                  nc=r.n_contrib(), radii=r.radii.clone())
+            assert runs["two_phase"]["maxtile"] > 64, "the forced capacity must be exceeded for the fallback leg to mean anything"
+            a = runs["two_phase"]
+            for name in ("segments", "overflow_fallback"):
+                b = runs[name]
+                assert (a["P"], a["maxtile"]) == (b["P"], b["maxtile"])
+                np.testing.assert_array_equal(a["ts"], b["ts"], err_msg=name + ": tile offsets")
+                np.testing.assert_array_equal(a["pl"], b["pl"], err_msg=name + ": canonical lists")
+                np.testing.assert_array_equal(a["hc"], b["hc"], err_msg=name + ": half-list lengths")
+                # (the half-list area is only defined inside the counted prefixes)
+                T = a["hc"].shape[0]
+                for vt in range(T):
+                    s0, n = a["ts"][vt], a["ts"][vt + 1] - a["ts"][vt]
+                    for h in range(2):
+                        c = a["hc"][vt, h]
+                        np.testing.assert_array_equal(a["hl"][2 * s0 + h * n: 2 * s0 + h * n + c], b["hl"][2 * s0 + h * n: 2 * s0 + h * n + c])
+                np.testing.assert_array_equal(a["nc"], b["nc"], err_msg=name + ": n_contrib")
+                assert torch.equal(a["radii"], b["radii"])
+                for x, y in zip(a["img"], b["img"]):
+                    assert (x is None) == (y is None) and (x is None or torch.equal(x, y)), name + ": images"
+            # the no-sync forward cannot fall back: it reports the overflow
+            _lib.set_knob("LSR_SEGMENTS", 1)
+            views = util.view_table(bi, hip_device)
+            t = lambda x: x.to(hip_device).contiguous()
+            kw = dict(features=t(bi["features"]), pair_capacity=2 * a["P"] + 64, max_tile_hint=int(a["maxtile"]))
+            if bi["shs"] is not None:
+                kw["shs"] = t(bi["shs"])
+            for cap, want in ((0, False), (64, True)):
+                _lib.set_knob("LSR_SEG_CAP", cap)
+                with torch.no_grad():
+                    out = rasterize_views(views, H, W, bi["sh_degree"], t(bi["means"]), t(bi["cov6"]), t(bi["opac"]), **kw)
+                st = last_forward_status()
+                assert st["overflow"] == want and st["num_pairs"] == a["P"], (cap, st)
+                if not want:
+                    assert torch.equal(out[1], a["img"][1]) and torch.equal(out[2], a["img"][2])
+        finally:
+            _lib.set_knob("LSR_SEGMENTS", 1)
+            _lib.set_knob("LSR_SEG_CAP", 0)
