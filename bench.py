@@ -866,7 +866,8 @@ def main():
             torch_oracle=pick(cpu.get("torch_oracle"), ("value", "unit", "cores", "kind")))
         line["fwdbwd"] = pick(fb, ("views_per_s", "ms_per_view", "ms_per_step"))
         line["roofline_bwd"] = pick(roofline_bwd, ("kernel", "achieved", "frac", "algorithmic_bytes_per_launch", "launch_ms"))
-        line["parity_gate"] = pick(gate, ("ok", "lists_bit_exact", "max_abs_err", "pixels_over_tol", "fragile_pixels_excluded", "views_checked", "tol"))
+        # (not through r4: the error is ~1e-6 and would print as 0.0)
+        line["parity_gate"] = None if gate is None else {k: gate[k] for k in ("ok", "lists_bit_exact", "max_abs_err", "pixels_over_tol", "fragile_pixels_excluded", "views_checked", "tol")}
         line["roofline_path"] = pick(path, ("algorithmic_bytes_per_view", "achieved", "frac", "frac_shared_scene", "pairs_per_view"))
         line["roofline_path_fwdbwd"] = pick(path_fb, ("algorithmic_bytes_per_view", "achieved", "frac", "frac_shared_scene"))
         line["roofline_valu"] = pick(roofline_valu, ("valu_insts_per_launch", "frac"))

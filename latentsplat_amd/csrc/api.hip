@@ -442,39 +442,32 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
     const bool mapped = h_event != nullptr;
     const bool fold = fold_tile_scan(*d);
     // Single-pass binning when the dims allow it (segment_capacity): the projection kernel writes the sort keys itself.
-    // Should a tile list turn out longer than a key segment (the host reads the longest list below anyway), the call is
-    // run again on the two-phase path, whose workspace is sized after the fact — rare (more than 8192 Gaussians over
-    // one tile at the usual sizes), correct, and invisible to the caller: lsr_forward_render takes the same decision
-    // from the same two numbers.
-    const uint32_t seg_cap = segment_capacity(*d);
+    // A tile list longer than its key segment is no failure: lsr_forward_render then launches the scatter for exactly
+    // those tiles (the host reads the longest list below anyway).
+    const bool seg = segment_capacity(*d) != 0u;
     uint32_t hdr[2] = {0, 0};
-    for (int attempt = seg_cap ? 0 : 1; attempt < 2; ++attempt) {
-        const bool seg = attempt == 0;
-        if (++h_seq == 0u) h_seq = 1u;                        // 0 is what a fresh buffer holds
-        FoldedScan fs{};
-        fs.enabled = fold ? 1 : 0;
-        fs.host_words = mapped ? h_hdr_dev : nullptr; fs.host_seq = h_seq; fs.capacity = 0xFFFFFFFFu; fs.seg_cap = 0xFFFFFFFFu;
-        if (fused_preprocess_sh(*d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(*d, *in, geom, radii, fs, s));
-        else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, fs, seg, s));
-        if (fold && mapped) LSR_HIP(hipEventRecord(h_event, s));
-        rc = sh_forward_inline(*d, *in, geom, s);   // view-dependent payload of calls the fused kernel does not cover
+    if (++h_seq == 0u) h_seq = 1u;                        // 0 is what a fresh buffer holds
+    FoldedScan fs{};
+    fs.enabled = fold ? 1 : 0;
+    fs.host_words = mapped ? h_hdr_dev : nullptr; fs.host_seq = h_seq; fs.capacity = 0xFFFFFFFFu;
+    if (fused_preprocess_sh(*d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(*d, *in, geom, radii, fs, s));
+    else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, fs, seg, s));
+    if (fold && mapped) LSR_HIP(hipEventRecord(h_event, s));
+    rc = sh_forward_inline(*d, *in, geom, s);   // view-dependent payload of calls the fused kernel does not cover
+    if (rc) return rc;
+    if (!fold) {
+        LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, mapped ? h_hdr_dev : nullptr, h_seq, 0xFFFFFFFFu, s));
+        if (mapped) LSR_HIP(hipEventRecord(h_event, s));
+    }
+    bool have = false;
+    if (mapped) {
+        rc = wait_pair_count(h_hdr, h_seq, h_event, have);
         if (rc) return rc;
-        if (!fold) {
-            LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, mapped ? h_hdr_dev : nullptr, h_seq, 0xFFFFFFFFu, seg ? seg_cap : 0xFFFFFFFFu, s));
-            if (mapped) LSR_HIP(hipEventRecord(h_event, s));
-        }
-        bool have = false;
-        hdr[0] = hdr[1] = 0;
-        if (mapped) {
-            rc = wait_pair_count(h_hdr, h_seq, h_event, have);
-            if (rc) return rc;
-            if (have) { hdr[0] = h_hdr[0]; hdr[1] = h_hdr[1]; }
-        }
-        if (!have) {
-            LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));
-            LSR_HIP(hipStreamSynchronize(s));
-        }
-        if (!seg || hdr[1] <= seg_cap) break;       // every list fits its segment (or this was the two-phase run)
+        if (have) { hdr[0] = h_hdr[0]; hdr[1] = h_hdr[1]; }
+    }
+    if (!have) {
+        LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));
+        LSR_HIP(hipStreamSynchronize(s));
     }
     *num_pairs_host = (int64_t)hdr[0];
     *max_tile_pairs_host = (int32_t)hdr[1];
@@ -496,10 +489,9 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
     if (num_pairs < 0 || max_tile_pairs < 0) return LSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    // binning + compositing.  Single-pass binning iff lsr_forward_prepare used it: the dims allow it and no list
-    // outgrew its segment (the decision prepare took from the same two numbers)
-    const uint32_t seg_cap = segment_capacity(*d);
-    const bool seg = seg_cap != 0u && (uint32_t)max_tile_pairs <= seg_cap;
+    // binning + compositing.  Single-pass binning iff lsr_forward_prepare used it (the same pure function of the dims);
+    // `max_tile_pairs` tells launch_binning whether any tile outgrew its key segment and needs the fallback scatter
+    const bool seg = segment_capacity(*d) != 0u;
     return forward_tail(*d, *in, (char *)geom_ws, (char *)bin_ws, (char *)img_ws, num_pairs, max_tile_pairs, *out, s, false, seg);
 }
 
@@ -525,19 +517,17 @@ int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     char *geom = (char *)geom_ws;
     // the same stage sequence as prepare + render; nothing between the launches waits for the device
     const bool fold = fold_tile_scan(*d);
-    // single-pass binning whenever the dims allow it; a list longer than its key segment raises the overflow flag of
-    // lsr_forward_status like a pair count beyond `pair_capacity` does (re-run such a scene with LSR_SEGMENTS=0 or
-    // through the synchronous forward, which falls back by itself)
-    const uint32_t seg_cap = segment_capacity(*d);
-    const bool seg = seg_cap != 0u;
+    // single-pass binning whenever the dims allow it; the fallback scatter for tiles that outgrow their key segments is
+    // always launched here (its workgroups leave at once when the device's longest list fits)
+    const bool seg = segment_capacity(*d) != 0u;
     FoldedScan fs{};
     fs.enabled = fold ? 1 : 0;
-    fs.capacity = (uint32_t)pair_capacity; fs.seg_cap = 0xFFFFFFFFu;
+    fs.capacity = (uint32_t)pair_capacity;
     if (fused_preprocess_sh(*d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(*d, *in, geom, out->radii, fs, s));
     else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, fs, seg, s));
     rc = sh_forward_inline(*d, *in, geom, s);
     if (rc) return rc;
-    if (!fold) LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, 0u, (uint32_t)pair_capacity, seg ? seg_cap : 0xFFFFFFFFu, s));
+    if (!fold) LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, 0u, (uint32_t)pair_capacity, s));
     return forward_tail(*d, *in, geom, (char *)bin_ws, (char *)img_ws, pair_capacity, max_tile_hint, *out, s, true, seg);
 }
 

@@ -35,19 +35,18 @@ constexpr int kScanRegs = 8;   // counts per thread kept in registers (4 at 1024
 
 __global__ void __launch_bounds__(kScanThreads)
 k_tile_scan(const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *header,
-            uint32_t *host_words, uint32_t host_seq, uint32_t *__restrict__ order, int N, uint32_t capacity, uint32_t seg_cap) {
+            uint32_t *host_words, uint32_t host_seq, uint32_t *__restrict__ order, int N, uint32_t capacity) {
     __shared__ TileScanShared<kScanThreads> s_scan;
-    tile_scan_block<kScanThreads, kScanRegs, false>(count, start, header, HostMirror{host_words, host_seq}, order, N, capacity, s_scan, seg_cap);
+    tile_scan_block<kScanThreads, kScanRegs, false>(count, start, header, HostMirror{host_words, host_seq}, order, N, capacity, s_scan);
 }
 
-hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_words, uint32_t host_seq, uint32_t pair_capacity,
-                            uint32_t seg_cap, hipStream_t s) {
+hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_words, uint32_t host_seq, uint32_t pair_capacity, hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     const int N = d.num_views * (int)num_tiles(d);
     prof_begin(kStTileScan, s);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kScanThreads), 0, s,
                        (const uint32_t *)(geom + L.tile_count), (uint32_t *)(geom + L.tile_start),
-                       (uint32_t *)(geom + L.header), host_words, host_seq, (uint32_t *)(geom + L.tile_order), N, pair_capacity, seg_cap);
+                       (uint32_t *)(geom + L.header), host_words, host_seq, (uint32_t *)(geom + L.tile_order), N, pair_capacity);
     prof_end(kStTileScan, s);
     return hipGetLastError();
 }
@@ -56,11 +55,18 @@ hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_words,
 constexpr int kScatThreads = 256;
 constexpr int kScatItems = 12;   // most (view, Gaussian) items of one thread; the launcher picks the count
 
+// over_cap != 0 (single-pass binning, round 5): the projection kernel has already written the keys of every tile whose
+// list fits its fixed-capacity segment; this launch only places the pairs of the tiles that do NOT fit
+// (tile_count > over_cap) into their exact segments of the binning workspace — the device-side fallback for overfull
+// tiles.  The synchronous forward launches it when the host has seen such a list, the no-sync forward always (every
+// workgroup leaves at once when the header's longest list fits).
 template <bool LDS_RESERVE, bool NARROW>
 __global__ void __launch_bounds__(kScatThreads, 8)
 k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
           const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ tile_cursor,
-          uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, uint32_t key_shift, unsigned long long *trace) {
+          uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, uint32_t key_shift, unsigned long long *trace,
+          const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ header, uint32_t over_cap) {
+    if (over_cap && header[kHdrMaxTile] <= over_cap) return;   // (uniform) no overfull tile in this call
 #ifdef LSR_ENABLE_TRACE
 #define LSR_STAMP(k) do { if (trace && threadIdx.x == 0) trace[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
 #else
@@ -74,6 +80,7 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
     const size_t vo = (size_t)v * G;
     const uint32_t *ts = tile_start + (size_t)v * T;
     uint32_t *cur = tile_cursor + (size_t)v * T;
+    const uint32_t *tcv = tile_count + (size_t)v * T;
     const int base = (int)(unit % chunks) * (kScatThreads * items);
     // rectangles stay PACKED in registers between the two passes (narrow records: one word, wide: x0 | y0 << 16,
     // x1 | y1 << 16); the empty asm makes each pass unpack its own copy instead of keeping four coordinates
@@ -109,7 +116,10 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
             int x0, y0, x1, y1;
             unpack(it, x0, y0, x1, y1);
             for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) atomicAdd(&s_cnt[y * gx + x], 1u);
+                for (int x = x0; x < x1; ++x) {
+                    if (over_cap && tcv[y * gx + x] <= over_cap) continue;
+                    atomicAdd(&s_cnt[y * gx + x], 1u);
+                }
         }
         __syncthreads();
         LSR_STAMP(2);
@@ -135,6 +145,7 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) {
                 const int t = y * gx + x;
+                if (over_cap && tcv[t] <= over_cap) continue;
                 uint32_t pos;
                 if (LDS_RESERVE) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
                 else pos = ts[t] + atomicAdd(&cur[t], 1u);
@@ -181,7 +192,8 @@ struct HalfOut {
     uint32_t long_cap;        // entries of the array (tiles of the call)
     uint32_t *long_count[2];  // header words
     IndexPacking ip;          // how keys and list entries carry the Gaussian index (lsr_internal.h)
-    uint32_t seg_cap;         // single-pass binning: the keys of tile vt are keys[vt * seg_cap ...] (0: keys[tile_start[vt] ...])
+    uint32_t seg_cap;         // single-pass binning: a list of up to seg_cap keys sits in seg_keys[vt * seg_cap ...] (0: two-phase binning)
+    const uint64_t *seg_keys;
 };
 constexpr int kSortTier2 = 8192;
 __device__ __forceinline__ uint32_t long_tile(const HalfOut &ho, int cls, uint32_t i) {
@@ -305,11 +317,6 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
         if (tid == 0) ho.header[kHdrOverflow] = 1u;
         return;
     }
-    if (ho.seg_cap && n > ho.seg_cap) {           // single-pass binning: the segment could not hold the list (the scan has flagged it): render nothing
-        if (tid < 2) hcnt[tid] = 0;
-        if (tid == 0) ho.header[kHdrOverflow] = 1u;
-        return;
-    }
     if (n > (uint32_t)CAP) {        // for a later tier: a larger LDS variant, or (beyond the largest) the global merge path
         if (tid == 0 && tier == 0) {
             const int cls = n > (uint32_t)kSortTier2 ? 1 : 0;
@@ -318,7 +325,9 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
         }
         return;
     }
-    const uint64_t *src = ho.seg_cap ? keys + vt * (size_t)ho.seg_cap : keys + start;
+    // single-pass binning: a list that fits its fixed-capacity segment was written there by the projection kernel; an
+    // overfull tile's keys were placed at its exact offsets of the binning workspace by the fallback scatter
+    const uint64_t *src = (ho.seg_cap && n <= ho.seg_cap) ? ho.seg_keys + vt * (size_t)ho.seg_cap : keys + start;
     if (n == 1) {
         if (tid == 0) {
             const uint32_t w = (uint32_t)src[0], idx = key_index(ho, w);
@@ -593,7 +602,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     // single-pass binning: the projection kernel has already written the keys into the tile segments of the geometry
     // workspace — no scatter, and the keys area of the binning workspace stays untouched
     if (seg && L.seg_cap == 0) return hipErrorInvalidValue;
-    uint64_t *keys = seg ? (uint64_t *)(geom + L.seg_keys) : (uint64_t *)(bin + B.keys);
+    uint64_t *keys = (uint64_t *)(bin + B.keys);
     uint32_t *plist = (uint32_t *)(bin + B.point_list);
     const uint32_t *ts = (const uint32_t *)(geom + L.tile_start);
     HalfOut ho;
@@ -607,7 +616,11 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     ho.long_count[0] = ho.header + kHdrLongTiles; ho.long_count[1] = ho.long_count[0] + 1;
     ho.ip = index_packing(d);
     ho.seg_cap = seg ? L.seg_cap : 0u;
-    if (!seg) {
+    ho.seg_keys = (const uint64_t *)(geom + L.seg_keys);
+    // the scatter: everything (two-phase binning), or only the tiles whose lists outgrew their segments — launched when
+    // the host knows of such a list, or cannot know (no-sync forward: the workgroups leave at once when there is none)
+    const uint32_t over_cap = seg ? L.seg_cap : 0u;
+    if (!seg || device_counts || (uint32_t)max_tile_pairs > L.seg_cap) {
         const bool lds = T <= 8192;
         // Items per thread: the launch should be ONE round of resident workgroups (8 per CU, fewer when
         // the per-tile counters of a large image take the LDS) — with a fixed 2048 Gaussians per block the
@@ -636,7 +649,8 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
         const uint32_t capacity = (uint32_t)(num_pairs < 0xFFFFFFFFll ? num_pairs : 0xFFFFFFFFll);
 #define LSR_SCAT2(LDSR, NRW, SHM)                                                                         \
     hipLaunchKernelGGL((k_scatter<LDSR, NRW>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T, \
-                       (const char *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, index_packing(d).key_shift, strace)
+                       (const char *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, index_packing(d).key_shift, strace, \
+                       (const uint32_t *)(geom + L.tile_count), (const uint32_t *)(geom + L.header), over_cap)
 #define LSR_SCAT(LDSR, SHM) do { if (narrow_bins(d)) LSR_SCAT2(LDSR, true, SHM); else LSR_SCAT2(LDSR, false, SHM); } while (0)
         if (lds) LSR_SCAT(true, (size_t)T * 8);
         else LSR_SCAT(false, 0);

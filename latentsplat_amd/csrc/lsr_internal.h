@@ -104,8 +104,10 @@ constexpr uint32_t kCodeNone = 0x11u;   // c0 = 1 > c1 = 0, r0 = 1 > r1 = 0
 // retires — no k_scatter launch, no second machine-wide pass over the binning records (the workgroup re-reads its own
 // 24 KB of them while they are still in its L2).  The tile scan still produces the exact offsets, so k_sort_tiles
 // writes the canonical point_list and the half-tile lists exactly where they were.
-// A tile with more pairs than a segment holds sets the overflow flag; the synchronous forward sees the longest list on
-// the host anyway and re-runs such a call on the two-phase path (api.hip), the no-sync forward reports the flag.
+// A tile with more pairs than a segment holds keeps only its first `cap` keys there (the surplus lands on the segment's
+// last slot); such tiles are binned a second time by k_scatter's overfull-tiles-only instance into their exact
+// segments of the binning workspace, and k_sort_tiles reads them from there (binning.hip): correct for any list length,
+// slower only for the scenes that need it.
 // segment_capacity(d) (api.hip) is a pure function of the dims and the LSR_SEGMENTS / LSR_SEG_BUDGET_MB knobs: 0 = the
 // call takes the two-phase path.  The segments sit BEHIND everything else in the layout, so no other offset depends
 // on it.
@@ -114,6 +116,7 @@ struct SegOut {            // kernel argument of the projection kernels
     uint64_t *keys;        // [V*T][cap] (nullptr: two-phase binning)
     uint32_t cap;
     uint32_t key_shift;    // IndexPacking::key_shift
+    uint32_t ablate;       // LSR_SEG_ABLATE (timing experiments only, wrong results): 1 no key stores, 2 no emission pass
 };
 
 inline GeomLayout geom_layout(const lsr_dims &d) {
@@ -238,7 +241,6 @@ struct FoldedScan {
     uint32_t *host_words; uint32_t host_seq;
     uint32_t capacity;
     uint32_t *tile_start, *tile_order;     // filled in by launch_preprocess
-    uint32_t seg_cap;                      // single-pass binning: keys per tile segment (a longer list = overflow); else UINT32_MAX
 };
 inline bool fold_tile_scan(const lsr_dims &d) {
     return d.num_gaussians > 0 && (int64_t)d.num_views * num_tiles(d) <= kFoldTiles && env_int("LSR_FOLD_SCAN", 1) != 0;
@@ -247,8 +249,7 @@ inline bool fold_tile_scan(const lsr_dims &d) {
 // segment_capacity); the caller then skips k_scatter (launch_binning's `seg`)
 hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, const FoldedScan &fs,
                              bool seg, hipStream_t s);
-hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_words, uint32_t host_seq, uint32_t pair_capacity,
-                            uint32_t seg_cap, hipStream_t s);
+hipError_t launch_tile_scan(const lsr_dims &d, char *geom, uint32_t *host_words, uint32_t host_seq, uint32_t pair_capacity, hipStream_t s);
 hipError_t launch_pack_view(const float *viewmatrix, const float *projmatrix, const float *campos, const float *bg,
                             float tanfovx, float tanfovy, const float *tanfovx_dev, const float *tanfovy_dev, float *out,
                             hipStream_t s);

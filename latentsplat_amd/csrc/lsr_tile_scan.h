@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 template <int THREADS, int REGS, bool ATOMIC>
 __device__ __forceinline__ void tile_scan_block(const uint32_t *count, uint32_t *__restrict__ start, uint32_t *header,
                                                 HostMirror hm, uint32_t *__restrict__ order, int N, uint32_t capacity,
-                                                TileScanShared<THREADS> &sh, uint32_t seg_cap = 0xFFFFFFFFu) {
+                                                TileScanShared<THREADS> &sh) {
     constexpr int kWaves = THREADS / LSR_WAVE;
     const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
     const int per = (N + THREADS - 1) / THREADS;
@@ -160,8 +160,7 @@ __device__ __forceinline__ void tile_scan_block(const uint32_t *count, uint32_t 
     }
     if (tid == THREADS - 1) {
         start[N] = min(total, capacity); header[kHdrPairs] = total; header[kHdrMaxTile] = maxc;
-        // (single-pass binning: a list longer than a tile's key segment lost its surplus keys — same flag)
-        header[kHdrOverflow] = (total > capacity || wrapped || maxc > seg_cap) ? 1u : 0u;
+        header[kHdrOverflow] = (total > capacity || wrapped) ? 1u : 0u;
     }
     // ---- work items, costliest first: counting sort on THREADS classes of the per-tile cost (= canonical list
     // length; the two half-tile items of a tile stay together).  The exact half list lengths only exist after

@@ -202,13 +202,28 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
     if (SEG) {
         // ---- reserve: count -> first slot of this workgroup in the tile's segment (the counter becomes the cursor) ----
         __syncthreads();
-        for (int t = threadIdx.x; t < VB * T; t += kPreThreads) {
-            const int v = v0 + t / T;
-            const uint32_t c = s_hist[t];
-            uint32_t first = 0u;
-            if (c && v < d.num_views)
-                first = __hip_atomic_fetch_add(&tile_count[(size_t)v * T + (t % T)], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_hist[t] = first;
+        // (four counters per thread and round, their returning atomics in flight together: one round trip to the
+        // memory-side atomic unit per round instead of one per counter.  Only non-empty counters issue an atomic — adds of
+        // zero to a clamped address put thousands of same-address atomics of EVERY workgroup on one word: measured 5.5 ms
+        // instead of 0.15 for a one-view-per-workgroup launch)
+        for (int t0 = threadIdx.x; t0 < VB * T; t0 += 4 * kPreThreads) {
+            uint32_t c[4], first[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = t0 + k * kPreThreads;
+                c[k] = t < VB * T ? s_hist[t] : 0u;
+                if (c[k] && v0 + t / T >= d.num_views) c[k] = 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = t0 + k * kPreThreads;
+                if (c[k]) first[k] = __hip_atomic_fetch_add(&tile_count[(size_t)(v0 + t / T) * T + (t % T)], c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = t0 + k * kPreThreads;
+                if (t < VB * T) s_hist[t] = first[k];
+            }
         }
         __syncthreads();
         // ---- emit: the same (Gaussian, view) items in the same order; a thread reads back the records it wrote ----
@@ -216,7 +231,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
 #pragma unroll 1
         for (int it = 0; it < kItems; ++it) {
             const int chunk0 = base + it * kPreThreads;
-            if (chunk0 >= G) break;   // block-uniform
+            if (chunk0 >= G || (seg.ablate & 2u)) break;   // block-uniform
             const int i = chunk0 + threadIdx.x;
             const bool in_range = i < G;
             const size_t ii = in_range ? (size_t)i : 0;
@@ -243,8 +258,8 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
                         const uint32_t pos = atomicAdd(&cur[t], 1u);
                         const uint32_t code = seg.key_shift ? span_code(sp, x - x0, y - y0) : 0u;
                         // clamped, not tested (a store under a per-lane condition cost k_scatter 17 %): the surplus keys of
-                        // an overfull segment land on its last slot, and the tile scan flags the overflow
-                        seg.keys[(size_t)((seg0 + (uint32_t)t) * cap + min(pos, cap - 1u))] = key | code;
+                        // an overfull segment land on its last slot; such a tile is binned again by the fallback scatter
+                        if (!(seg.ablate & 1u)) seg.keys[(size_t)((seg0 + (uint32_t)t) * cap + min(pos, cap - 1u))] = key | code;
                     }
             }
         }
@@ -283,7 +298,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
             }
             __syncthreads();
             tile_scan_block<kPreThreads, 0, false>(s_counts, fs.tile_start, header, HostMirror{fs.host_words, fs.host_seq},
-                                                   fs.tile_order, N, fs.capacity, s_scan, fs.seg_cap);
+                                                   fs.tile_order, N, fs.capacity, s_scan);
         }
     }
 }
@@ -316,7 +331,8 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     const bool shared = d.vs_means == 0 && d.vs_cov == 0 && d.vs_opac == 0 && (d.color_mode != LSR_COLOR_PRECOMP || d.vs_color == 0) &&
                         (d.feat_channels == 0 || d.vs_feat == 0);
     const int span = shared ? d.num_views : (d.views_per_group > 1 ? d.views_per_group : 1);   // views per input slice
-    const int vb = (span % 4 == 0 || (shared && span >= 4)) ? 4 : ((span % 2 == 0 || (shared && span >= 2)) ? 2 : 1);
+    int vb = (span % 4 == 0 || (shared && span >= 4)) ? 4 : ((span % 2 == 0 || (shared && span >= 2)) ? 2 : 1);
+    if (const int forced_vb = env_int("LSR_PRE_VB", 0)) vb = std::min(vb, forced_vb >= 4 ? 4 : (forced_vb >= 2 ? 2 : 1));   // (development knob)
     // Gaussians per thread: kPreItems / vb (one LDS histogram flush per 2048 items) unless that leaves fewer than two
     // workgroups per CU — a single 300 k view was 147 workgroups of 8 sequential Gaussians per thread on 256 CUs
     const int64_t yblocks = (d.num_views + vb - 1) / vb;
@@ -336,12 +352,11 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     const bool fma = projection_contraction();
     // single-pass binning: the caller asks for it only when segment_capacity(d) > 0, which implies byte tile coordinates
     // and T <= 1024 (the LDS histogram of up to 4 views)
-    SegOut so{nullptr, 0u, index_packing(d).key_shift};
+    SegOut so{nullptr, 0u, index_packing(d).key_shift, (uint32_t)env_int("LSR_SEG_ABLATE", 0)};
     if (seg_mode) {
         if (!lds || !narrow || L.seg_cap == 0) return hipErrorInvalidValue;
         so.keys = (uint64_t *)(geom + L.seg_keys); so.cap = L.seg_cap;
     }
-    fs.seg_cap = seg_mode ? L.seg_cap : 0xFFFFFFFFu;
 #define LSR_PRE4(CM, LH, VBV, FM, SG) hipLaunchKernelGGL((k_preprocess<CM, LH, VBV, FM, SG>), grid, dim3(kPreThreads), shm, s, d, in, rec, RF, binrec, narrow, radii, tc, (uint32_t *)(geom + L.header), fs, items, so)
 #define LSR_PRE3(CM, LH, VBV, FM) do { if (LH && seg_mode) LSR_PRE4(CM, LH, VBV, FM, LH); else LSR_PRE4(CM, LH, VBV, FM, false); } while (0)
 #define LSR_PRE2(CM, LH, VBV) do { if (fma) LSR_PRE3(CM, LH, VBV, true); else LSR_PRE3(CM, LH, VBV, false); } while (0)

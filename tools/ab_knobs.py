@@ -69,6 +69,18 @@ def main():
             m, c, o, f = (t.detach().requires_grad_(True) for t in (inp["means"], inp["cov"], inp["opac"], inp["features"]))
             rasterize_views(inp["views"], 256, 256, 0, m, c, o, features=f)[1].backward(gf)
         wl["raster16"] = (r_fwd, r_fb)
+    if "nosync16" in want:      # the no-sync forward (pair capacity 1.5 x the measured count), back to back on one stream
+        from latentsplat_amd.rasterizer import last_forward_status
+        inp2 = bench.build_inputs(args.gaussians, 16, 256, dev, 1234)
+        with torch.no_grad():
+            rasterize_views(inp2["views"], 256, 256, 0, inp2["means"], inp2["cov"], inp2["opac"], features=inp2["features"])
+        st = last_forward_status()
+        kw = dict(pair_capacity=int(1.5 * st["num_pairs"]), max_tile_hint=int(st["max_tile_pairs"]))
+
+        def n_fwd():
+            with torch.no_grad():
+                rasterize_views(inp2["views"], 256, 256, 0, inp2["means"], inp2["cov"], inp2["opac"], features=inp2["features"], **kw)
+        wl["nosync16"] = (n_fwd, n_fwd)
     for name, scenes in (("cfg3", 1), ("cfg4", 4)):
         if name not in want:
             continue
