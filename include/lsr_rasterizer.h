@@ -116,7 +116,13 @@ typedef struct lsr_dims {
                                  is consistent with.  Which of the two the external CUDA fork uses for
                                  colour cannot be determined offline (SURVEY.md Appendix A.4 [UNK];
                                  tools/dump_fork_vectors.py case fork_probe_sh_axes decides it). */
+    int32_t forward_flags;  /* (ABI v8) bit 0, LSR_FWD_FOR_BACKWARD: an lsr_backward of this forward will follow.  The
+                               forward compositing kernel then records on which 4x4-pixel sub-blocks every list entry
+                               actually contributed and narrows the render lists' sub-block bits to those (identical
+                               images; the backward evaluates ~14 % fewer (entry, sub-block) pairs, the forward pays
+                               one LDS atomic per loop iteration).  Ignored by lsr_backward itself. */
 } lsr_dims;
+#define LSR_FWD_FOR_BACKWARD 1
 
 typedef struct lsr_inputs {
     const float *views;      /* [V][LSR_VIEW_FLOATS] */
@@ -244,6 +250,23 @@ int lsr_forward_abandon(lsr_stream_t stream);
 int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, void *bin_ws, void *img_ws,
                        int64_t pair_capacity, int32_t max_tile_hint, const lsr_outputs *out,
                        lsr_stream_t stream);
+
+/* ---- forward with a SPECULATIVE workspace size (ABI v8).  The synchronous forward idles the device for ~10 us per call:
+ * between the host's read of the pair count in lsr_forward_prepare and the arrival of lsr_forward_render's launches.
+ * A caller that renders the same shape again and again (a training loop) knows roughly how many pairs to expect: this call
+ * launches the WHOLE forward at once — bin_ws sized for `pair_capacity` pairs exactly as for lsr_forward_nosync,
+ * `max_tile_hint` >= 1 the longest tile list the launch structure (sort tiers, fallback scatter) is chosen for — and only
+ * then waits for the device's counts the way lsr_forward_prepare does, while the device goes on sorting and compositing.
+ *   *overflow_host == 0: the forward is complete and bit-identical to lsr_forward_prepare + lsr_forward_render;
+ *                        lsr_backward takes `num_pairs = pair_capacity` for it (the workspace layout).
+ *   *overflow_host != 0: the scene produced more pairs than `pair_capacity` or a list longer than `max_tile_hint`; such
+ *                        lists were left out (no out-of-bounds access), the outputs are incomplete: run
+ *                        lsr_forward_prepare + lsr_forward_render on the same workspaces (they size bin_ws exactly).
+ * The counts returned are the true ones either way (what the caller bases its next capacity on). */
+int lsr_forward_speculative(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, void *bin_ws, void *img_ws,
+                            int64_t pair_capacity, int32_t max_tile_hint, const lsr_outputs *out,
+                            int64_t *num_pairs_host, int32_t *max_tile_pairs_host, int32_t *overflow_host,
+                            lsr_stream_t stream);
 
 /* Pair count, longest tile list and overflow flag (0/1) of the most recent forward that used
  * geom_ws.  Copies 32 bytes to the host and synchronises `stream`. */

@@ -18,6 +18,7 @@ VIEW_FLOATS = 44
 COLOR_NONE, COLOR_SH, COLOR_PRECOMP = 0, 1, 2
 FEAT_DIRECT, FEAT_SH = 0, 1
 SH_AXES_3DGS, SH_AXES_REFERENCE = 0, 1   # lsr_dims.color_sh_convention
+FWD_FOR_BACKWARD = 1                      # lsr_dims.forward_flags
 MAX_SH_GROUP_FLOATS = 120   # C*Kf the fused latent-SH path supports (LDS budget of sh.hip)
 MAX_FEAT_CHANNELS = 32
 
@@ -34,7 +35,7 @@ class Dims(C.Structure):
                 ("vs_feat", C.c_int64), ("cov_elems", C.c_int32), ("feat_mode", C.c_int32),
                 ("feat_sh_degree", C.c_int32), ("feat_sh_coeffs", C.c_int32),
                 ("color_sh_channel_major", C.c_int32), ("views_per_group", C.c_int32),
-                ("color_sh_convention", C.c_int32)]
+                ("color_sh_convention", C.c_int32), ("forward_flags", C.c_int32)]
 
 
 class Inputs(C.Structure):
@@ -117,7 +118,7 @@ PLY_VERTEX_FLOATS = 17
 EXPORTS = (
     "lsr_abi_version", "lsr_error_string", "lsr_last_hip_error", "lsr_geom_workspace_bytes",
     "lsr_image_workspace_bytes", "lsr_binning_workspace_bytes", "lsr_grad_workspace_bytes",
-    "lsr_get_layout", "lsr_build_views", "lsr_pack_view", "lsr_forward_prepare", "lsr_forward_render", "lsr_forward_nosync",
+    "lsr_get_layout", "lsr_build_views", "lsr_pack_view", "lsr_forward_prepare", "lsr_forward_render", "lsr_forward_nosync", "lsr_forward_speculative",
     "lsr_forward_status", "lsr_forward_abandon", "lsr_backward",
     "lsr_profile_enable", "lsr_profile_num_stages", "lsr_profile_stage_name", "lsr_profile_read",
     "lsr_debug_set_knob", "lsr_set_projection_contraction", "lsr_get_projection_contraction",
@@ -179,6 +180,9 @@ def load():
                                        C.POINTER(Outputs), P]
     lib.lsr_forward_nosync.restype = C.c_int
     lib.lsr_forward_nosync.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, I32, C.POINTER(Outputs), P]
+    lib.lsr_forward_speculative.restype = C.c_int
+    lib.lsr_forward_speculative.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, I32, C.POINTER(Outputs),
+                                            C.POINTER(I64), C.POINTER(I32), C.POINTER(I32), P]
     lib.lsr_forward_abandon.restype = C.c_int
     lib.lsr_forward_abandon.argtypes = [P]
     lib.lsr_forward_status.restype = C.c_int

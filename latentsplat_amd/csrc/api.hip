@@ -224,8 +224,9 @@ static int sh_forward_inline(const lsr_dims &d, const lsr_inputs &in, char *geom
 // the other half on a side stream: bit-identical, never faster — both halves are issue-bound — and deleted in
 // round 4.  Callers with independent batches overlap whole calls on two streams instead: INTEGRATION.md.)
 static int forward_tail(const lsr_dims &d, const lsr_inputs &in, char *geom, char *bin, char *img, int64_t num_pairs,
-                        int32_t max_tile_pairs, const lsr_outputs &out, hipStream_t s, bool device_counts, bool seg) {
-    LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts, seg));
+                        int32_t max_tile_pairs, const lsr_outputs &out, hipStream_t s, bool device_counts, bool seg,
+                        bool speculative = false) {
+    LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts, seg, speculative));
     LSR_STAGE("render_forward", s, launch_render_forward(d, in, geom, bin, num_pairs, img, out, s));
     return LSR_OK;
 }
@@ -399,22 +400,22 @@ static int wait_pair_count(volatile uint32_t *h, uint32_t seq, hipEvent_t ev, bo
     }
 }
 
-int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii,
-                        int64_t *num_pairs_host, int32_t *max_tile_pairs_host, lsr_stream_t stream) {
-    g_last_hip_error = 0;
-    int rc = check_dims(d);
-    if (rc) return rc;
-    rc = check_inputs(d, in);
-    if (rc) return rc;
-    if (!geom_ws || !num_pairs_host || !max_tile_pairs_host) return LSR_ENULL;
-    if (d->num_gaussians > 0 && !radii) return LSR_ENULL;
-    hipStream_t s = (hipStream_t)stream;
-    char *geom = (char *)geom_ws;
-    // Pair count and longest list come back through a 64-byte pinned, device-mapped host buffer (one per host
-    // thread, allocated on first use; the library's only allocation and it is host memory): wait_pair_count above.
-    // Without mapped memory: a device-to-host copy of the header behind the scan.
-    static thread_local uint32_t *h_hdr = nullptr, *h_hdr_dev = nullptr;
+// The per-thread mapped host words through which the scanning workgroup reports the pair count and the longest list
+// (pinned, device-mapped; the library's only allocation), the event behind the projection kernel (the polling loop's
+// safety net) and the sequence number of the thread's calls.
+namespace {
+struct HostWords {
+    uint32_t *host = nullptr, *dev = nullptr;
+    hipEvent_t event = nullptr;
+    bool mapped() const { return event != nullptr; }
+};
+uint32_t next_seq() {
     static thread_local uint32_t h_seq = 0;
+    if (++h_seq == 0u) h_seq = 1u;                        // 0 is what a fresh buffer holds
+    return h_seq;
+}
+void host_words(HostWords &w) {
+    static thread_local uint32_t *h_hdr = nullptr, *h_hdr_dev = nullptr;
     static thread_local hipEvent_t h_events[64] = {};     // one per device this thread has used (events belong to a device)
     static thread_local bool h_tried = false;
     if (!h_tried) {
@@ -428,47 +429,80 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
             (void)hipGetLastError();
         }
     }
-    hipEvent_t h_event = nullptr;
-    {
-        int dev = -1;
-        if (h_hdr && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-            if (!h_events[dev] && hipEventCreateWithFlags(&h_events[dev], hipEventDisableTiming) != hipSuccess) {
-                (void)hipGetLastError();
-                h_events[dev] = nullptr;
-            }
-            h_event = h_events[dev];
+    w = HostWords();
+    int dev = -1;
+    if (h_hdr && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (!h_events[dev] && hipEventCreateWithFlags(&h_events[dev], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            h_events[dev] = nullptr;
         }
+        w.event = h_events[dev];
     }
-    const bool mapped = h_event != nullptr;
-    const bool fold = fold_tile_scan(*d);
-    // Single-pass binning when the dims allow it (segment_capacity): the projection kernel writes the sort keys itself.
-    // A tile list longer than its key segment is no failure: lsr_forward_render then launches the scatter for exactly
-    // those tiles (the host reads the longest list below anyway).
-    const bool seg = segment_capacity(*d) != 0u;
-    uint32_t hdr[2] = {0, 0};
-    if (++h_seq == 0u) h_seq = 1u;                        // 0 is what a fresh buffer holds
-    FoldedScan fs{};
-    fs.enabled = fold ? 1 : 0;
-    fs.host_words = mapped ? h_hdr_dev : nullptr; fs.host_seq = h_seq; fs.capacity = 0xFFFFFFFFu;
-    if (fused_preprocess_sh(*d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(*d, *in, geom, radii, fs, s));
-    else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, radii, fs, seg, s));
-    if (fold && mapped) LSR_HIP(hipEventRecord(h_event, s));
-    rc = sh_forward_inline(*d, *in, geom, s);   // view-dependent payload of calls the fused kernel does not cover
-    if (rc) return rc;
-    if (!fold) {
-        LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, mapped ? h_hdr_dev : nullptr, h_seq, 0xFFFFFFFFu, s));
-        if (mapped) LSR_HIP(hipEventRecord(h_event, s));
-    }
+    w.host = h_hdr; w.dev = h_hdr_dev;
+}
+// the host's only wait of a forward: pair count and longest list of the call with sequence number `seq`
+int read_counts(const lsr_dims &d, const char *geom, const HostWords &hw, uint32_t seq, hipStream_t s, uint32_t hdr[2]) {
     bool have = false;
-    if (mapped) {
-        rc = wait_pair_count(h_hdr, h_seq, h_event, have);
+    hdr[0] = hdr[1] = 0;
+    if (hw.mapped()) {
+        int rc = wait_pair_count(hw.host, seq, hw.event, have);
         if (rc) return rc;
-        if (have) { hdr[0] = h_hdr[0]; hdr[1] = h_hdr[1]; }
+        if (have) { hdr[0] = hw.host[0]; hdr[1] = hw.host[1]; }
     }
     if (!have) {
-        LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(*d).header, sizeof(hdr), hipMemcpyDeviceToHost, s));
+        LSR_HIP(hipMemcpyAsync(hdr, geom + geom_layout(d).header, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         LSR_HIP(hipStreamSynchronize(s));
     }
+    return LSR_OK;
+}
+// Projection (+ key emission, + SH payload) and the tile scan of one forward.  host: report the counts to the mapped
+// host words under `seq`; capacity: pairs the binning workspace holds (UINT32_MAX: sized after the fact).
+int launch_front(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, const HostWords *hw, uint32_t seq,
+                 uint32_t capacity, hipStream_t s) {
+    const bool fold = fold_tile_scan(d);
+    const bool seg = segment_capacity(d) != 0u;
+    const bool mapped = hw && hw->mapped();
+    FoldedScan fs{};
+    fs.enabled = fold ? 1 : 0;
+    fs.host_words = mapped ? hw->dev : nullptr; fs.host_seq = seq; fs.capacity = capacity;
+    if (fused_preprocess_sh(d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(d, in, geom, radii, fs, s));
+    else LSR_STAGE("preprocess", s, launch_preprocess(d, in, geom, radii, fs, seg, s));
+    if (fold && mapped) LSR_HIP(hipEventRecord(hw->event, s));
+    int rc = sh_forward_inline(d, in, geom, s);   // view-dependent payload of calls the fused kernel does not cover
+    if (rc) return rc;
+    if (!fold) {
+        LSR_STAGE("tile_scan", s, launch_tile_scan(d, geom, mapped ? hw->dev : nullptr, seq, capacity, s));
+        if (mapped) LSR_HIP(hipEventRecord(hw->event, s));
+    }
+    return LSR_OK;
+}
+}  // namespace
+
+int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii,
+                        int64_t *num_pairs_host, int32_t *max_tile_pairs_host, lsr_stream_t stream) {
+    g_last_hip_error = 0;
+    int rc = check_dims(d);
+    if (rc) return rc;
+    rc = check_inputs(d, in);
+    if (rc) return rc;
+    if (!geom_ws || !num_pairs_host || !max_tile_pairs_host) return LSR_ENULL;
+    if (d->num_gaussians > 0 && !radii) return LSR_ENULL;
+    hipStream_t s = (hipStream_t)stream;
+    char *geom = (char *)geom_ws;
+    // Pair count and longest list come back through a 64-byte pinned, device-mapped host buffer (one per host
+    // thread, allocated on first use): wait_pair_count above.  Without mapped memory: a device-to-host copy of the
+    // header behind the scan.
+    // Single-pass binning when the dims allow it (segment_capacity): the projection kernel writes the sort keys itself.
+    // A tile list longer than its key segment is no failure: lsr_forward_render then launches the scatter for exactly
+    // those tiles (the host reads the longest list here anyway).
+    HostWords hw;
+    host_words(hw);
+    const uint32_t seq = next_seq();
+    rc = launch_front(*d, *in, geom, radii, &hw, seq, 0xFFFFFFFFu, s);
+    if (rc) return rc;
+    uint32_t hdr[2];
+    rc = read_counts(*d, geom, hw, seq, s, hdr);
+    if (rc) return rc;
     *num_pairs_host = (int64_t)hdr[0];
     *max_tile_pairs_host = (int32_t)hdr[1];
     if (hdr[0] == 0xFFFFFFFFu) return LSR_EUNSUPPORTED;   // more (Gaussian, tile) pairs than the 32-bit offsets address (count saturated)
@@ -515,20 +549,50 @@ int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     if (pair_capacity < 1 || pair_capacity >= ((int64_t)1 << 32) || max_tile_hint < 0) return LSR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     char *geom = (char *)geom_ws;
-    // the same stage sequence as prepare + render; nothing between the launches waits for the device
-    const bool fold = fold_tile_scan(*d);
-    // single-pass binning whenever the dims allow it; the fallback scatter for tiles that outgrow their key segments is
-    // always launched here (its workgroups leave at once when the device's longest list fits)
-    const bool seg = segment_capacity(*d) != 0u;
-    FoldedScan fs{};
-    fs.enabled = fold ? 1 : 0;
-    fs.capacity = (uint32_t)pair_capacity;
-    if (fused_preprocess_sh(*d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(*d, *in, geom, out->radii, fs, s));
-    else LSR_STAGE("preprocess", s, launch_preprocess(*d, *in, geom, out->radii, fs, seg, s));
-    rc = sh_forward_inline(*d, *in, geom, s);
+    // the same stage sequence as prepare + render; nothing between the launches waits for the device.  Single-pass
+    // binning whenever the dims allow it; the fallback scatter for tiles that outgrow their key segments is always
+    // launched here (its workgroups leave at once when the device's longest list fits)
+    rc = launch_front(*d, *in, geom, out->radii, nullptr, 0u, (uint32_t)pair_capacity, s);
     if (rc) return rc;
-    if (!fold) LSR_STAGE("tile_scan", s, launch_tile_scan(*d, geom, nullptr, 0u, (uint32_t)pair_capacity, s));
-    return forward_tail(*d, *in, geom, (char *)bin_ws, (char *)img_ws, pair_capacity, max_tile_hint, *out, s, true, seg);
+    return forward_tail(*d, *in, geom, (char *)bin_ws, (char *)img_ws, pair_capacity, max_tile_hint, *out, s, true, segment_capacity(*d) != 0u);
+}
+
+int lsr_forward_speculative(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, void *bin_ws, void *img_ws,
+                            int64_t pair_capacity, int32_t max_tile_hint, const lsr_outputs *out,
+                            int64_t *num_pairs_host, int32_t *max_tile_pairs_host, int32_t *overflow_host, lsr_stream_t stream) {
+    g_last_hip_error = 0;
+    int rc = check_dims(d);
+    if (rc) return rc;
+    rc = check_inputs(d, in);
+    if (rc) return rc;
+    if (!geom_ws || !bin_ws || !img_ws || !out || !out->mask || !out->depth || !num_pairs_host || !max_tile_pairs_host || !overflow_host) return LSR_ENULL;
+    if (d->num_gaussians > 0 && !out->radii) return LSR_ENULL;
+    if (d->color_mode != LSR_COLOR_NONE && !out->color) return LSR_ENULL;
+    if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
+    if (pair_capacity < 1 || pair_capacity >= ((int64_t)1 << 32) || max_tile_hint < 1) return LSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    char *geom = (char *)geom_ws;
+    // Everything is launched at once with the launch structure of the SYNCHRONOUS forward for (pair_capacity,
+    // max_tile_hint) — sort tiers, fallback scatter — and only then does the host wait for the counts: the device goes on
+    // sorting and compositing meanwhile (the synchronous forward idles ~10 us per call between the host's read and the
+    // arrival of its next launches).  Lists beyond the hint are left out of the render lists (binning.hip n_limit), offsets
+    // beyond the capacity are clamped by the scan: a scene that needs more than it was given renders garbage-free but
+    // incomplete images and is reported as overflow.
+    HostWords hw;
+    host_words(hw);
+    const uint32_t seq = next_seq();
+    rc = launch_front(*d, *in, geom, out->radii, &hw, seq, (uint32_t)pair_capacity, s);
+    if (rc) return rc;
+    rc = forward_tail(*d, *in, geom, (char *)bin_ws, (char *)img_ws, pair_capacity, max_tile_hint, *out, s, false,
+                      segment_capacity(*d) != 0u, true);
+    if (rc) return rc;
+    uint32_t hdr[2];
+    rc = read_counts(*d, geom, hw, seq, s, hdr);
+    if (rc) return rc;
+    *num_pairs_host = (int64_t)hdr[0];
+    *max_tile_pairs_host = (int32_t)hdr[1];
+    *overflow_host = ((int64_t)hdr[0] > pair_capacity || hdr[1] > (uint32_t)max_tile_hint || hdr[0] == 0xFFFFFFFFu) ? 1 : 0;
+    return LSR_OK;
 }
 
 int lsr_forward_status(const lsr_dims *d, const void *geom_ws, int64_t *num_pairs_host, int32_t *max_tile_pairs_host,

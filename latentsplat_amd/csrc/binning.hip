@@ -194,6 +194,9 @@ struct HalfOut {
     IndexPacking ip;          // how keys and list entries carry the Gaussian index (lsr_internal.h)
     uint32_t seg_cap;         // single-pass binning: a list of up to seg_cap keys sits in seg_keys[vt * seg_cap ...] (0: two-phase binning)
     const uint64_t *seg_keys;
+    uint32_t n_limit;         // speculative forward: the longest list the launch structure was chosen for (the caller's hint); a
+                              // longer list is left unsorted with EMPTY render lists — the host sees the true longest list
+                              // and runs the call again with exact sizes (UINT32_MAX otherwise)
 };
 constexpr int kSortTier2 = 8192;
 __device__ __forceinline__ uint32_t long_tile(const HalfOut &ho, int cls, uint32_t i) {
@@ -315,6 +318,10 @@ __device__ __forceinline__ void sort_tile(uint64_t *s_keys, size_t vt, int tier,
     if ((uint64_t)start + n > ho.capacity) {      // a list beyond the workspace (synchronous forward: the host's count was short): flag, render nothing
         if (tid < 2) hcnt[tid] = 0;
         if (tid == 0) ho.header[kHdrOverflow] = 1u;
+        return;
+    }
+    if (n > ho.n_limit) {         // speculative forward, hint too small: nothing of this tile may reach the compositing kernels
+        if (tid < 2) hcnt[tid] = 0;
         return;
     }
     if (n > (uint32_t)CAP) {        // for a later tier: a larger LDS variant, or (beyond the largest) the global merge path
@@ -591,7 +598,7 @@ static void sort_launch(dim3 grid, hipStream_t s, int cls, const uint32_t *order
 }
 
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
-                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts, bool seg) {
+                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts, bool seg, bool speculative) {
     (void)radii;
     const GeomLayout L = geom_layout(d);
     if (num_pairs <= 0 || d.num_gaussians == 0)   // nothing to sort: every half-tile render list is empty
@@ -617,6 +624,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
     ho.ip = index_packing(d);
     ho.seg_cap = seg ? L.seg_cap : 0u;
     ho.seg_keys = (const uint64_t *)(geom + L.seg_keys);
+    ho.n_limit = speculative ? (uint32_t)max_tile_pairs : 0xFFFFFFFFu;
     // the scatter: everything (two-phase binning), or only the tiles whose lists outgrew their segments — launched when
     // the host knows of such a list, or cannot know (no-sync forward: the workgroups leave at once when there is none)
     const uint32_t over_cap = seg ? L.seg_cap : 0u;

@@ -293,7 +293,8 @@ hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const cha
 // device_counts: the pair count / longest list are NOT known on the host (no-sync forward):
 // `num_pairs` is then the workspace capacity and `max_tile_pairs` only a hint for the sort variant
 hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_pairs,
-                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts, bool seg);
+                          int32_t max_tile_pairs, const int32_t *radii, hipStream_t s, bool device_counts, bool seg,
+                          bool speculative = false);
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                  const char *bin, int64_t num_pairs, char *img, const lsr_outputs &out,
                                  hipStream_t s);

@@ -259,6 +259,9 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
                         const uint32_t code = seg.key_shift ? span_code(sp, x - x0, y - y0) : 0u;
                         // clamped, not tested (a store under a per-lane condition cost k_scatter 17 %): the surplus keys of
                         // an overfull segment land on its last slot; such a tile is binned again by the fallback scatter
+                        if (seg.ablate & 4u) {      // timing experiment: the same number of stores, perfectly coalesced (wrong results)
+                            seg.keys[(size_t)((blockIdx.x & 1023u) * 4096u + ((threadIdx.x + 256u * (pos & 15u)) & 4095u))] = key | code;
+                        } else
                         if (!(seg.ablate & 1u)) seg.keys[(size_t)((seg0 + (uint32_t)t) * cap + min(pos, cap - 1u))] = key | code;
                     }
             }

@@ -84,6 +84,7 @@ struct RenderFwdParams {
     const float4 *rec;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
     int rec_f4;
     const uint32_t *tile_start, *half_count, *half_list;
+    uint32_t *half_list_rw;       // RECORD instances: the same lists, written back with the sub-block bits refined (below)
     IndexPacking ip;              // how the list entries carry the Gaussian index and the sub-block bits
     float *out_color, *out_feat, *out_mask, *out_depth;
     float *final_T;
@@ -96,8 +97,19 @@ struct RenderFwdParams {
 // takes items b, 2B-1-b, 2B+b, 4B-1-b, ... (B = number of bins) — pairing expensive with cheap items
 // so every SIMD starts with nearly the same total; everything beyond the first item per wave comes from
 // the queue.
-template <int NCHP, int WPB>
-__global__ void __launch_bounds__(LSR_WAVE * WPB, WPB == 14 ? 7 : 1)   // (the 2 x 14-wave variant needs 72 registers: seven waves per SIMD)
+//
+// RECORD (round 5; forwards that a backward will follow: lsr_dims::forward_flags): while it composites, the kernel notes for
+// every staged entry on WHICH of the half's eight sub-blocks it contributed to at least one pixel (kept by the alpha and
+// the transmittance test) and, when a batch is done, writes those bits back over the entry's sub-block bits in the half
+// list.  The bits k_sort_tiles put there describe the footprint's bounding box (39 pixel evaluations per pair, 34 for the
+// exact ellipse, fewer where pixels have run out of transmittance); the compositing BACKWARD walks the same lists and is
+// 2.5 x as expensive per evaluation — with the refined bits it evaluates an entry only where it has a gradient at all.
+// Cost here: one LDS atomic-or per loop iteration on the word of the staged record that otherwise holds the constant
+// -1/255 (kept in a register pair instead).  Lossless for the backward by construction: an (entry, sub-block) without a
+// contributing pixel has alpha T = 0 everywhere on the sub-block, i.e. no gradient (the stopping entry of a pixel is not
+// blended and lies beyond the pixel's n_contrib).
+template <int NCHP, int WPB, bool RECORD = false>
+__global__ void __launch_bounds__(LSR_WAVE * WPB, WPB == 14 ? 7 : ((RECORD && WPB == 12) ? 6 : 1))   // (2 x 14 waves: 72 registers, seven waves per SIMD; the RECORD instance of 2 x 12 must stay within six)
 k_render_fwd(RenderFwdParams p) {
     // Staged entries, one record per list entry: (x, y, a2, c2) (b2, log2(255 o), z / 255, -1 / 255) payload / 255 ...
     // (lsr_blend.h: the loop works in units of 255 alpha).  The odd float4 stride keeps the per-lane staging
@@ -127,12 +139,16 @@ k_render_fwd(RenderFwdParams p) {
     if (lane < 8) s_list[lane][LSR_WAVE] = null_off;   // the rows' pad word (never a real entry)
     if (lane == 0) {
         s_ent[LSR_WAVE][0] = make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);     // e' = NaN fails the keep test
-        s_ent[LSR_WAVE][1] = make_float4(0.0f, 0.0f, 0.0f, -kInv255);
+        s_ent[LSR_WAVE][1] = make_float4(0.0f, 0.0f, 0.0f, RECORD ? 0.0f : -kInv255);
 #pragma unroll
         for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     const uint32_t num_items = p.num_items;
     const int coff = p.has_color ? 3 : 0;
+    // RECORD: -1/255 lives in a register pair (the staged record's fourth word of its second quad collects the hit bits)
+    float2_t kz2 = float2_t{-kInv255, -kInv255};
+    asm volatile("" : "+s"(kz2));     // (a scalar register pair: the one constant-bus operand of the two packed operations below)
+    const uint32_t gbit = 1u << (lane >> 3);
     const size_t HW = (size_t)p.H * p.W;
     // lane group -> sub-block (gcol, grow) of the half (bit 4*grow + gcol of the list entries' mask);
     // lane -> its two pixels (lx, ly), (lx + 1, ly) of the sub-block
@@ -239,7 +255,7 @@ k_render_fwd(RenderFwdParams p) {
                 const float4 a = cur.a, b = cur.b;
                 const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
                 s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
-                s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z * kInv255, -kInv255);
+                s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z * kInv255, RECORD ? 0.0f : -kInv255);   // (RECORD: hit bits, none yet)
 #pragma unroll
                 for (int c4 = 0; c4 < NCHP / 4; ++c4)
                     s_ent[lane][2 + c4] = make_float4(cur.pay[c4].x * kInv255, cur.pay[c4].y * kInv255, cur.pay[c4].z * kInv255, cur.pay[c4].w * kInv255);
@@ -264,7 +280,8 @@ k_render_fwd(RenderFwdParams p) {
 #ifdef LSR_ENABLE_TRACE
             trace_iters += nk;
 #endif
-            for (uint32_t i = 0; i < nk; ++i) {
+            uint32_t hist = 0u;    // RECORD: one bit per iteration of the current chunk, newest in bit 0: this lane's pixels took part
+            auto entry_step = [&](uint32_t i) __attribute__((always_inline)) {
                 const uint32_t off = lp[i];
                 const float4 *E = (const float4 *)(ent_base + off);
                 const float4 a = E[0], b = E[1];
@@ -283,24 +300,41 @@ k_render_fwd(RenderFwdParams p) {
                 const float s = __builtin_fmaf(a.w * dy, dy, b.y);
                 const float2_t p1 = __builtin_elementwise_fma(float2_t{a.z, a.z}, d2, float2_t{t, t});
                 const float2_t ex = __builtin_elementwise_fma(p1, d2, float2_t{s, s});
-                const float2_t al = float2_t{fminf(kmax, fast_exp2(ex.x)), fminf(kmax, fast_exp2(ex.y))};   // 255 alpha
+                float2_t al;                                                                                   // 255 alpha
+                if (RECORD) {   // (v_min as written: fminf makes the compiler re-canonicalise kmax in every iteration of this register-tight instance)
+                    const float e0 = fast_exp2(ex.x), e1 = fast_exp2(ex.y);
+                    float m0, m1;
+                    asm("v_min_f32 %0, %1, %2" : "=v"(m0) : "v"(kmax), "v"(e0));
+                    asm("v_min_f32 %0, %1, %2" : "=v"(m1) : "v"(kmax), "v"(e1));
+                    al = float2_t{m0, m1};
+                } else al = float2_t{fminf(kmax, fast_exp2(ex.x)), fminf(kmax, fast_exp2(ex.y))};
                 // keep <=> 0 <= e' <= l2o' (alpha >= 1/255 and power <= 0): one unsigned comparison of the float bits
                 const uint32_t lim = __float_as_uint(b.y);
                 const uint64_t ok0 = __ballot(__float_as_uint(ex.x) <= lim), ok1 = __ballot(__float_as_uint(ex.y) <= lim);
-                const float2_t aT = pk_mul_nw(al, T2);                                                   // 255 alpha T
-                const float2_t tT = pk_fma_bhi_nw(aT, zk, T2);    // T (1 - alpha)
+                // aT = 255 alpha T, tT = T (1 - alpha): ONE asm block, so that the compiler's hazard recognizer (which puts a wait
+                // state behind every packed-f32 result that the next instruction reads; the hardware needs none:
+                // tools/microbench/pk_hazard.hip) cannot separate the pair
+                float2_t aT, tT;
+                if (RECORD) asm("v_pk_mul_f32 %0, %2, %3\n\tv_pk_fma_f32 %1, %0, %4, %3" : "=&v"(aT), "=v"(tT) : "v"(al), "v"(T2), "s"(kz2));
+                else asm("v_pk_mul_f32 %0, %2, %3\n\tv_pk_fma_f32 %1, %0, %4, %3 op_sel:[0,1,0]" : "=&v"(aT), "=v"(tT) : "v"(al), "v"(T2), "v"(zk));
                 const uint64_t room0 = __ballot(tT.x >= LSR_T_EPS), room1 = __ballot(tT.y >= LSR_T_EPS);
                 const uint64_t stop0 = ok0 & ~room0, stop1 = ok1 & ~room1;
-                const float w0 = __builtin_amdgcn_inverse_ballot_w64(ok0 & room0) ? aT.x : 0.0f;
-                const float w1 = __builtin_amdgcn_inverse_ballot_w64(ok1 & room1) ? aT.y : 0.0f;
+                const uint64_t hit0 = ok0 & room0, hit1 = ok1 & room1;
+                const float w0 = __builtin_amdgcn_inverse_ballot_w64(hit0) ? aT.x : 0.0f;
+                const float w1 = __builtin_amdgcn_inverse_ballot_w64(hit1) ? aT.y : 0.0f;
                 const float2_t ww = float2_t{w0, w1};
+                if (RECORD) {   // hist = 2 hist + (one of this lane's pixels blended the entry): one add-with-carry, the carry-in being the lane mask
+                    unsigned long long carry_out;
+                    asm volatile("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(hist), "=s"(carry_out) : "s"(hit0 | hit1));
+                }
 #pragma unroll
                 for (int c = 0; c < NCHP; c += 2) {
                     pk_fma_splat<false>(acc[c], pay[c / 2], ww);
                     pk_fma_splat<true>(acc[c + 1], pay[c / 2], ww);
                 }
                 pk_fma_splat<false>(D2, zk, ww);     // depth  += (z / 255) w'
-                pk_fma_splat<true>(T2, zk, ww);      // T      -= w' / 255
+                if (RECORD) asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(T2) : "s"(kz2), "v"(ww));   // T -= w' / 255
+                else pk_fma_splat<true>(T2, zk, ww);
                 if (stop0 | stop1) {  // rare, wave-uniform: a pixel's transmittance ran out here
                     // 1-based list position of the stopping entry, from its staging slot
                     const uint32_t pos = base + 1u + (off - wave_off) / (uint32_t)(kEnt * 16);
@@ -310,8 +344,36 @@ k_render_fwd(RenderFwdParams p) {
                     pxx = float2_t{st0 ? __builtin_nanf("") : pxx.x, st1 ? __builtin_nanf("") : pxx.y};   // never kept again
                     done0 |= stop0; done1 |= stop1;
                 }
+            };
+            if (!RECORD) {
+                for (uint32_t i = 0; i < nk; ++i) entry_step(i);
+            } else {
+                // chunks of 32 iterations (the history register); after a chunk the eight lanes of a group OR their
+                // histories and lane j marks the group's bit on the records of the entries of iterations j, j + 8, ...
+                const int l8 = lane & 7;
+                for (uint32_t c0 = 0; c0 < nk; c0 += 32u) {
+                    const uint32_t c1 = min(nk, c0 + 32u);
+                    hist = 0u;
+                    for (uint32_t i = c0; i < c1; ++i) entry_step(i);
+                    hist |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hist, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+                    hist |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hist, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+                    hist |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hist, 0x141, 0xf, 0xf, false);   // row_half_mirror
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t i = c0 + (uint32_t)(l8 + 8 * r);
+                        if (i < c1 && ((hist >> (c1 - 1u - i)) & 1u)) atomicOr((unsigned int *)(ent_base + lp[i] + 28), gbit);
+                    }
+                }
             }
             wave_lds_fence();  // WAR on the LDS slice before the next batch is staged
+            if (RECORD) {
+                // the staged entry's sub-block bits <- the sub-blocks it contributed to (a subset of them)
+                if (m) {
+                    const uint32_t hits = ((const uint32_t *)&s_ent[lane][1])[3] & 0xFFu;
+                    if (hits != m) p.half_list_rw[(hlist - p.half_list) + e] = (cur.w & kListIndexMask) | (hits << kListBitsShift);
+                }
+                wave_lds_fence();
+            }
         }
 
         // background colour through the scalar cache (constant address space; the table was written by an
@@ -807,6 +869,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.tile_start = (const uint32_t *)(geom + L.tile_start);
     p.half_count = (const uint32_t *)(geom + L.half_count);
     p.half_list = (const uint32_t *)(bin + B.half_list);
+    p.half_list_rw = (uint32_t *)(const_cast<char *>(bin) + B.half_list);
     p.ip = index_packing(d);
     p.out_color = out.color; p.out_feat = out.feature; p.out_mask = out.mask; p.out_depth = out.depth;
     p.final_T = (float *)(img + I.final_T); p.n_contrib = (uint32_t *)(img + I.n_contrib);
@@ -852,6 +915,17 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
         return hipGetLastError();
     }
     const int variant = env_int("LSR_FWD_VARIANT", 0);
+    // a forward that a backward will follow (lsr_dims::forward_flags) refines the lists' sub-block bits while it composites
+    // (k_render_fwd RECORD; the entries must carry bits: scenes of up to 2^24 Gaussians).  LSR_FWD_RECORD=0 turns it off.
+    const bool record = (d.forward_flags & LSR_FWD_FOR_BACKWARD) != 0 && p.ip.all_bits == 0u && env_int("LSR_FWD_RECORD", 1) != 0;
+#define LSR_RFR(N, WPB, WPC)                                                                               \
+    do {                                                                                                   \
+        p.waves_per_cu = (WPC);                                                                            \
+        hipLaunchKernelGGL((k_render_fwd<N, WPB, true>), dim3(p.num_cus * ((WPC) / (WPB))), dim3(LSR_WAVE * WPB), 0, s, p); \
+    } while (0)
+    if (record && nchp == 4 && variant == 0) LSR_RFR(4, 12, 24);
+    else if (record && nchp == 8) LSR_RFR(8, 16, 16);
+    else
     if (nchp == 4) { if (variant == 2) LSR_RF(4, 16, 16); else if (variant == 3) LSR_RF(4, 14, 28); else LSR_RF(4, 12, 24); }   // 2 x 12 waves per CU: 0.245 vs 0.281 ms per 16 views with 16
     // 7 / 8 channels (colour + 4 latent channels: the reference's configs[3] / [4] payload; 7.3 KB of LDS and 90 VGPRs per
     // wave).  Round 4 measured 2 x 10 waves per CU (what LDS and registers allow at most) and 2 x 8: configs[3] 0.1426 /
@@ -860,6 +934,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     else if (nchp == 12) LSR_RF(12, 12, 12);
     else LSR_RF(36, 4, 8);
 #undef LSR_RF
+#undef LSR_RFR
     prof_end(kStRenderFwd, s);
 #ifdef LSR_ENABLE_TRACE
     if (trace_path) {  // debug only: dump per-item timing of this launch

@@ -131,6 +131,26 @@ def get_color_sh_convention() -> str:
     return "reference" if _COLOR_SH_CONVENTION == _lib.SH_AXES_REFERENCE else "3dgs"
 
 
+# ---- speculative workspace sizing (lsr_forward_speculative) ----
+# The synchronous forward sizes its binning workspace after the device has counted the pairs, and the device idles while
+# the host turns that number into the next launches.  Calls of a shape that has been rendered before launch the whole
+# forward at once with room for 1.25 x the largest recent pair count (and a sort-tier hint above the longest recent tile
+# list) and read the true counts afterwards, while the device is already sorting: identical results, no idle gap.  A scene
+# that needs more than was provided is simply run again through the exact path (and raises the estimate).
+# LSR_SPECULATIVE=0 turns it off.
+_SPECULATE = __import__("os").environ.get("LSR_SPECULATIVE", "1") != "0"
+_ESTIMATES: dict = {}      # shape key -> [pairs, longest tile list] (decaying maxima of the recent calls)
+SPECULATION_STATS = dict(speculative=0, reruns=0, exact=0)
+
+
+def _tier_hint(longest: float) -> int:
+    """The sort-tier boundary (1024, 2048, 4096, 8192, ...) at or above 1.3 x the expected longest list."""
+    t = 1024
+    while t < 1.3 * longest:
+        t *= 2
+    return t
+
+
 class _Plan:
     """Everything one forward call hands to the matching backward."""
     __slots__ = ("dims", "geom", "bin", "img", "num_pairs", "radii", "V", "G", "H", "W", "C",
@@ -201,7 +221,9 @@ class _RasterizeViews(torch.autograd.Function):
         d = Dims(V, G, H, W, Cf, color_mode, int(sh_degree), K, *strides,
                  cov_elems, _lib.FEAT_SH if feat_sh else _lib.FEAT_DIRECT, max(int(feat_sh_degree), 0), Kf,
                  1 if (shs is not None and shs_channel_major) else 0, vpg if vpg > 1 else 0,
-                 _COLOR_SH_CONVENTION)
+                 _COLOR_SH_CONVENTION,
+                 # a backward will follow: the forward narrows the render lists to where every entry contributed
+                 _lib.FWD_FOR_BACKWARD if (torch.is_grad_enabled() and any(ctx.needs_input_grad)) else 0)
         inp = Inputs(_ptr(views), _ptr(means3D), _ptr(cov3D), _ptr(opacities), _ptr(color), _ptr(features))
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         u8 = dict(dtype=torch.uint8, device=dev)
@@ -226,24 +248,45 @@ class _RasterizeViews(torch.autograd.Function):
                 # latency mode: no host synchronisation; the pair count stays on the device
                 # (last_forward_status() reads it back when the caller wants to check for overflow)
                 npairs.value, maxtile.value = int(pair_capacity), int(max_tile_hint)
+                layout_pairs = npairs.value
                 binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), npairs.value, 2 ** 31 - 1), **u8)
                 _lib.check(lib.lsr_forward_nosync(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img),
                                                   npairs.value, maxtile.value, C.byref(outs), stream),
                            "lsr_forward_nosync")
             else:
-                try:
-                    _lib.check(lib.lsr_forward_prepare(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii),
-                                                       C.byref(npairs), C.byref(maxtile), stream),
-                               "lsr_forward_prepare")
-                    # the largest pair-count dependent allocation (the likeliest out-of-memory site of a forward)
-                    binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), npairs.value, maxtile.value), **u8)
-                    _lib.check(lib.lsr_forward_render(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img),
-                                                      npairs.value, maxtile.value, C.byref(outs), stream),
-                               "lsr_forward_render")
-                except BaseException:
-                    # (a no-op since ABI v7 — every launch of a forward is on the caller's stream — kept for v6 libraries)
-                    lib.lsr_forward_abandon(stream)
-                    raise
+                shape_key = (dev.index, V, G, H, W, Cf, color_mode, K, Kf, vpg, cov_elems, strides)
+                est = _ESTIMATES.get(shape_key) if (_SPECULATE and not debug and G > 0) else None
+                done = False
+                if est is not None and est[0] > 0:
+                    cap, hint = int(1.25 * est[0]) + 4096, _tier_hint(est[1])
+                    binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), cap, hint), **u8)
+                    ov = C.c_int32(0)
+                    _lib.check(lib.lsr_forward_speculative(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img), cap, hint,
+                                                           C.byref(outs), C.byref(npairs), C.byref(maxtile), C.byref(ov), stream),
+                               "lsr_forward_speculative")
+                    done = not ov.value
+                    SPECULATION_STATS["speculative" if done else "reruns"] += 1
+                    if done:
+                        layout_pairs = cap          # the workspace layout the backward has to use
+                if not done:
+                    SPECULATION_STATS["exact"] += 1
+                    try:
+                        _lib.check(lib.lsr_forward_prepare(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii),
+                                                           C.byref(npairs), C.byref(maxtile), stream),
+                                   "lsr_forward_prepare")
+                        # the largest pair-count dependent allocation (the likeliest out-of-memory site of a forward)
+                        binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), npairs.value, maxtile.value), **u8)
+                        _lib.check(lib.lsr_forward_render(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img),
+                                                          npairs.value, maxtile.value, C.byref(outs), stream),
+                                   "lsr_forward_render")
+                        layout_pairs = npairs.value
+                    except BaseException:
+                        # (a no-op since ABI v7 — every launch of a forward is on the caller's stream — kept for v6 libraries)
+                        lib.lsr_forward_abandon(stream)
+                        raise
+                if _SPECULATE:
+                    old = _ESTIMATES.get(shape_key, (0, 0))
+                    _ESTIMATES[shape_key] = (max(npairs.value, int(0.95 * old[0])), max(maxtile.value, int(0.95 * old[1])))
             if debug:
                 torch.cuda.synchronize(dev)
                 if pair_capacity <= 0:
@@ -258,7 +301,7 @@ class _RasterizeViews(torch.autograd.Function):
                                        f"with the host's {npairs.value}")
         plan = _Plan()
         plan.dims, plan.geom, plan.bin, plan.img = d, geom, binws, img
-        plan.num_pairs, plan.radii = npairs.value, radii
+        plan.num_pairs, plan.radii = layout_pairs, radii
         plan.V, plan.G, plan.H, plan.W, plan.C, plan.color_mode, plan.K = V, G, H, W, Cf, color_mode, K
         ctx.plan = plan
         LAST_STATS.update(num_pairs=None if pair_capacity > 0 else npairs.value, max_tile_pairs=maxtile.value, views=V,

@@ -206,7 +206,10 @@ print("HASH", h.hexdigest())
                 # front of its share for the per-pixel state only): the same gradient records as one wave per list
                 "bwd_unsplit_lists": dict(LSR_BWD_PARTS="0"), "bwd_eight_parts": dict(LSR_BWD_PARTS="3")}
     for name, extra in variants.items():
-        env = dict(os.environ, LSR_FWD_QUAD="0", **extra)
+        # (LSR_FWD_RECORD=0 throughout: the half-tile forward kernel narrows the render lists to the sub-blocks an entry
+        # contributed to when a backward follows, the row / sub-block kernels do not — the backward's float sums then
+        # group differently; test_forward_for_backward_narrows_the_render_lists_losslessly holds that to its own contract)
+        env = dict(os.environ, LSR_FWD_QUAD="0", LSR_FWD_RECORD="0", **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (name, r.stderr[-2000:])
         digests[name] = r.stdout.strip().splitlines()[-1]
@@ -275,3 +278,63 @@ def test_early_pair_count_equals_the_device_header(hip_device):
             dp, dm, ov = C.c_int64(0), C.c_int32(0), C.c_int32(0)
             _lib.check(lib.lsr_forward_status(C.byref(run.d), p(run.geom), C.byref(dp), C.byref(dm), C.byref(ov), stream), "status")
             assert (npairs.value, maxtile.value) == (dp.value, dm.value) == (run.P, run.maxtile)
+
+
+def test_speculative_forward_equals_exact_and_recovers_from_overflow(hip_device):
+    """Round 5: calls of a shape that has been rendered before launch the whole forward with a workspace sized from the
+    previous calls' pair counts and read the true counts afterwards (lsr_forward_speculative: no idle device between
+    the host's read and the next launches).  The results must be bit for bit those of the exact (prepare + render) path —
+    forward outputs, the workspaces the backward reads, gradients up to the order of their atomic sums — and a scene of
+    the same shape that needs MORE pairs or LONGER lists than provided must come out right as well (detected from the
+    counts, run again through the exact path)."""
+    from latentsplat_amd import rasterizer as rz
+    dev = hip_device
+    G, V, size = 24000, 3, 96
+    small = util.make_scene(G, image_size=size, views=V, color_sh_degree=1, feature_channels=4, seed=21)
+    big = util.make_scene(G, image_size=size, views=V, color_sh_degree=1, feature_channels=4, seed=22, sigma_px=(2.0, 12.0))   # ~6 x the pairs
+    def tensors(sc):
+        bi = util.boundary_inputs(sc, size, size, bg=(0.2, 0.1, 0.0))
+        return util.view_table(bi, dev), {k: bi[k].to(dev) for k in ("means", "cov6", "opac", "shs", "features")}
+    gen = torch.Generator().manual_seed(3)
+    g_col, g_feat = torch.randn((V, 3, size, size), generator=gen).to(dev), torch.randn((V, 4, size, size), generator=gen).to(dev)
+
+    def run(views, t):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+        out = rz.rasterize_views(views, size, size, 1, leaves["means"], leaves["cov6"], leaves["opac"], shs=leaves["shs"], features=leaves["features"])
+        st = rz.last_forward_status()
+        torch.autograd.backward([out[0], out[1]], [g_col, g_feat])
+        return [o.detach().clone() for o in out], {k: v.grad.clone() for k, v in leaves.items()}, st
+
+    def same(a, b, what):
+        for x, y in zip(a[0], b[0]):
+            assert torch.equal(x, y), what + ": forward outputs"
+        assert a[2] == b[2], (what, a[2], b[2])
+        for k in a[1]:
+            scale = max(1.0, float(b[1][k].abs().max()))
+            assert float((a[1][k] - b[1][k]).abs().max()) <= 2e-5 * scale, (what, k)
+
+    vs, ts = tensors(small)
+    vb, tb = tensors(big)
+    rz._ESTIMATES.clear()
+    stats0 = dict(rz.SPECULATION_STATS)
+    exact_small = run(vs, ts)                      # first call of the shape: exact path, records the estimate
+    assert rz.SPECULATION_STATS["exact"] == stats0["exact"] + 1 and rz.SPECULATION_STATS["speculative"] == stats0["speculative"]
+    spec_small = run(vs, ts)                       # second call: speculative, fits
+    assert rz.SPECULATION_STATS["speculative"] == stats0["speculative"] + 1
+    same(spec_small, exact_small, "speculative == exact")
+    spec_big = run(vb, tb)                         # same shape, far more pairs and longer lists: overflow -> exact re-run
+    assert rz.SPECULATION_STATS["reruns"] == stats0["reruns"] + 1
+    assert spec_big[2]["num_pairs"] > 2 * exact_small[2]["num_pairs"]
+    again_big = run(vb, tb)                        # the estimate has grown: speculative again
+    assert rz.SPECULATION_STATS["speculative"] == stats0["speculative"] + 2
+    rz._ESTIMATES.clear()
+    exact_big = run(vb, tb)
+    same(spec_big, exact_big, "overflow re-run == exact")
+    same(again_big, exact_big, "speculative after the re-run == exact")
+    # a hint that is too small on its own (the pair capacity fits): lists beyond it must be caught as well
+    key = next(iter(rz._ESTIMATES))
+    rz._ESTIMATES[key] = (rz._ESTIMATES[key][0], 16)
+    reruns = rz.SPECULATION_STATS["reruns"]
+    low_hint = run(vb, tb)
+    assert rz.SPECULATION_STATS["reruns"] == reruns + 1
+    same(low_hint, exact_big, "too small a tile hint == exact")

@@ -607,3 +607,64 @@ def test_single_pass_binning_equals_two_phase_and_falls_back_on_overflow(hip_dev
         finally:
             _lib.set_knob("LSR_SEGMENTS", 1)
             _lib.set_knob("LSR_SEG_CAP", 0)
+
+
+@pytest.mark.parametrize("case", [
+    dict(G=30_000, size=96, views=4, color_sh_degree=None, feature_channels=4),                      # 4 payload channels
+    dict(G=14_000, size=(80, 112), views=3, color_sh_degree=2, feature_channels=4),                  # 7 channels, ragged image
+    dict(G=4_000, size=64, views=4, color_sh_degree=None, feature_channels=4, sigma_px=(3.0, 25.0), opacity_scale=1.0),   # long lists, pixels that run out of transmittance
+])
+def test_forward_for_backward_narrows_the_render_lists_losslessly(hip_device, case):
+    """Round 5: a forward that a backward will follow (lsr_dims.forward_flags, set by the autograd op) records on which
+    sub-blocks every list entry contributed and narrows the entry's sub-block bits in the half-tile render list to those.
+    The images are untouched, the narrowed bits are a subset of the footprint-box bits, and the gradients the backward
+    computes from the narrowed lists are those from the original lists (up to the order of float sums)."""
+    from latentsplat_amd import _lib
+    from latentsplat_amd.rasterizer import rasterize_views
+    case = dict(case)
+    size = case.pop("size")
+    H, W = size if isinstance(size, tuple) else (size, size)
+    sc = util.make_scene(case.pop("G"), image_size=max(H, W), **case)
+    bi = util.boundary_inputs(sc, H, W, bg=(0.3, 0.2, 0.1))
+    dev = hip_device
+    try:
+        _lib.set_knob("LSR_FWD_ROWS", 0)          # the half-tile kernel (the one that records) whatever the batch size
+        plain = util.HipRun(bi, dev)
+        rec = util.HipRun(bi, dev, forward_flags=_lib.FWD_FOR_BACKWARD)
+        for a, b in ((plain.color_out, rec.color_out), (plain.feat_out, rec.feat_out), (plain.mask_out, rec.mask_out), (plain.depth_out, rec.depth_out)):
+            assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+        np.testing.assert_array_equal(plain.n_contrib(), rec.n_contrib())
+        np.testing.assert_array_equal(plain.point_list(), rec.point_list())
+        ts, hc, hp, hr = plain.tile_start(), plain.half_count(), plain.half_list(), rec.half_list()
+        np.testing.assert_array_equal(hc, rec.half_count())
+        before = after = 0
+        for vt in range(hc.shape[0]):
+            s0, n = ts[vt], ts[vt + 1] - ts[vt]
+            for h in range(2):
+                a = hp[2 * s0 + h * n: 2 * s0 + h * n + hc[vt, h]]
+                b = hr[2 * s0 + h * n: 2 * s0 + h * n + hc[vt, h]]
+                np.testing.assert_array_equal(a & 0x00FFFFFF, b & 0x00FFFFFF)            # the same entries in the same order
+                assert not ((b >> 24) & ~(a >> 24)).any(), "narrowed bits must be a subset of the footprint-box bits"
+                before += int(sum(bin(int(x)).count("1") for x in (a >> 24)))
+                after += int(sum(bin(int(x)).count("1") for x in (b >> 24)))
+        assert after < 0.97 * before, (before, after)
+        # gradients through the autograd op, with and without the narrowing
+        views = util.view_table(bi, dev)
+        t = {k: (None if bi[k] is None else bi[k].to(dev)) for k in ("means", "cov6", "opac", "shs", "features")}
+        gen = torch.Generator().manual_seed(13)
+        grads = {}
+        for record in (1, 0):
+            _lib.set_knob("LSR_FWD_RECORD", record)
+            leaves = {k: (None if v is None else v.clone().requires_grad_(True)) for k, v in t.items()}
+            out = rasterize_views(views, H, W, bi["sh_degree"], leaves["means"], leaves["cov6"], leaves["opac"], shs=leaves["shs"], features=leaves["features"])
+            outs = [o for o in out[:2] if o is not None]
+            gen.manual_seed(13)
+            torch.autograd.backward(outs, [torch.randn(o.shape, generator=gen).to(dev) for o in outs])
+            grads[record] = {k: v.grad.clone() for k, v in leaves.items() if v is not None}
+            assert torch.equal(out[2], plain.mask_out) and torch.equal(out[3], plain.depth_out)
+        for k in grads[1]:
+            scale = max(1.0, float(grads[0][k].abs().max()))
+            assert float((grads[1][k] - grads[0][k]).abs().max()) <= 2e-5 * scale, k
+    finally:
+        _lib.set_knob("LSR_FWD_ROWS", -1)
+        _lib.set_knob("LSR_FWD_RECORD", 1)

@@ -74,7 +74,7 @@ class HipRun:
     """Runs the HIP forward through the C ABI directly (no autograd) and keeps the workspaces so
     tests can read intermediates back."""
 
-    def __init__(self, bi: dict, device="cuda", shared_means=False):
+    def __init__(self, bi: dict, device="cuda", shared_means=False, forward_flags=0):
         from latentsplat_amd import _lib
         from latentsplat_amd._lib import Dims, Inputs, Layout, Outputs
         self.lib = lib = _lib.load()
@@ -94,7 +94,7 @@ class HipRun:
         assert self.features is None or self.features.shape[0] == V, \
             f"HipRun: features have leading dim {self.features.shape[0]}, expected {V} views"
         self.d = d = Dims(V, G, H, W, Cf, mode, bi["sh_degree"], K, 0 if shared_means else 3 * G,
-                          0 if shared_means else 6 * G, 0, 0, Cf * G if Cf else 0, 6, 0, 0, 0, 0, 0)
+                          0 if shared_means else 6 * G, 0, 0, Cf * G if Cf else 0, 6, 0, 0, 0, 0, 0, 0, forward_flags)
         p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
         self.inp = Inputs(p(self.views), p(self.means), p(self.cov6), p(self.opac), p(self.color), p(self.features))
         u8 = dict(dtype=torch.uint8, device=dev)
