@@ -161,7 +161,7 @@ class _RasterizeViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, views, means3D, means2D, cov3D, opacities, shs, colors_precomp, features,
                 H: int, W: int, sh_degree: int, debug: bool, feat_sh_degree: int = -1,
-                shs_channel_major: bool = False, pair_capacity: int = 0, max_tile_hint: int = 0):
+                shs_channel_major: bool = False, pair_capacity: int = 0, max_tile_hint: int = 0, grad_mode: bool = True):
         lib = _lib.load()
         ctx.set_materialize_grads(False)  # unused outputs (mask / depth ...) arrive as None, not zeros
         dev = means3D.device
@@ -223,7 +223,8 @@ class _RasterizeViews(torch.autograd.Function):
                  1 if (shs is not None and shs_channel_major) else 0, vpg if vpg > 1 else 0,
                  _COLOR_SH_CONVENTION,
                  # a backward will follow: the forward narrows the render lists to where every entry contributed
-                 _lib.FWD_FOR_BACKWARD if (torch.is_grad_enabled() and any(ctx.needs_input_grad)) else 0)
+                 # (grad_mode: torch.is_grad_enabled() of the CALLER — inside Function.forward it is always off)
+                 _lib.FWD_FOR_BACKWARD if (grad_mode and any(ctx.needs_input_grad)) else 0)
         inp = Inputs(_ptr(views), _ptr(means3D), _ptr(cov3D), _ptr(opacities), _ptr(color), _ptr(features))
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         u8 = dict(dtype=torch.uint8, device=dev)
@@ -376,7 +377,7 @@ class _RasterizeViews(torch.autograd.Function):
         # order: views, means3D, means2D, cov3D, opacities, shs, colors_precomp, features, H, W, deg,
         #        debug, feat_sh_degree, shs_channel_major
         return (None, d_means, d_m2d, d_cov, d_opac, d_color if has_shs else None,
-                d_color if has_cp else None, d_feat, None, None, None, None, None, None, None, None)
+                d_color if has_cp else None, d_feat, None, None, None, None, None, None, None, None, None)
 
 
 def rasterize_views(views: Tensor, image_height: int, image_width: int, sh_degree: int, means3D: Tensor,
@@ -413,7 +414,7 @@ def rasterize_views(views: Tensor, image_height: int, image_width: int, sh_degre
     color, feat, mask, depth, radii = _RasterizeViews.apply(
         views, means3D, means2D, cov3D_precomp, opacities, shs, colors_precomp, features,
         int(image_height), int(image_width), int(sh_degree), bool(debug), int(feat_sh_degree),
-        bool(shs_channel_major), int(pair_capacity or 0), int(max_tile_hint))
+        bool(shs_channel_major), int(pair_capacity or 0), int(max_tile_hint), torch.is_grad_enabled())
     return (color if color.numel() else None, feat if feat.numel() else None, mask, depth, radii)
 
 
@@ -513,6 +514,6 @@ class GaussianRasterizer(nn.Module):
         views = _pack_view(rs, means3D.device)
         color, feat, mask, depth, radii = _RasterizeViews.apply(
             views, means3D, means2D, cov3D_precomp, opacities, shs, colors_precomp, features,
-            int(rs.image_height), int(rs.image_width), int(rs.sh_degree), bool(rs.debug), -1, False)
+            int(rs.image_height), int(rs.image_width), int(rs.sh_degree), bool(rs.debug), -1, False, 0, 0, torch.is_grad_enabled())
         return (color[0] if color.numel() else None, feat[0] if feat.numel() else None,
                 mask, depth, radii[0])
