@@ -175,7 +175,10 @@ inline GradLayout grad_layout(const lsr_dims &d) {
     const size_t VG = (size_t)d.num_views * (size_t)d.num_gaussians;
     L.rec_floats = grad_rec_floats(d);
     L.rec = 0;
-    L.fixed = align_up(VG * (size_t)L.rec_floats * 4 + 256);   // [V*G][rec_floats] int64, deterministic mode only
+    // behind the float records: 512 zeroed bytes — the compositing backward's work-queue word (fixed - 512) and one all-zero
+    // record line (fixed - 256) that the per-Gaussian backward kernels read in place of the records of CULLED (view,
+    // Gaussian) slots: one cached line instead of a third of the record array
+    L.fixed = align_up(VG * (size_t)L.rec_floats * 4 + 512);   // [V*G][rec_floats] int64, deterministic mode only
     L.total = L.fixed + (deterministic_backward() ? align_up(VG * (size_t)L.rec_floats * 8) : 0);
     return L;
 }
@@ -298,6 +301,9 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
 hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                  const char *bin, int64_t num_pairs, char *img, const lsr_outputs &out,
                                  hipStream_t s);
+// Zeroes what the compositing backward accumulates into: the gradient records, the queue / zero-line slack and, in
+// deterministic mode, the fixed-point records.
+hipError_t launch_clear_grad(const lsr_dims &d, const int32_t *radii, char *grad, hipStream_t s);
 hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom,
                                   const char *bin, int64_t num_pairs, const char *img,
                                   const lsr_outputs &fwd, const lsr_out_grads &gout, char *grad,

@@ -25,6 +25,7 @@ struct PreBwdParams {
     const float *geo;       // screen-space records; slot 7 = colour clamp bits (SH mode)
     int geo_floats;
     const float *rec;       // packed gradient records (lsr_internal.h GradLayout)
+    const float *zero_rec;  // an all-zero record line: read in place of the (uncleared, unwritten) record of a culled slot
     int rec_floats;
     lsr_in_grads g;
     GroupStrides gs;        // view groups (blockIdx.y): element offsets of the next group's slices
@@ -77,11 +78,13 @@ k_preprocess_bwd(PreBwdParams pk) {
     const int v_first = feat_rmw ? 0 : part, v_step = feat_rmw ? 1 : PARTS, v_end = (feat_rmw && part != 0) ? 0 : V;   // all wave-uniform
     for (int v = v_first; v < v_end; v += v_step) {
         const size_t o = (size_t)v * G + i;
-        const float *rc = p.rec + o * p.rec_floats;
+        const bool vis = p.radii[o] > 0;
+        // (the records of culled slots are not cleared: their lanes read the zero line — one cached line instead of 32 % of
+        // the record array)
+        const float *rc = vis ? p.rec + o * p.rec_floats : p.zero_rec;
         const float4 r0 = *(const float4 *)rc, r1 = *(const float4 *)(rc + 4);           // m1x m1y m2xx m2xy | m2yy m0 gz -
         float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q1 = q0;
         if (pay16) { q0 = *(const float4 *)(rc + 8); q1 = *(const float4 *)(rc + 12); }
-        const bool vis = p.radii[o] > 0;
         // opacity: the record holds m0 = sum opacity * G * dL/dalpha; dL/dopacity = m0 / opacity
         // (m0 != 0 implies opacity >= 1/255)
         if (d.vs_opac != 0) {
@@ -311,6 +314,7 @@ hipError_t launch_preprocess_backward(const lsr_dims &d_all, const lsr_inputs &i
     p.gs = group_strides(d_all);
     p.geo = (const float *)(geom + L.rec); p.geo_floats = L.rec_floats;
     p.rec = (const float *)(grad + R.rec); p.rec_floats = R.rec_floats;
+    p.zero_rec = (const float *)(grad + R.fixed - 256);
     p.g = gin;
     prof_begin(kStPreprocessBwd, s);
     const int parts = d.num_views >= 4 ? 4 : (d.num_views >= 2 ? 2 : 1);

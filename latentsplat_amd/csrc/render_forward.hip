@@ -281,10 +281,15 @@ k_render_fwd(RenderFwdParams p) {
             trace_iters += nk;
 #endif
             uint32_t hist = 0u;    // RECORD: one bit per iteration of the current chunk, newest in bit 0: this lane's pixels took part
+            // RECORD: the list word of the NEXT iteration is read while this one computes (row 64 of a list is its pad word).
+            // Measured between two builds (profiles/r05_ab_knobs.md): the RECORD instance 0.228 -> 0.221 ms per 16 views, the
+            // plain instance 0.2051 -> 0.2080 — so only here.
+            uint32_t off_next = RECORD ? lp[0] : 0u;
             auto entry_step = [&](uint32_t i) __attribute__((always_inline)) {
-                const uint32_t off = lp[i];
+                const uint32_t off = RECORD ? off_next : lp[i];
                 const float4 *E = (const float4 *)(ent_base + off);
                 const float4 a = E[0], b = E[1];
+                if (RECORD) off_next = lp[i + 1];
                 float2_t pay[NCHP / 2];     // (c, c+1) pairs: either half is broadcast to both pixels by the packed ops' op_sel
 #pragma unroll
                 for (int c4 = 0; c4 < NCHP / 4; ++c4) {

@@ -50,7 +50,11 @@ __global__ void __launch_bounds__(64 * kWaves) k_valu(const Entry *ents, float *
         s_ent[wid][lane][0] = make_float4(e.x, e.y, e.a2, e.c2);
         s_ent[wid][lane][1] = make_float4(e.b2, e.l2o, e.z * kInv255, -kInv255);
         s_ent[wid][lane][2] = make_float4(e.pay[0] * kInv255, e.pay[1] * kInv255, e.pay[2] * kInv255, e.pay[3] * kInv255);
+#ifdef DISTINCT   // every lane group at a DIFFERENT staged entry per iteration, as in the product kernel (8 distinct records per LDS read)
+        for (int b = 0; b < 8; ++b) s_list[wid][b][lane] = (uint32_t)((wid * kEntries + ((lane * 5 + b * 7) & (kEntries - 1))) * 48);
+#else
         for (int b = 0; b < 8; ++b) s_list[wid][b][lane] = (uint32_t)((wid * kEntries + lane) * 48);
+#endif
     }
     __syncthreads();
     const int grp = lane >> 3, gcol = grp & 3, grow = grp >> 2, lx = 2 * (lane & 1), ly = (lane >> 1) & 3;
@@ -119,7 +123,11 @@ __global__ void __launch_bounds__(64 * kWaves) k_mfma(const Entry *ents, float *
         s_coef[wid][g][lane][1] = make_float2(c1, e.c2);      // m1 = u,  m5 = v^2
         s_coef[wid][g][lane][2] = make_float2(c2, 0.0f);      // m2 = v
         s_coef[wid][g][lane][3] = make_float2(e.a2, 0.0f);    // m3 = u^2
+#ifdef DISTINCT
+        s_list[wid][g][lane] = (lane * 5 + g * 7) & (kEntries - 1);
+#else
         s_list[wid][g][lane] = lane;
+#endif
     }
     s_pay[wid][lane] = make_float4(e.pay[0] * kInv255, e.pay[1] * kInv255, e.pay[2] * kInv255, e.pay[3] * kInv255);
     s_lz[wid][lane] = make_float2(e.l2o, e.z * kInv255);
@@ -202,11 +210,18 @@ int main() {
     std::vector<unsigned long long> c(blocks * kWaves);
     double per256[2] = {0, 0};
     for (int variant = 0; variant < 2; ++variant) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        float ms = 0.0f;
         for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(e0, 0);
             if (variant == 0) hipLaunchKernelGGL(k_valu, dim3(blocks), dim3(64 * kWaves), 0, 0, d_e, d_out, d_cyc, reps);
             else hipLaunchKernelGGL(k_mfma, dim3(blocks), dim3(64 * kWaves), 0, 0, d_e, d_out, d_cyc, reps);
+            (void)hipEventRecord(e1, 0);
             (void)hipDeviceSynchronize();
+            (void)hipEventElapsedTime(&ms, e0, e1);
         }
+        printf("  kernel %.3f ms (hipEvents)\n", ms);
         (void)hipMemcpy(variant ? o2.data() : o1.data(), d_out, sizeof(float) * o1.size(), hipMemcpyDeviceToHost);
         (void)hipMemcpy(c.data(), d_cyc, 8 * c.size(), hipMemcpyDeviceToHost);
         double mean = 0;
@@ -214,6 +229,8 @@ int main() {
         mean /= c.size();
         // a wave performs (variant 0: kEntries iterations x 128, variant 1: kEntries / 4 steps x 256) evaluations per rep; 6 waves share a SIMD
         const double evals = (variant == 0 ? kEntries * 128.0 : (kEntries / 4) * 256.0) * reps;
+        // (a wave's lifetime against the kernel's: all 24 waves of a CU resident together <=> the two agree)
+        printf("  mean wave lifetime %.3f ms at 2.42 GHz\n", mean / 2.42e6);
         per256[variant] = mean / evals * 256.0 / 6.0;
         printf("%s: %.0f cycles per wave for %d batches -> %.1f shader cycles per 256 evaluations per SIMD (6 waves per SIMD)\n",
                variant ? "k_mfma (1 pixel / lane, 2 MFMA per 256 evaluations)" : "k_valu (today's loop)", mean, reps, per256[variant]);
