@@ -61,7 +61,7 @@ constexpr int kScatItems = 12;   // most (view, Gaussian) items of one thread; t
 // tiles.  The synchronous forward launches it when the host has seen such a list, the no-sync forward always (every
 // workgroup leaves at once when the header's longest list fits).
 template <bool LDS_RESERVE, bool NARROW>
-__global__ void __launch_bounds__(kScatThreads, 8)
+__global__ void __launch_bounds__(kScatThreads, NARROW ? 8 : 6)   // (the wide-coordinate instance, images beyond 4080 px a side, keeps two words per rectangle: 80 registers instead of a spill)
 k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
           const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ tile_cursor,
           uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, uint32_t key_shift, unsigned long long *trace,

@@ -14,7 +14,11 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python be
 bash tools/pmc_profile.sh $TAG --steps 3 --warmup 1 --clock-warmup 0 --no-cpu-baseline --no-latency > /dev/null 2>&1
 python tools/rocpd_summary.py $OUT/stats/bench_results.db "$TAG ($LSR_PROFILE_COMMIT): python bench.py --steps 40 (16 views x 300k Gaussians, 256x256; fwd then fwd+bwd, decoder legs)" > $OUT/kernel_stats.md
 python tools/pmc_summary.py gpurun_out/pmc_$TAG --traffic-json $OUT/traffic_render_forward.json > $OUT/pmc.md
+# the headline workload ALONE (forward, 16 views x 300 k: one launch shape per kernel), so that per-kernel rates quoted in
+# DESIGN.md (LDS bank conflicts, VALU busy) can be recomputed from a file under profiles/
+bash tools/pmc_profile.sh ${TAG}_headline --steps 3 --warmup 1 --clock-warmup 0 --no-cpu-baseline --no-latency --no-bwd > /dev/null 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_${TAG}_headline > $OUT/pmc_headline.md
 # gpurun merges at most 64 MiB back: keep the summaries, drop the raw databases / traces they were made from
-rm -rf $OUT/stats gpurun_out/pmc_$TAG
+rm -rf $OUT/stats gpurun_out/pmc_$TAG gpurun_out/pmc_${TAG}_headline
 du -sh gpurun_out | tail -1
 cat $OUT/bench.json
