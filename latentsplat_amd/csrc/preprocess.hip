@@ -200,8 +200,9 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
         }
     }
     if (SEG) {
-        // ---- reserve: count -> first slot of this workgroup in the tile's segment (the counter becomes the cursor) ----
+        // ---- reserve: count -> first slot of this workgroup in the tile's segment ----
         __syncthreads();
+        uint32_t *s_first = s_hist + VB * T;      // (the dynamic allocation holds two arrays of VB * T words in this instance)
         // (four counters per thread and round, their returning atomics in flight together: one round trip to the
         // memory-side atomic unit per round instead of one per counter.  Only non-empty counters issue an atomic — adds of
         // zero to a clamped address put thousands of same-address atomics of EVERY workgroup on one word: measured 5.5 ms
@@ -222,49 +223,79 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int t = t0 + k * kPreThreads;
-                if (t < VB * T) s_hist[t] = first[k];
+                if (t < VB * T) s_first[t] = first[k];
             }
         }
         __syncthreads();
-        // ---- emit: the same (Gaussian, view) items in the same order; a thread reads back the records it wrote ----
         const uint32_t cap = seg.cap;
+        // ---- emit, one view of the workgroup at a time, THROUGH LDS: the keys are first bucketed by tile in the (now idle)
+        // record staging array — a key's slot is its tile's local offset (exclusive scan of the workgroup's counts) plus its
+        // arrival rank — together with their final positions, and then leave as one linear pass over the slots: every
+        // lane stores, and the lanes of a tile's run hit consecutive addresses.  Written straight from the item loop (the
+        // first version of this pass) the same keys were 7.4 M lane-scattered 8-byte stores at 31 % lane utilisation: 0.053
+        // of the kernel's 0.155 ms (ablations in profiles/r05_ab_knobs.md); a thread still reads back only the binning
+        // records it wrote itself. ----
+        constexpr int KI = kPreItems / VB;                               // most Gaussians per thread
+        uint32_t *s_delta = (uint32_t *)s_rec;                           // [T] first slot in the segment minus local offset
+        const int kbase = (T * 4 + 7) & ~7;
+        uint64_t *s_key = (uint64_t *)((char *)s_rec + kbase);
+        const uint32_t buf = (uint32_t)((sizeof(s_rec) - kbase) / 12);
+        uint32_t *s_pos = (uint32_t *)((char *)s_rec + kbase + (size_t)buf * 8);
+        __shared__ uint32_t s_scanw[kPreThreads / LSR_WAVE];
+        const int tpt = (T + kPreThreads - 1) / kPreThreads;             // tiles per thread of the scan (<= 4: T <= 1024)
 #pragma unroll 1
-        for (int it = 0; it < kItems; ++it) {
-            const int chunk0 = base + it * kPreThreads;
-            if (chunk0 >= G || (seg.ablate & 2u)) break;   // block-uniform
-            const int i = chunk0 + threadIdx.x;
-            const bool in_range = i < G;
-            const size_t ii = in_range ? (size_t)i : 0;
-            // the records of this Gaussian in the block's views: unconditional loads at clamped addresses, all in
-            // flight together (a load under a per-lane condition is waited for at the join)
-            uint3 br[VB];
+        for (int vb = 0; vb < VB; ++vb) {
+            const int v = v0 + vb;
+            if (v >= d.num_views || (seg.ablate & 2u)) break;             // block-uniform
+            uint32_t *cur = s_hist + vb * T;
+            // local offsets of this view's tiles: a contiguous chunk of tiles per thread
+            uint32_t cnt[4], mine = 0;
 #pragma unroll
-            for (int vb = 0; vb < VB; ++vb) {
-                const int vc = min(v0 + vb, d.num_views - 1);
-                br[vb] = *(const uint3 *)(binrec + ((size_t)vc * G + ii) * sizeof(BinRec));
+            for (int k = 0; k < 4; ++k) {
+                const int t = (int)threadIdx.x * tpt + k;
+                cnt[k] = (k < tpt && t < T) ? cur[t] : 0u;
+                mine += cnt[k];
+            }
+            uint32_t n_v;
+            uint32_t off = block_exclusive_scan<kPreThreads>(mine, s_scanw, n_v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = (int)threadIdx.x * tpt + k;
+                if (k < tpt && t < T) { cur[t] = off; s_delta[t] = s_first[vb * T + t] - off; off += cnt[k]; }
+            }
+            __syncthreads();
+            const uint32_t seg0 = (uint32_t)v * (uint32_t)T;
+            // this view's records of the thread's Gaussians: unconditional loads at clamped addresses, all in flight together
+            uint3 br[KI];
+#pragma unroll
+            for (int it = 0; it < KI; ++it) {
+                const int i = min(base + min(it, kItems - 1) * kPreThreads + (int)threadIdx.x, G - 1);
+                br[it] = *(const uint3 *)(binrec + ((size_t)v * G + (size_t)i) * sizeof(BinRec));
             }
 #pragma unroll
-            for (int vb = 0; vb < VB; ++vb) {
-                const int v = v0 + vb;
-                const uint32_t rc = (in_range && v < d.num_views) ? br[vb].x : 0u;   // (a culled record holds an empty rectangle)
+            for (int it = 0; it < KI; ++it) {
+                const int i = base + it * kPreThreads + (int)threadIdx.x;
+                const uint32_t rc = (it < kItems && i < G) ? br[it].x : 0u;     // (a culled record holds an empty rectangle)
                 const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff, y1 = rc >> 24;
-                const uint64_t key = ((uint64_t)br[vb].y << 32) | ((uint32_t)i << seg.key_shift);
-                const uint32_t sp = br[vb].z;
-                uint32_t *cur = s_hist + vb * T;
-                const uint32_t seg0 = (uint32_t)v * (uint32_t)T;
+                const uint64_t key = ((uint64_t)br[it].y << 32) | ((uint32_t)i << seg.key_shift);
+                const uint32_t sp = br[it].z;
                 for (int y = y0; y < y1; ++y)
                     for (int x = x0; x < x1; ++x) {
                         const int t = y * gx + x;
-                        const uint32_t pos = atomicAdd(&cur[t], 1u);
+                        const uint32_t slot = atomicAdd(&cur[t], 1u);
                         const uint32_t code = seg.key_shift ? span_code(sp, x - x0, y - y0) : 0u;
-                        // clamped, not tested (a store under a per-lane condition cost k_scatter 17 %): the surplus keys of
-                        // an overfull segment land on its last slot; such a tile is binned again by the fallback scatter
-                        if (seg.ablate & 4u) {      // timing experiment: the same number of stores, perfectly coalesced (wrong results)
-                            seg.keys[(size_t)((blockIdx.x & 1023u) * 4096u + ((threadIdx.x + 256u * (pos & 15u)) & 4095u))] = key | code;
-                        } else
-                        if (!(seg.ablate & 1u)) seg.keys[(size_t)((seg0 + (uint32_t)t) * cap + min(pos, cap - 1u))] = key | code;
+                        // position in the tile's segment, CLAMPED (not tested): the surplus keys of an overfull segment land
+                        // on its last slot; such a tile is binned again by the fallback scatter
+                        const uint32_t pos = (seg0 + (uint32_t)t) * cap + min(slot + s_delta[t], cap - 1u);
+                        if (slot < buf) { s_key[slot] = key | code; s_pos[slot] = pos; }
+                        else seg.keys[pos] = key | code;              // (more pairs in one view of this workgroup than the array holds)
                     }
             }
+            __syncthreads();
+            const uint32_t nflush = min(n_v, buf);
+            if (!(seg.ablate & 1u))
+                for (uint32_t j = threadIdx.x; j < nflush; j += kPreThreads) seg.keys[s_pos[j]] = s_key[j];
+            __syncthreads();
         }
     }
     // ---- the tile scan, folded in (round 4; it used to be a kernel of its own between this one and k_scatter): the LAST
@@ -340,7 +371,9 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     // workgroups per CU — a single 300 k view was 147 workgroups of 8 sequential Gaussians per thread on 256 CUs
     const int64_t yblocks = (d.num_views + vb - 1) / vb;
     const int64_t fill = ((int64_t)d.num_gaussians * yblocks + (int64_t)kPreThreads * 2 * device_cus() - 1) / ((int64_t)kPreThreads * 2 * device_cus());
-    const int pre_items = std::max(1, env_int("LSR_PRE_ITEMS", kPreItems));   // (development knob: (Gaussian, view) items per thread and histogram flush)
+    // (development knob: (Gaussian, view) items per thread and histogram flush; the key emission of the single-pass binning
+    // keeps a thread's binning records in registers: never more than kPreItems there)
+    const int pre_items = seg_mode ? std::min(kPreItems, std::max(1, env_int("LSR_PRE_ITEMS", kPreItems))) : std::max(1, env_int("LSR_PRE_ITEMS", kPreItems));
     const int items = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1, pre_items / vb), fill));
     dim3 grid((d.num_gaussians + kPreThreads * items - 1) / (kPreThreads * items), (unsigned)yblocks);
     float *rec = (float *)(geom + L.rec);
@@ -351,7 +384,7 @@ hipError_t launch_preprocess(const lsr_dims &d, const lsr_inputs &in, char *geom
     FoldedScan fs = fs_in;
     fs.tile_start = (uint32_t *)(geom + L.tile_start); fs.tile_order = (uint32_t *)(geom + L.tile_order);
     const bool lds = (size_t)T * vb <= 4096;
-    const size_t shm = lds ? (size_t)T * vb * 4 : 0;
+    const size_t shm = lds ? (size_t)T * vb * 4 * (seg_mode ? 2 : 1) : 0;   // (single-pass binning: counts and first slots)
     const bool fma = projection_contraction();
     // single-pass binning: the caller asks for it only when segment_capacity(d) > 0, which implies byte tile coordinates
     // and T <= 1024 (the LDS histogram of up to 4 views)
