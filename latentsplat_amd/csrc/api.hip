@@ -93,7 +93,7 @@ uint32_t lsr::segment_capacity(const lsr_dims &d) {
     if (!env_int("LSR_SEGMENTS", 1) || d.num_gaussians <= 0) return 0u;
     const int64_t T = num_tiles(d);
     if (!narrow_bins(d) || T > 1024) return 0u;
-    if (fused_preprocess_sh(d)) return 0u;        // (k_preprocess_sh keeps the two-phase path for now)
+    if (fused_preprocess_sh(d) && !fused_segments_fit(d)) return 0u;   // (its LDS: coefficient rows + two count arrays)
     const int64_t VT = (int64_t)d.num_views * T;
     const int64_t budget = (int64_t)env_int("LSR_SEG_BUDGET_MB", 512) << 20;
     int64_t cap = 8192;
@@ -465,7 +465,7 @@ int launch_front(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *r
     FoldedScan fs{};
     fs.enabled = fold ? 1 : 0;
     fs.host_words = mapped ? hw->dev : nullptr; fs.host_seq = seq; fs.capacity = capacity;
-    if (fused_preprocess_sh(d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(d, in, geom, radii, fs, s));
+    if (fused_preprocess_sh(d)) LSR_STAGE("preprocess_sh", s, launch_preprocess_sh(d, in, geom, radii, fs, seg, s));
     else LSR_STAGE("preprocess", s, launch_preprocess(d, in, geom, radii, fs, seg, s));
     if (fold && mapped) LSR_HIP(hipEventRecord(hw->event, s));
     int rc = sh_forward_inline(d, in, geom, s);   // view-dependent payload of calls the fused kernel does not cover

@@ -290,7 +290,9 @@ hipError_t launch_sh_forward(const lsr_dims &d, const lsr_inputs &in, char *geom
 // Projection + SH payload as one kernel (sh.hip k_preprocess_sh) for calls whose payload is harmonics only and whose
 // views share their inputs; replaces launch_preprocess + launch_sh_forward when fused_preprocess_sh(d).
 bool fused_preprocess_sh(const lsr_dims &d);
-hipError_t launch_preprocess_sh(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, const FoldedScan &fs, hipStream_t s);
+// (seg: single-pass binning, as launch_preprocess; segment_capacity(d) > 0 only when fused_segments_fit(d))
+hipError_t launch_preprocess_sh(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, const FoldedScan &fs, bool seg, hipStream_t s);
+bool fused_segments_fit(const lsr_dims &d);   // sh.hip: the fused kernel's LDS holds the single-pass binning's arrays for these dims
 hipError_t launch_sh_backward(const lsr_dims &d, const lsr_inputs &in, const char *geom, const char *grad,
                               const lsr_in_grads &gin, hipStream_t s);
 // device_counts: the pair count / longest list are NOT known on the host (no-sync forward):

@@ -280,12 +280,13 @@ struct PreShArgs {
     int lds_hist;       // tile histogram of the group's views privatised in LDS (behind the coefficient rows)
     int hist_off;       // its offset in the dynamic LDS allocation, in words
     int views_total;    // views of the whole call (the scan's count array)
+    SegOut seg;         // single-pass binning (SEG instances): the key segments; the coefficient area doubles as the bucket array
 };
 
 #ifndef LSR_PSH_WAVES
 #define LSR_PSH_WAVES 1
 #endif
-template <int DEGC, int COFF, bool FMA>
+template <int DEGC, int COFF, bool FMA, bool SEG>
 __global__ void __launch_bounds__(kShThreads, LSR_PSH_WAVES)
 k_preprocess_sh(ShParams pk, PreShArgs a) {
     const ShParams p = group_params(pk);
@@ -417,11 +418,90 @@ k_preprocess_sh(ShParams pk, PreShArgs a) {
             }
         }
     }
-    if (a.lds_hist) {
+    if (a.lds_hist && !SEG) {
         __syncthreads();
         for (int t = tid; t < V * T; t += kShThreads) {
             const uint32_t cnt = s_hist[t];
             if (cnt) atomicAdd(&tile_count[t], cnt);
+        }
+    }
+    if (SEG) {
+        // ---- single-pass binning (round 5), as in k_preprocess: reserve this workgroup's slots in the tiles' key segments
+        // with the returning form of the count atomics, then emit the keys of its (view, Gaussian) items view by view
+        // through an LDS bucket pass (the coefficient rows are dead by now: their area holds the buckets) ----
+        __syncthreads();
+        uint32_t *s_first = s_hist + V * T;
+        for (int t0 = tid; t0 < V * T; t0 += 4 * kShThreads) {
+            uint32_t c[4], first[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int t = t0 + k * kShThreads; c[k] = t < V * T ? s_hist[t] : 0u; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = t0 + k * kShThreads;
+                if (c[k]) first[k] = __hip_atomic_fetch_add(&tile_count[t], c[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int t = t0 + k * kShThreads; if (t < V * T) s_first[t] = first[k]; }
+        }
+        __syncthreads();
+        const uint32_t cap = a.seg.cap;
+        uint32_t *s_delta = (uint32_t *)s_lds;
+        const int kbase = (T * 4 + 7) & ~7;
+        uint64_t *s_key = (uint64_t *)((char *)s_lds + kbase);
+        const uint32_t buf = (uint32_t)(((size_t)a.hist_off * 4 - kbase) / 12);
+        uint32_t *s_pos = (uint32_t *)((char *)s_lds + kbase + (size_t)buf * 8);
+        __shared__ uint32_t s_scanw[kShWaves];
+        const int tpt = (T + kShThreads - 1) / kShThreads;
+#pragma unroll 1
+        for (int v = 0; v < V; ++v) {
+            uint32_t *cur = s_hist + v * T;
+            uint32_t cnt[4], mine = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = tid * tpt + k;
+                cnt[k] = (k < tpt && t < T) ? cur[t] : 0u;
+                mine += cnt[k];
+            }
+            uint32_t n_v;
+            uint32_t off = block_exclusive_scan<kShThreads>(mine, s_scanw, n_v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = tid * tpt + k;
+                if (k < tpt && t < T) { cur[t] = off; s_delta[t] = s_first[v * T + t] - off; off += cnt[k]; }
+            }
+            __syncthreads();
+            const uint32_t seg0 = (uint32_t)(view0 + v) * (uint32_t)T;
+            // the workgroup's Gaussians of this view: wave w takes chunks w, w + 4 (records written by whichever wave
+            // projected the view: visible since the barrier above)
+            uint3 br[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = min(wave + kShWaves * k, a.chunks - 1);
+                const int i = min((blockIdx.x * a.chunks + c) * LSR_WAVE + lane, G - 1);
+                br[k] = *(const uint3 *)(binrec + ((size_t)v * G + (size_t)i) * sizeof(BinRec));
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = wave + kShWaves * k;
+                const int i = (blockIdx.x * a.chunks + c) * LSR_WAVE + lane;
+                const uint32_t rc = (c < a.chunks && i < G) ? br[k].x : 0u;
+                const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff, y1 = rc >> 24;
+                const uint64_t key = ((uint64_t)br[k].y << 32) | ((uint32_t)i << a.seg.key_shift);
+                const uint32_t sp = br[k].z;
+                for (int y = y0; y < y1; ++y)
+                    for (int x = x0; x < x1; ++x) {
+                        const int t = y * gx + x;
+                        const uint32_t slot = atomicAdd(&cur[t], 1u);
+                        const uint32_t code = a.seg.key_shift ? span_code(sp, x - x0, y - y0) : 0u;
+                        const uint32_t pos = (seg0 + (uint32_t)t) * cap + min(slot + s_delta[t], cap - 1u);
+                        if (slot < buf) { s_key[slot] = key | code; s_pos[slot] = pos; }
+                        else a.seg.keys[pos] = key | code;
+                    }
+            }
+            __syncthreads();
+            const uint32_t nflush = min(n_v, buf);
+            for (uint32_t j = tid; j < nflush; j += kShThreads) a.seg.keys[s_pos[j]] = s_key[j];
+            __syncthreads();
         }
     }
     // ---- the tile scan in the last workgroup to arrive (as in k_preprocess; the counts pass through LDS) ----
@@ -734,7 +814,21 @@ bool fused_preprocess_sh(const lsr_dims &d) {
     return shared || d.views_per_group > 1;
 }
 
-hipError_t launch_preprocess_sh(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, const FoldedScan &fs_in, hipStream_t s) {
+// words of the fused kernel's coefficient area (what make_params / launch_preprocess_sh lay out), from the dims alone
+static size_t coef_words_of(const lsr_dims &d) {
+    const int ks0 = group_enabled(d, 0) ? d.sh_coeffs * 3 : 0, ks1 = group_enabled(d, 1) ? d.feat_sh_coeffs * d.feat_channels : 0;
+    const size_t offF = ((size_t)LSR_WAVE * ks0 + 3) & ~(size_t)3;
+    return offF + (size_t)LSR_WAVE * ks1;
+}
+// single-pass binning in the fused kernel: coefficient area (at least 16 KB: it doubles as the bucket array) + the tile
+// histogram + the first-slot array of the group's views within the 64 KB a launch gets without a function attribute
+bool fused_segments_fit(const lsr_dims &d) {
+    const size_t hist_off = std::max<size_t>((coef_words_of(d) + 3) & ~(size_t)3, 4096);
+    const size_t VgT = (size_t)group_dims(d).num_views * (size_t)num_tiles(d);
+    return (hist_off + 2 * VgT) * 4 <= 65536;
+}
+
+hipError_t launch_preprocess_sh(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *radii, const FoldedScan &fs_in, bool seg_mode, hipStream_t s) {
     const GeomLayout L = geom_layout(d);
     {
         hipError_t e = launch_clear(geom + L.header, L.tile_start - L.header, s);   // header + tile_count + tile_cursor
@@ -759,16 +853,28 @@ hipError_t launch_preprocess_sh(const lsr_dims &d, const lsr_inputs &in, char *g
     // without a function attribute (degree-4 colour + 13 latent channels at degree 2 take 50 KB of coefficient rows:
     // with 8192 counters behind them the launch would ask for 82 KB); larger calls count with global atomics
     a.lds_hist = ((size_t)Vg * T <= 8192 && ((size_t)a.hist_off + (size_t)Vg * T) * 4 <= 65536) ? 1 : 0;
-    size_t shm = ((size_t)a.hist_off + (a.lds_hist ? (size_t)Vg * T : 0)) * 4;
+    // single-pass binning (the caller asks for it only when segment_capacity(d) > 0: byte tile coordinates, T <= 1024): the
+    // kernel then also emits the sort keys; its bucket array lives in the coefficient area, which therefore is at least 16 KB,
+    // and the histogram is followed by the array of first slots — up to 8 chunks of 64 Gaussians per workgroup (two per wave)
+    a.seg = SegOut{nullptr, 0u, index_packing(d).key_shift, 0u};
+    if (seg_mode) {
+        a.hist_off = std::max(a.hist_off, 4096);
+        if (L.seg_cap == 0 || !narrow_bins(d) || ((size_t)a.hist_off + 2 * (size_t)Vg * T) * 4 > 65536) return hipErrorInvalidValue;
+        a.lds_hist = 1;
+        a.seg.keys = (uint64_t *)(geom + L.seg_keys); a.seg.cap = L.seg_cap;
+    }
+    size_t shm = ((size_t)a.hist_off + (a.lds_hist ? (size_t)Vg * T * (seg_mode ? 2 : 1) : 0)) * 4;
     if (a.fs.enabled) shm = std::max<size_t>(shm, (size_t)kFoldTiles * 4);            // the scan stages the counts at the start of the allocation
     const dim3 grid((unsigned)((nchunks + a.chunks - 1) / a.chunks), groups), block(kShThreads);
     const bool fma = projection_contraction();
     prof_begin(kStPreprocess, s);
-#define LSR_PSH(DC, CO) do { if (fma) hipLaunchKernelGGL((k_preprocess_sh<DC, CO, true>), grid, block, shm, s, p, a); \
-                             else hipLaunchKernelGGL((k_preprocess_sh<DC, CO, false>), grid, block, shm, s, p, a); } while (0)
+#define LSR_PSH2(DC, CO, FM) do { if (seg_mode) hipLaunchKernelGGL((k_preprocess_sh<DC, CO, FM, true>), grid, block, shm, s, p, a); \
+                                  else hipLaunchKernelGGL((k_preprocess_sh<DC, CO, FM, false>), grid, block, shm, s, p, a); } while (0)
+#define LSR_PSH(DC, CO) do { if (fma) LSR_PSH2(DC, CO, true); else LSR_PSH2(DC, CO, false); } while (0)
     if (degc == 4) LSR_PSH(4, 3); else if (degc == 3) LSR_PSH(3, 3); else if (degc == 2) LSR_PSH(2, 3);
     else if (degc == 1) LSR_PSH(1, 3); else if (degc == 0) LSR_PSH(0, 3); else LSR_PSH(-1, 0);
 #undef LSR_PSH
+#undef LSR_PSH2
     prof_end(kStPreprocess, s);
     return hipGetLastError();
 }
