@@ -163,6 +163,9 @@ typedef struct lsr_layout {
      *           depth 0 = culled; span = footprint of alpha >= 1/255 in 4-pixel cells relative to the rectangle
      * bin_point_list: [P] canonical per-tile lists (depth order, ties by index): tile t of view v owns
      *           [tile_start[v*T+t], tile_start[v*T+t+1])
+     * (ABI v8: with key segments — lsr_geom_workspace_bytes includes them, behind everything listed here — bin_keys only
+     *           holds the keys of tiles whose lists outgrew their segment; a forward run with LSR_FWD_FOR_BACKWARD narrows the
+     *           sub-block bits of bin_half_list to the sub-blocks on which the entry blended a pixel)
      * bin_half_list: [2P] render lists (ABI v6): the tile with canonical list [s, s+n) owns [2s, 2s+2n); the list of
      *           its upper (h = 0: pixel rows 0-7) / lower (h = 1: rows 8-15) half starts at 2s + h*n and has
      *           geom_half_count[2*(v*T+t)+h] entries `index | sub-block bits << 24`: the canonical list restricted to
@@ -207,7 +210,11 @@ int lsr_pack_view(const float *viewmatrix, const float *projmatrix, const float 
                   float tanfovx, float tanfovy, const float *tanfovx_dev, const float *tanfovy_dev,
                   float *view_out, lsr_stream_t stream);
 
-/* ---- forward, phase 1: per-Gaussian preprocess + per-tile counting + tile offset scan.
+/* ---- forward, phase 1: per-Gaussian preprocess + per-tile counting + tile offset scan — and, since ABI v8, the BINNING:
+ * every (view, tile) owns a fixed-capacity key segment at the end of geom_ws, a workgroup of the preprocess kernel reserves
+ * its slots with the (returning) count atomics and writes the sort keys of its Gaussians itself (upstream's
+ * duplicateWithKeys, fused; no scatter kernel, no second pass over the binning records).  Dims for which that does not apply
+ * (tile grids beyond 255 a side or 1024 tiles per view; LSR_SEGMENTS=0) keep the two-phase binning in phase 2.
  * Writes radii.  Waits once for the device to return the pair count and the longest tile list through
  * the two host pointers (both required): the last workgroup of the preprocess kernel scans the tile counts
  * (ABI v7: no separate scan kernel for calls of up to 4096 (view, tile) pairs) and writes the two numbers plus the
@@ -221,8 +228,9 @@ int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, 
                         int64_t *num_pairs_host, int32_t *max_tile_pairs_host,
                         lsr_stream_t stream);
 
-/* ---- forward, phase 2: binning, per-tile depth sort, front-to-back compositing. Async.  Must follow
- * the lsr_forward_prepare of the same geom_ws on the same stream. */
+/* ---- forward, phase 2: per-tile depth sort, front-to-back compositing (and the binning of whatever phase 1 left: all of it
+ * for dims without key segments, else only the tiles whose lists outgrew their segment — `max_tile_pairs` tells). Async.  Must
+ * follow the lsr_forward_prepare of the same geom_ws on the same stream, with the two numbers it returned. */
 int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, void *bin_ws,
                        void *img_ws, int64_t num_pairs, int32_t max_tile_pairs,
                        const lsr_outputs *out, lsr_stream_t stream);
@@ -244,6 +252,8 @@ int lsr_forward_abandon(lsr_stream_t stream);
  *   - if the scene produces MORE pairs than `pair_capacity`, the last tile lists are truncated (no
  *     out-of-bounds access), the images are then wrong and the overflow word is set: check it with
  *     lsr_forward_status at the next convenient synchronisation point and re-run with more room;
+ *   - a tile list longer than its key segment is NOT an overflow: the fallback scatter for such tiles is always part of
+ *     this launch sequence (its workgroups leave at once when the device's longest list fits);
  *   - lsr_backward takes `num_pairs = pair_capacity` for such a forward.
  * No allocation, no host wait, no host-visible write: the launch sequence can be captured in a
  * hipGraph (torch.cuda.graph) and replayed. */
