@@ -630,7 +630,7 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
     if (d->feat_channels > 0 && !gin->features) return LSR_ENULL;
     if (num_pairs > 0 && !bin_ws) return LSR_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    // zero the packed gradient records the compositing backward accumulates into (those of visible slots only)
+    // zero the packed gradient records the compositing backward accumulates into
     LSR_HIP(launch_clear_grad(*d, radii, (char *)grad_ws, s));
     if (num_pairs > 0)
         LSR_STAGE("render_backward", s, launch_render_backward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs,

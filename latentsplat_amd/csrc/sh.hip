@@ -507,7 +507,10 @@ k_preprocess_sh(ShParams pk, PreShArgs a) {
     // ---- the tile scan in the last workgroup to arrive (as in k_preprocess; the counts pass through LDS) ----
     if (a.fs.enabled) {
         __shared__ uint32_t s_last;
-        __shared__ TileScanShared<kShThreads> s_scan;
+        // (the scan's 4 KB of counters live in the dynamic allocation behind the staged counts, not in static LDS: static
+        // bytes count against every workgroup of the launch, and 4.7 KB of them were the difference between three and four
+        // workgroups per CU at the configs[3] / [4] payload)
+        TileScanShared<kShThreads> &s_scan = *(TileScanShared<kShThreads> *)((char *)s_lds + (size_t)kFoldTiles * 4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -843,7 +846,8 @@ hipError_t launch_preprocess_sh(const lsr_dims &d, const lsr_inputs &in, char *g
     a.fs = fs_in;
     a.fs.tile_start = (uint32_t *)(geom + L.tile_start); a.fs.tile_order = (uint32_t *)(geom + L.tile_order);
     a.views_total = d.num_views;
-    // chunks per workgroup: one round of resident workgroups (three per CU) when the scene is large enough, at most 8
+    // chunks per workgroup: one round of resident workgroups (three per CU, the number round 4 sized this for; four fit since
+    // round 5) when the scene is large enough, at most 8
     const int64_t resident = (int64_t)device_cus() * 3 / groups;
     const int64_t nchunks = (d.num_gaussians + LSR_WAVE - 1) / LSR_WAVE;
     a.chunks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (nchunks + std::max<int64_t>(resident, 1) - 1) / std::max<int64_t>(resident, 1)));
@@ -864,7 +868,7 @@ hipError_t launch_preprocess_sh(const lsr_dims &d, const lsr_inputs &in, char *g
         a.seg.keys = (uint64_t *)(geom + L.seg_keys); a.seg.cap = L.seg_cap;
     }
     size_t shm = ((size_t)a.hist_off + (a.lds_hist ? (size_t)Vg * T * (seg_mode ? 2 : 1) : 0)) * 4;
-    if (a.fs.enabled) shm = std::max<size_t>(shm, (size_t)kFoldTiles * 4);            // the scan stages the counts at the start of the allocation
+    if (a.fs.enabled) shm = std::max<size_t>(shm, (size_t)kFoldTiles * 4 + sizeof(TileScanShared<kShThreads>));   // the scan stages the counts at the start of the allocation, its counters behind them
     const dim3 grid((unsigned)((nchunks + a.chunks - 1) / a.chunks), groups), block(kShThreads);
     const bool fma = projection_contraction();
     prof_begin(kStPreprocess, s);

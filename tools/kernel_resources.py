@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "latentsplat_amd", "csrc")
-FLAGS = {"preprocess": ["-ffp-contract=off", "-fno-slp-vectorize"], "sh": ["-ffp-contract=off"],
+FLAGS = {"preprocess": ["-ffp-contract=off", "-fno-slp-vectorize"], "sh": ["-ffp-contract=off", "-fno-slp-vectorize"],
          "preprocess_backward": ["-fno-slp-vectorize"], "render_forward": ["-fno-slp-vectorize"], "render_backward": ["-fno-slp-vectorize"]}
 
 
