@@ -8,13 +8,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "latentsplat_amd", "csrc")
-FLAGS = {"preprocess": ["-ffp-contract=off", "-fno-slp-vectorize"], "sh": ["-ffp-contract=off", "-fno-slp-vectorize"],
-         "preprocess_backward": ["-fno-slp-vectorize"], "render_forward": ["-fno-slp-vectorize"], "render_backward": ["-fno-slp-vectorize"]}
+FLAGS = {"preprocess": ["-ffp-contract=off"], "sh": ["-ffp-contract=off"]}   # per-unit flags of csrc/Makefile (COMMON is spelled out below)
 
 
 def main():
     unit = sys.argv[1]
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I../../include", "-I.", "-fno-fast-math",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I../../include", "-I.", "-fno-fast-math", "-fno-slp-vectorize",
            "-Rpass-analysis=kernel-resource-usage", "-c", unit + ".hip", "-o", "/dev/null"] + FLAGS.get(unit, []) + sys.argv[2:]
     err = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True).stderr
     rows, cur = [], None
