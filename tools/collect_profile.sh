@@ -18,7 +18,11 @@ python tools/pmc_summary.py gpurun_out/pmc_$TAG --traffic-json $OUT/traffic_rend
 # DESIGN.md (LDS bank conflicts, VALU busy) can be recomputed from a file under profiles/
 bash tools/pmc_profile.sh ${TAG}_headline --steps 3 --warmup 1 --clock-warmup 0 --no-cpu-baseline --no-latency --no-bwd > /dev/null 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_${TAG}_headline > $OUT/pmc_headline.md
+# the reference-shaped training step alone (configs[4]'s per-GPU batch: 4 scenes x 4 views, colour SH 4 + latent SH 2): the SH
+# kernels' rates (VALU busy, HBM bytes) quoted in DESIGN.md come from this file
+PMC_CMD="python tools/bench_decoder.py --scenes 4 --views 4 --steps 3" bash tools/pmc_profile.sh ${TAG}_cfg4 > /dev/null 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_${TAG}_cfg4 > $OUT/pmc_cfg4.md
 # gpurun merges at most 64 MiB back: keep the summaries, drop the raw databases / traces they were made from
-rm -rf $OUT/stats gpurun_out/pmc_$TAG gpurun_out/pmc_${TAG}_headline
+rm -rf $OUT/stats gpurun_out/pmc_$TAG gpurun_out/pmc_${TAG}_headline gpurun_out/pmc_${TAG}_cfg4
 du -sh gpurun_out | tail -1
 cat $OUT/bench.json
