@@ -690,13 +690,43 @@ k_sh_bwd(ShParams pk) {
             // `s_waitcnt vmcnt(0)` in front of every store, and on gfx9 that also waits for the PREVIOUS
             // store — 28 serial store round trips per thread.  Views beyond nv and culled Gaussians have
             // zero rows in both LDS arrays, so all four view terms are added unconditionally.
+            // Thread <-> ONE coefficient (k, c) of every per-th Gaussian (per = 256 / ks Gaussians per sweep; lane-consecutive
+            // addresses as in a flat t += 256 loop): the element's index arithmetic — two divisions by runtime constants, the
+            // band select, two LDS addresses: 24 vector instructions per element, seven of them quarter-rate v_mul_lo_u32,
+            // around four multiply-adds in the flat loop's ISA — is paid once per thread.  The thread index goes through an
+            // empty asm so that the compiler cannot hoist that arithmetic out of the view-chunk loop, where its results stay
+            // live across pass 1 (48 more bytes of scratch per lane: measured 7 % slower than the flat loop; as written 1.5 %
+            // faster — this kernel is bound by its chain of barrier-separated phases, not by its instruction count:
+            // profiles/r05_ab_knobs.md section 10).  ks > 256 (more than 28 latent channels at degree 2) keeps the flat loop.
             auto colour_pass = [&](auto RMW) {
+                if (ks <= kShThreads) {
+                    int t0 = tid;
+                    asm volatile("" : "+v"(t0));
+                    const int per = udiv_small(kShThreads, p.mdiv[0]);
+                    if (t0 >= per * ks) return;
+                    const int gq = udiv_small(t0, p.mdiv[0]), rem = t0 - gq * ks;
+                    int k, c;
+                    if (cmaj) { c = udiv_small(rem, p.mdivK); k = rem - c * K; }
+                    else { k = (rem * 0xAAABu) >> 17; c = rem - 3 * k; }
+                    const int kb = k < nbC ? k : 25;   // coefficients beyond the evaluated bands: zero slot
+                    const float *pb = s_basC + gq * kShBasisC + kb, *pg = s_gch + gq * cs + c;
+                    float *o = dst + t0;
+                    const int db = per * kShBasisC, dg = per * cs, dd = per * ks;
+                    for (int g = gq; g < rows; g += per) {
+                        float a = decltype(RMW)::value ? *o : 0.0f;
+#pragma unroll
+                        for (int vi = 0; vi < kShWaves; ++vi) a = __builtin_fmaf(pb[vi * LSR_WAVE * kShBasisC], pg[vi * LSR_WAVE * cs], a);
+                        *o = a;
+                        pb += db; pg += dg; o += dd;
+                    }
+                    return;
+                }
                 for (int t = tid; t < rows * ks; t += kShThreads) {
                     const int g = udiv_small(t, p.mdiv[0]), rem = t - g * ks;
                     int k, c;
                     if (cmaj) { c = udiv_small(rem, p.mdivK); k = rem - c * K; }
                     else { k = (rem * 0xAAABu) >> 17; c = rem - 3 * k; }
-                    const int kb = k < nbC ? k : 25;   // coefficients beyond the evaluated bands: zero slot
+                    const int kb = k < nbC ? k : 25;
                     float a = decltype(RMW)::value ? dst[t] : 0.0f;
                     const float *pb = s_basC + g * kShBasisC + kb, *pg = s_gch + g * cs + c;
 #pragma unroll
@@ -722,6 +752,26 @@ k_sh_bwd(ShParams pk) {
             const int ks = p.ks[1];
             float *dst = p.g.features + (d.vs_feat != 0 ? (size_t)v0 * d.vs_feat : 0) + (size_t)g0 * ks;
             auto feature_pass = [&](auto RMW) {
+                if (ks <= kShThreads) {   // one coefficient (c, k) of every per-th Gaussian per thread (see the colour pass)
+                    int t0 = tid;
+                    asm volatile("" : "+v"(t0));
+                    const int per = udiv_small(kShThreads, p.mdiv[1]);
+                    if (t0 >= per * ks) return;
+                    const int gq = udiv_small(t0, p.mdiv[1]), rem = t0 - gq * ks;
+                    const int c = udiv_small(rem, p.mdivKf), k = rem - c * Kf;
+                    const int kb = k < nbF ? k : 9;
+                    const float *pb = s_basF + gq * kShBasisF + kb, *pg = s_gch + gq * cs + COFF + c;
+                    float *o = dst + t0;
+                    const int db = per * kShBasisF, dg = per * cs, dd = per * ks;
+                    for (int g = gq; g < rows; g += per) {
+                        float a = decltype(RMW)::value ? *o : 0.0f;
+#pragma unroll
+                        for (int vi = 0; vi < kShWaves; ++vi) a = __builtin_fmaf(pb[vi * LSR_WAVE * kShBasisF], pg[vi * LSR_WAVE * cs], a);
+                        *o = a;
+                        pb += db; pg += dg; o += dd;
+                    }
+                    return;
+                }
                 for (int t = tid; t < rows * ks; t += kShThreads) {
                     const int g = udiv_small(t, p.mdiv[1]), rem = t - g * ks;
                     const int c = udiv_small(rem, p.mdivKf), k = rem - c * Kf;
