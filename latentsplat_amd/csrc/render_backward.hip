@@ -50,6 +50,7 @@ struct RenderBwdParams {
     const uint32_t *items;        // work items of the forward (view*T + tile | half << 28), costliest first
     const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t *queue;              // work-queue head (zeroed with the gradient workspace)
+    int prio_pct;                 // issue priority by progress: percentage of the launch's mean tile list (0 = off; see the kernel)
     const float *views;
     const float4 *geo;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
     int rec_f4;
@@ -171,6 +172,19 @@ k_render_bwd(RenderBwdParams p) {
     const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);   // 0 .. WPB*WGS-1
     const uint32_t bin = (blockIdx.x % (uint32_t)p.num_cus) * 4u + (vwave & 3u);
     const uint32_t j0 = vwave >> 2;
+    // Issue priority by progress (round 5).  A wave walks its list at HIGH priority (s_setprio 3) until prio_target entries are
+    // left of it — prio_pct % of the launch's mean tile list (pair count / tiles) — and finishes at priority 0.  Waves close
+    // to the end of their item yield the issue slots of their SIMD to the ones that still have far to go, so the four waves
+    // of a SIMD finish their items closer together and the launch's drain — SIMDs down to one or two waves, which cannot fill
+    // the issue slots — gets shorter.  Measured (profiles/r05_ab_knobs.md section 12; 18 % is the flat optimum between 15 and
+    // 20): 16 views x 300 k 0.60 -> 0.574 ms, 8 / 32 views -6 %, 10^6 Gaussians -7 %, the list-splitting instance -8 % (6 views)
+    // and -13 % (configs[3]); the 8-channel unsplit instance (configs[4]) LOSES 1.5-10 % at every setting and lists shorter than
+    // a few batches (100 k Gaussians: +4 %) cannot resolve the switch point, so the launcher leaves those at 0 and targets
+    // below three batches switch it off here.  (A static priority by item cost did nothing: section 6; the
+    // inverse order — the end of an item at high priority — costs 0-10 %; only the order matters: 3 -> 1 and 1 -> 0 measure the same
+    // as 3 -> 0.  The forward, six waves per SIMD, does not gain.)  Results do not depend on it.
+    uint32_t prio_target = p.prio_pct ? (uint32_t)(((uint64_t)p.header[kHdrPairs] * (uint32_t)p.prio_pct) / (50ull * (uint64_t)max(p.header[kHdrNumItems], 1u))) : 0u;
+    if (prio_target < 3u * LSR_WAVE) prio_target = 0u;
     bool first = true;
     for (;;) {
         uint32_t qi;
@@ -300,8 +314,11 @@ k_render_bwd(RenderBwdParams p) {
             w_ahead = load_ent(LSR_WAVE + lane);
         }
 
+        uint32_t burn_end = 0u;
+        if (prio_target && walk_end > prio_target) { burn_end = walk_end - prio_target; __builtin_amdgcn_s_setprio(3); }
         for (uint32_t cbase = 0; cbase < walk_end; cbase += LSR_WAVE) {
             const bool emit = !SPLIT || cbase >= emit_from;   // wave-uniform
+            if (burn_end && cbase >= burn_end) { __builtin_amdgcn_s_setprio(0); burn_end = 0u; }
             const StageRec cur = nxt;
             nxt = load_rec(w_ahead);
             w_ahead = load_ent(cbase + 2 * LSR_WAVE + lane);
@@ -463,6 +480,7 @@ k_render_bwd(RenderBwdParams p) {
             }
             wave_lds_fence_bwd();
         }
+        if (burn_end) __builtin_amdgcn_s_setprio(0);
     }  // item loop
 }
 
@@ -490,6 +508,9 @@ static void launch_variant(RenderBwdParams p, uint64_t items, hipStream_t s) {
     if (forced >= 0) pl = forced > 3 ? 3 : forced;
     else while (pl < 3 && (items << (pl + 1)) <= slots) ++pl;
     p.parts_log2 = pl;
+    // issue priority by progress (see the kernel): on for the instances it was measured to help, LSR_BWD_PRIO_PCT >= 0 forces a value
+    const int prio_knob = env_int("LSR_BWD_PRIO_PCT", -1);
+    p.prio_pct = prio_knob >= 0 ? prio_knob : ((!DG && (NCHP == 4 || (NCHP == 8 && pl > 0))) ? 18 : 0);
     if (pl) hipLaunchKernelGGL((k_render_bwd<NCHP, DG, WPB, WGS, true>), dim3(p.num_cus * WGS), dim3(LSR_WAVE * WPB), 0, s, p);
     else hipLaunchKernelGGL((k_render_bwd<NCHP, DG, WPB, WGS, false>), dim3(p.num_cus * WGS), dim3(LSR_WAVE * WPB), 0, s, p);
 }
