@@ -79,6 +79,8 @@ struct RenderFwdParams {
     uint32_t num_items;           // items of this launch (2 per (view, tile))
     uint32_t quad_items;          // k_render_fwd_small: leading (costliest) items rendered as sub-block items
     uint32_t *queue;              // work-queue head (zeroed per forward)
+    const uint32_t *header;       // geometry-workspace header (pair count: the launch's mean list length)
+    int prio_pct;                 // issue priority by progress as in k_render_bwd (percentage of the mean tile list; 0 = off)
     unsigned long long *trace;    // debug builds (LSR_ENABLE_TRACE): per item {start clk, end clk, hw id, iterations << 32 | entries}
     const float *views;
     const float4 *rec;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
@@ -157,6 +159,9 @@ k_render_fwd(RenderFwdParams p) {
 
     const uint32_t simd_bins = (uint32_t)p.num_cus * 4u, slots = (uint32_t)p.num_cus * (uint32_t)p.waves_per_cu;
     const uint32_t vwave = (uint32_t)wid + (uint32_t)WPB * (blockIdx.x / (uint32_t)p.num_cus);   // 0 .. waves_per_cu - 1
+    // issue priority by progress (k_render_bwd's comment): high until prio_target entries are left of the wave's list, then low
+    uint32_t prio_target = p.prio_pct ? (uint32_t)(((uint64_t)p.header[kHdrPairs] * (uint32_t)p.prio_pct) / (50ull * (uint64_t)max(num_items, 1u))) : 0u;
+    if (prio_target < 3u * LSR_WAVE) prio_target = 0u;
     const uint32_t bin = (blockIdx.x % (uint32_t)p.num_cus) * 4u + (vwave & 3u);
     // First item of every wave: static, folded (boustrophedon) over the cost-sorted list, so the
     // waves of a SIMD start with a balanced total.  Everything beyond the first `slots` items
@@ -239,6 +244,8 @@ k_render_fwd(RenderFwdParams p) {
             w_ahead = load_ent(LSR_WAVE + lane);
         }
 
+        uint32_t burn_end = 0u;
+        if (prio_target && hn > prio_target) { burn_end = hn - prio_target; __builtin_amdgcn_s_setprio(3); }
         for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
             if ((done0 & done1) == ~0ull) break;
 
@@ -379,7 +386,9 @@ k_render_fwd(RenderFwdParams p) {
                 }
                 wave_lds_fence();
             }
+            if (burn_end && base + LSR_WAVE >= burn_end) { __builtin_amdgcn_s_setprio(0); burn_end = 0u; }
         }
+        if (burn_end) __builtin_amdgcn_s_setprio(0);
 
         // background colour through the scalar cache (constant address space; the table was written by an
         // earlier launch) — as plain loads these were three waited-for vector loads per pixel row
@@ -869,6 +878,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.items = (const uint32_t *)(geom + L.tile_order);
     p.num_items = 2u * (uint32_t)d.num_views * (uint32_t)p.T;
     p.queue = (uint32_t *)(geom + L.header) + kHdrQueueFwd;
+    p.header = (const uint32_t *)(geom + L.header); p.prio_pct = 0;
     p.views = in.views;
     p.rec = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
     p.tile_start = (const uint32_t *)(geom + L.tile_start);
@@ -928,6 +938,14 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
         p.waves_per_cu = (WPC);                                                                            \
         hipLaunchKernelGGL((k_render_fwd<N, WPB, true>), dim3(p.num_cus * ((WPC) / (WPB))), dim3(LSR_WAVE * WPB), 0, s, p); \
     } while (0)
+    // Issue priority by progress (render_backward.hip has the mechanism and the measurements): of the forward instances only the
+    // list-narrowing 8-channel one — four waves per SIMD, like the backward — gains (configs[4]: 0.349 -> 0.320 ms at 18 %; the
+    // plain 8-channel instance 0.298 either way; the 4-channel instances, six waves per SIMD, -1 % ... +8 %: profiles/r05_ab_knobs.md
+    // section 12).  LSR_FWD_PRIO_PCT >= 0 forces a value for every instance.
+    {
+        const int prio_knob = env_int("LSR_FWD_PRIO_PCT", -1);
+        p.prio_pct = prio_knob >= 0 ? prio_knob : ((record && nchp == 8) ? 18 : 0);
+    }
     if (record && nchp == 4 && variant == 0) LSR_RFR(4, 12, 24);
     else if (record && nchp == 8) LSR_RFR(8, 16, 16);
     else
