@@ -148,7 +148,7 @@ def test_launch_structure_knobs_do_not_change_results(hip_device):
     LSR_HOST_POLL), the order in which the per-tile sort visits the tiles (LSR_SORT_LPT) and whether the forward
     compositing kernel renders a half tile with one wave (two pixels per lane) or with two waves (one row of sub-blocks
     each, one pixel per lane: LSR_FWD_ROWS, chosen by the item count otherwise) and between how many waves the backward splits
-    a half-tile list (LSR_BWD_PARTS) only change WHEN and WHERE kernels run: images, the per-pixel workspaces the backward reads and the gradients must be bitwise identical (knobs
+    a half-tile list (LSR_BWD_PARTS), and the issue priorities the compositing waves give themselves (LSR_BWD_PRIO_PCT / LSR_FWD_PRIO_PCT) only change WHEN and WHERE kernels run: images, the per-pixel workspaces the backward reads and the gradients must be bitwise identical (knobs
     are read once per process, hence subprocesses), in the synchronous and the no-sync forward, under back-to-back
     calls and inside a captured hipGraph."""
     import os
@@ -204,7 +204,12 @@ print("HASH", h.hexdigest())
                 "fwd_row_items": dict(LSR_FWD_ROWS="1"), "fwd_half_tile_items": dict(LSR_FWD_ROWS="0"),
                 # the backward of this small shape splits every half-tile list between four waves (each walks the entries in
                 # front of its share for the per-pixel state only): the same gradient records as one wave per list
-                "bwd_unsplit_lists": dict(LSR_BWD_PARTS="0"), "bwd_eight_parts": dict(LSR_BWD_PARTS="3")}
+                "bwd_unsplit_lists": dict(LSR_BWD_PARTS="0"), "bwd_eight_parts": dict(LSR_BWD_PARTS="3"),
+                # round 5: the compositing waves change their issue priority with their progress through an item (on for some
+                # instances by default): forced off, and forced on for every instance of the backward and of the half-tile forward
+                "no_progress_priority": dict(LSR_BWD_PRIO_PCT="0", LSR_FWD_PRIO_PCT="0"),
+                "progress_priority_everywhere": dict(LSR_BWD_PRIO_PCT="40", LSR_FWD_PRIO_PCT="30", LSR_FWD_ROWS="0"),
+                "progress_priority_unsplit_bwd": dict(LSR_BWD_PRIO_PCT="25", LSR_BWD_PARTS="0")}
     for name, extra in variants.items():
         # (LSR_FWD_RECORD=0 throughout: the half-tile forward kernel narrows the render lists to the sub-blocks an entry
         # contributed to when a backward follows, the row / sub-block kernels do not — the backward's float sums then
