@@ -51,6 +51,29 @@ def test_workspace_sizes():
     assert lib.lsr_grad_workspace_bytes(C.byref(d)) >= 2 * 1000 * (8 + 16 + 4)
 
 
+def test_key_segments_in_the_geometry_workspace():
+    """Round 5 (ABI v8): calls that qualify for single-pass binning (byte tile coordinates, <= 1024 tiles) carry one
+    fixed-capacity key segment per (view, tile) at the end of the geometry workspace — 8 bytes x min(8192, G rounded up to
+    64) keys each — and the size is a pure function of the dims (what `query size, then run` relies on)."""
+    lib = _lib.load()
+    small, big = _dims(num_gaussians=1000), _dims(num_gaussians=100_000)
+    tiles = 2 * 4 * 4                                     # 2 views of 64 x 64
+    g_small, g_big = lib.lsr_geom_workspace_bytes(C.byref(small)), lib.lsr_geom_workspace_bytes(C.byref(big))
+    assert g_small == lib.lsr_geom_workspace_bytes(C.byref(small))
+    assert g_small >= tiles * 1024 * 8                    # capacity = 1000 rounded up to 64 = 1024 keys
+    assert g_big >= tiles * 8192 * 8                      # ... capped at the second sort tier
+    # images beyond 1024 tiles (here 2048 x 2048 = 16 384) fall back to the two-phase binning: no segments
+    huge = _dims(num_gaussians=1000, height=2048, width=2048)
+    per_tile = (lib.lsr_geom_workspace_bytes(C.byref(huge)) - g_small) / (2 * (128 * 128 - 16))
+    assert per_tile < 1024 * 8 / 4                        # far less than a segment per tile
+
+
+def test_speculative_sort_tier_hint():
+    """The sort-tier boundary the speculative forward asks for: the first power-of-two tier at or above 1.1 x the longest list."""
+    from latentsplat_amd.rasterizer import _tier_hint
+    assert [_tier_hint(x) for x in (0, 900, 931, 3289, 3724, 7000, 7500, 20000)] == [1024, 1024, 2048, 4096, 8192, 8192, 16384, 32768]
+
+
 @pytest.mark.parametrize("bad", [
     dict(num_views=0), dict(height=0), dict(feat_channels=33), dict(feat_channels=0, color_mode=0),
     dict(color_mode=1, sh_degree=5, sh_coeffs=36), dict(color_mode=1, sh_degree=2, sh_coeffs=4),
