@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LSR_ABI_VERSION 8
+#define LSR_ABI_VERSION 9
 #define LSR_TILE 16            /* tile edge in pixels (16x16 = the published algorithm's tile) */
 #define LSR_MAX_FEAT_CHANNELS 32
 #define LSR_MAX_SH_DEGREE 4
@@ -178,6 +178,12 @@ typedef struct lsr_layout {
     size_t img_final_T, img_n_contrib;
     size_t geom_bin_stride;
     size_t bin_half_list, geom_half_count;
+    /* (ABI v9) geom_item_flags: [2*V*T] u32, one word per half-tile work item (2*(v*T+t)+h), cleared by every forward;
+     *           bit 0 = the forward compositing kernel staged an entry of opacity >= 0.75 for the item: lsr_backward walks
+     *           such items back to front (the published recurrence) instead of front to back.  Header word 6
+     *           (geom_header + 24) is 1 when the forward's kernel filled the flags in (forwards run with
+     *           LSR_FWD_FOR_BACKWARD and all small-batch forwards), else lsr_backward walks every item back to front. */
+    size_t geom_item_flags;
 } lsr_layout;
 
 int lsr_abi_version(void);

@@ -62,7 +62,7 @@ class Layout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
                 ("geom_rec", "geom_rec_floats", "geom_bin", "geom_tile_count", "geom_tile_start",
                  "geom_header", "bin_keys", "bin_point_list", "img_final_T", "img_n_contrib", "geom_bin_stride",
-                 "bin_half_list", "geom_half_count")]
+                 "bin_half_list", "geom_half_count", "geom_item_flags")]
 
 
 class AdapterDims(C.Structure):      # lsr_adapter_dims (include/lsr_adapter.h, include/lsr_latent.h, include/lsr_ply.h)
@@ -127,6 +127,7 @@ EXPORTS = (
 )
 
 _lib = None
+ABI_VERSION = 9     # include/lsr_rasterizer.h LSR_ABI_VERSION
 
 
 def build(force: bool = False) -> str:
@@ -158,6 +159,12 @@ def load():
         raise LsrError(f"cannot load {_SO}: {e}") from e
     P, I32, I64, SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
     lib.lsr_abi_version.restype = C.c_int
+    # checked before any other prototype is bound: the structs below are this version's (an older or newer build would
+    # be handed structs of the wrong size; there is no compatibility mode)
+    abi = lib.lsr_abi_version()
+    if abi != ABI_VERSION:
+        raise LsrError(f"{_SO}: ABI version {abi}, this package needs {ABI_VERSION}; rebuild it "
+                       "(`python -c 'import __graft_entry__ as g; g.build()'`)")
     lib.lsr_error_string.restype = C.c_char_p
     lib.lsr_error_string.argtypes = [C.c_int]
     lib.lsr_last_hip_error.restype = C.c_int
@@ -216,14 +223,6 @@ def load():
     lib.lsr_ply_pack.argtypes = [I64, I32, C.POINTER(PlyInputs), P, P]
     lib.lsr_ply_write_host.restype = C.c_int
     lib.lsr_ply_write_host.argtypes = [C.c_char_p, P, I64]
-    abi = lib.lsr_abi_version()
-    if abi != 8:
-        # an older build selected with LSR_LIB for a kernel A/B is only accepted on explicit request
-        if not (os.environ.get("LSR_LIB") and os.environ.get("LSR_ALLOW_OLD_ABI") == "1"):
-            raise LsrError(f"{_SO}: ABI version {abi}, this package needs 8; rebuild it (LSR_ALLOW_OLD_ABI=1 with LSR_LIB "
-                           "accepts an older experiment build at your own risk)")
-        import warnings
-        warnings.warn(f"{_SO}: ABI version {abi} != 8 accepted because LSR_ALLOW_OLD_ABI=1")
     _lib = lib
     return lib
 

@@ -328,6 +328,7 @@ int lsr_get_layout(const lsr_dims *d, int64_t num_pairs, lsr_layout *out) {
     out->bin_half_list = B.half_list; out->geom_half_count = L.half_count;
     out->img_final_T = I.final_T; out->img_n_contrib = I.n_contrib;
     out->geom_bin_stride = bin_stride(*d);
+    out->geom_item_flags = L.item_flags;
     return LSR_OK;
 }
 

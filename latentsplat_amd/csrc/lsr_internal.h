@@ -23,7 +23,7 @@ namespace lsr {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t header, rec, bin, tile_count, tile_start, tile_cursor, tile_order, half_count, sh_clamp, seg_keys, total;
+    size_t header, rec, bin, tile_count, tile_start, tile_cursor, item_flags, tile_order, half_count, sh_clamp, seg_keys, total;
     int rec_floats;
     uint32_t seg_cap;      // keys per (view, tile) segment of the single-pass binning; 0 = two-phase binning (k_scatter)
 };
@@ -130,6 +130,10 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     L.header = o; o += 256;                        // header .. tile_cursor are cleared by ONE memset per forward
     L.tile_count = o; o = align_up(o + VT * 4);
     L.tile_cursor = o; o = align_up(o + VT * 4);   // adjacent to tile_count: one memset clears both
+    // one word per half-tile work item, inside the cleared range: kItemFlagSteep = the forward compositing kernel staged an
+    // entry of opacity >= kSteepOpacity for this item, i.e. a pixel may have blended an alpha close to the 0.99 clamp; the
+    // compositing backward then walks the item's list BACK TO FRONT (render_backward.hip)
+    L.item_flags = o; o = align_up(o + 2 * VT * 4);
     L.tile_start = o; o = align_up(o + (VT + 1) * 4);
     L.tile_order = o; o = align_up(o + 2 * VT * 4);   // work items (see kItem*), costliest first
     L.half_count = o; o = align_up(o + 2 * VT * 4);   // entries of the two half-tile render lists of every (view, tile)
@@ -194,6 +198,10 @@ inline GradLayout grad_layout(const lsr_dims &d) {
 // Input slice a view reads: its own (per-view strides), its group's, or the shared one (stride 0).
 __host__ __device__ inline int input_slice(const lsr_dims &d, int v) { return d.views_per_group > 1 ? v / d.views_per_group : v; }
 
+constexpr uint32_t kItemFlagSteep = 1u;
+// opacity from which an entry marks its item: 1 / (1 - alpha) — the factor by which the forward-order backward amplifies
+// the rounding of the pixel's total — can reach 4 from here on (100 at the clamp)
+constexpr float kSteepOpacity = 0.75f;
 constexpr uint32_t kItemTileMask = 0x0FFFFFFFu;
 constexpr int kItemHalfShift = 28;
 constexpr uint32_t kListIndexMask = 0x00FFFFFFu;   // half_list entry = Gaussian index | sub-block bits << 24
@@ -219,7 +227,8 @@ inline int wave_slots(int cus) { return cus * 4 * 4; }   // (at 4 resident compo
 // Environment knobs are development aids; each is read ONCE per process (never on the launch path).
 int env_int(const char *name, int fallback);        // api.hip: latched on first use
 // header words of the geometry workspace (kHdrQueueFwd: work-queue head of the forward compositing kernel)
-enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrNumItems = 3, kHdrOverflow = 4, kHdrPreDone = 5, kHdrQueueFwd = 8,
+enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrNumItems = 3, kHdrOverflow = 4, kHdrPreDone = 5,
+       kHdrFlagsValid = 6 /* the forward compositing kernel of this call filled in GeomLayout::item_flags */, kHdrQueueFwd = 8,
        kHdrLongTiles = 16 /* + 0, + 1: number of tiles beyond the first sort tier / beyond the second */ };
 
 // ---- optional per-stage hipEvent timing (api.hip); no-ops unless lsr_profile_enable(1) ----

@@ -30,6 +30,8 @@
 // entry of a half list (0.94 per (Gaussian, tile) pair).
 // Launches that cannot fill the wave slots (a few views) split every list between 2 / 4 / 8 waves (SPLIT instance).
 // Spec: SURVEY.md Appendix A.6.
+#include <type_traits>
+
 #include "lsr_blend.h"
 
 namespace lsr {
@@ -51,6 +53,8 @@ struct RenderBwdParams {
     const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t *queue;              // work-queue head (zeroed with the gradient workspace)
     int prio_pct;                 // issue priority by progress: percentage of the launch's mean tile list (0 = off; see the kernel)
+    const uint32_t *item_flags;   // [2 V T] kItemFlagSteep per half-tile item, written by the forward compositing kernel (lsr_internal.h)
+    int rev_mode;                 // which items are walked BACK TO FRONT: 0 none, 1 all, 2 the steep ones (and all when the forward left no flags)
     const float *views;
     const float4 *geo;            // [V*G][rec_f4] screen-space records (lsr_internal.h)
     int rec_f4;
@@ -185,6 +189,7 @@ k_render_bwd(RenderBwdParams p) {
     // as 3 -> 0.  The forward, six waves per SIMD, does not gain.)  Results do not depend on it.
     uint32_t prio_target = p.prio_pct ? (uint32_t)(((uint64_t)p.header[kHdrPairs] * (uint32_t)p.prio_pct) / (50ull * (uint64_t)max(p.header[kHdrNumItems], 1u))) : 0u;
     if (prio_target < 3u * LSR_WAVE) prio_target = 0u;
+    const bool flags_valid = p.rev_mode == 2 && p.header[kHdrFlagsValid] != 0u;
     bool first = true;
     for (;;) {
         uint32_t qi;
@@ -208,8 +213,13 @@ k_render_bwd(RenderBwdParams p) {
         const size_t vG = (size_t)v * p.G;
         const uint32_t tstart = p.tile_start[vt], tn = p.tile_start[vt + 1] - tstart;
         const uint32_t *hlist = p.half_list + 2 * (size_t)tstart + (size_t)half * tn;
+        // back to front for items in which an alpha can come close to the clamp (the header comment says why)
+        const bool rev = p.rev_mode == 1 || (p.rev_mode == 2 && (!flags_valid || (p.item_flags[2 * (size_t)vt + half] & kItemFlagSteep)));
 
-        // per-pixel state of the lane's two pixels as register pairs (pixel 0, pixel 1)
+        auto walk_item = [&](auto rev_tag) __attribute__((always_inline)) {
+        constexpr bool REV = decltype(rev_tag)::value;
+        // per-pixel state of the lane's two pixels as register pairs (pixel 0, pixel 1); R2: forward order — what is left behind
+        // the current entry (R_i); reverse order — S_i / 255, the unattenuated composite of everything behind it
         float2_b pxx, T2, R2, ddep2;
         float pyf;
         float2_b dpix[NCHP];          // dL/d output channel c at the two pixels
@@ -235,7 +245,7 @@ k_render_bwd(RenderBwdParams p) {
                 for (int c = 0; c < 3; ++c) {
                     const size_t o = ((size_t)v * 3 + c) * HW;
                     gl[c] = float2_b{p.g_color[o + pix0], p.g_color[o + pix1]};
-                    fl[c] = float2_b{p.f_color[o + pix0], p.f_color[o + pix1]};
+                    if (!REV) fl[c] = float2_b{p.f_color[o + pix0], p.f_color[o + pix1]};
                 }
             }
             if (p.g_feat) {
@@ -244,12 +254,12 @@ k_render_bwd(RenderBwdParams p) {
                     if (c >= coff && c - coff < p.C) {   // uniform
                         const size_t o = ((size_t)v * p.C + (c - coff)) * HW;
                         gl[c] = float2_b{p.g_feat[o + pix0], p.g_feat[o + pix1]};
-                        fl[c] = float2_b{p.f_feat[o + pix0], p.f_feat[o + pix1]};
+                        if (!REV) fl[c] = float2_b{p.f_feat[o + pix0], p.f_feat[o + pix1]};
                     }
             }
             const float2_b gmask = p.g_mask ? float2_b{p.g_mask[vp0], p.g_mask[vp1]} : float2_b{0.0f, 0.0f};
             const float2_b gdep = DEPTH_GRAD ? float2_b{p.g_depth[vp0], p.g_depth[vp1]} : float2_b{0.0f, 0.0f};
-            const float2_b fdep = DEPTH_GRAD ? float2_b{p.f_depth[vp0], p.f_depth[vp1]} : float2_b{0.0f, 0.0f};
+            const float2_b fdep = (DEPTH_GRAD && !REV) ? float2_b{p.f_depth[vp0], p.f_depth[vp1]} : float2_b{0.0f, 0.0f};
             const float2_b inm = float2_b{in0 ? 1.0f : 0.0f, in1 ? 1.0f : 0.0f};
             const float2_b Tfin = float2_b{in0 ? Tf0 : 1.0f, in1 ? Tf1 : 1.0f};
             T2 = float2_b{1.0f, 1.0f};
@@ -267,6 +277,19 @@ k_render_bwd(RenderBwdParams p) {
             if (DEPTH_GRAD) r0 = __builtin_elementwise_fma(fdep, gdep * inm, r0);
             ddep2 = DEPTH_GRAD ? gdep * inm * kInv255 : float2_b{0.0f, 0.0f};
             R2 = r0;
+            if (REV) {
+                // back to front: start behind the pixel's last entry with T = T_final and S / 255 = (g . bg - g_mask) / 255
+                // (the background reaches the colour channels only; features and depth have none)
+                T2 = Tfin;
+                float2_b s0 = -(gmask * inm) * kInv255;
+                if (p.has_color && p.g_color) {
+                    typedef const float __attribute__((address_space(4))) *kfloat_ptr;
+                    const kfloat_ptr vw = (kfloat_ptr)(p.views + (size_t)v * LSR_VIEW_FLOATS);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { const float bgc = vw[37 + c]; s0 = __builtin_elementwise_fma(dpix[c], float2_b{bgc, bgc}, s0); }
+                }
+                R2 = s0;
+            }
         }
         // wave-uniform upper bound of the list entries any pixel has to consider
 #pragma unroll
@@ -277,14 +300,22 @@ k_render_bwd(RenderBwdParams p) {
         // of the entries before it, so the wave first walks batches [0, b0) updating just T and R (a quarter of an emitting
         // step's instructions: no reciprocal, no moments, no cross-lane reduction, no table, no flush), with the operations of
         // the emitting walk — every entry's gradient is the unsplit kernel's bit for bit.
+        // (Back to front the roles swap: the part walks batches nb - 1 ... b0 and emits those below b1 — the state behind
+        // batch b1 - 1 is a function of the entries behind it.)
         uint32_t emit_from = 0, walk_end = maxlast;
+        const uint32_t nb = (maxlast + LSR_WAVE - 1) / LSR_WAVE;
+        uint32_t rev_stop = 0u, rev_emit_below = nb;     // REV: last batch walked, batches [rev_stop, rev_emit_below) emit
         if (SPLIT) {
-            const uint32_t nb = (maxlast + LSR_WAVE - 1) / LSR_WAVE;
             const uint32_t b0 = (part * nb) >> parts_log2, b1 = ((part + 1u) * nb) >> parts_log2;
-            if (b0 == b1) continue;          // a list shorter than the number of parts: this part has no batch
+            if (b0 == b1) return;          // a list shorter than the number of parts: this part has no batch
             emit_from = b0 * LSR_WAVE;
             walk_end = min(maxlast, b1 * LSR_WAVE);
+            rev_stop = b0; rev_emit_below = b1;
         }
+        // walk order: batch k of the walk starts at list position wbase(k)
+        const uint32_t nwalk = REV ? nb - rev_stop : (walk_end + LSR_WAVE - 1) / LSR_WAVE;
+        const uint32_t wfirst = REV ? (nb - 1u) * LSR_WAVE : 0u;
+        const uint32_t wstep = REV ? 0u - (uint32_t)LSR_WAVE : (uint32_t)LSR_WAVE;   // (batches below zero wrap and are clamped by load_ent)
 
         // software-pipelined staging as in the forward: records of batch b+1 and list entries of
         // batch b+2 are in flight while batch b is processed
@@ -309,19 +340,22 @@ k_render_bwd(RenderBwdParams p) {
 #pragma unroll
         for (int c4 = 0; c4 < NCHP / 4; ++c4) nxt.pay[c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (maxlast > 0) {   // wave-uniform
-            w_ahead = load_ent(lane);
+            w_ahead = load_ent(wfirst + lane);
             nxt = load_rec(w_ahead);
-            w_ahead = load_ent(LSR_WAVE + lane);
+            w_ahead = load_ent(wfirst + wstep + lane);
         }
 
+        // (the priority switch counts in walked entries: burn_end = entries walked at high priority)
         uint32_t burn_end = 0u;
-        if (prio_target && walk_end > prio_target) { burn_end = walk_end - prio_target; __builtin_amdgcn_s_setprio(3); }
-        for (uint32_t cbase = 0; cbase < walk_end; cbase += LSR_WAVE) {
-            const bool emit = !SPLIT || cbase >= emit_from;   // wave-uniform
-            if (burn_end && cbase >= burn_end) { __builtin_amdgcn_s_setprio(0); burn_end = 0u; }
+        const uint32_t wlen = REV ? nwalk * LSR_WAVE : walk_end;
+        if (prio_target && wlen > prio_target) { burn_end = wlen - prio_target; __builtin_amdgcn_s_setprio(3); }
+        uint32_t cbase = wfirst;
+        for (uint32_t wk = 0; wk < nwalk; ++wk, cbase += wstep) {
+            const bool emit = !SPLIT || (REV ? cbase < rev_emit_below * LSR_WAVE : cbase >= emit_from);   // wave-uniform
+            if (burn_end && wk * LSR_WAVE >= burn_end) { __builtin_amdgcn_s_setprio(0); burn_end = 0u; }
             const StageRec cur = nxt;
             nxt = load_rec(w_ahead);
-            w_ahead = load_ent(cbase + 2 * LSR_WAVE + lane);
+            w_ahead = load_ent(cbase + 2u * wstep + lane);
             // ---- stage up to 64 list entries (one per lane) ----
 #pragma unroll
             for (int b = 0; b < 8; ++b) s_list[b][lane] = (uint16_t)LSR_WAVE;   // every list slot starts as the null record's slot
@@ -347,9 +381,12 @@ k_render_bwd(RenderBwdParams p) {
             for (int b = 0; b < 8; ++b) {
                 at[b] = 0xFFFFu;           // 0xFFFF: not in this list
                 const uint64_t bal = __ballot((m >> b) & 1u);
-                nk = max(nk, (uint32_t)__builtin_popcountll(bal));
-                if (__builtin_amdgcn_inverse_ballot_w64(bal))
+                const uint32_t nb_b = (uint32_t)__builtin_popcountll(bal);
+                nk = max(nk, nb_b);
+                if (__builtin_amdgcn_inverse_ballot_w64(bal)) {
                     at[b] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    if (REV) at[b] = nb_b - 1u - at[b];     // the sub-block's list in reverse order
+                }
             }
             nk = __builtin_amdgcn_readfirstlane(nk);
 #pragma unroll
@@ -414,17 +451,35 @@ k_render_bwd(RenderBwdParams p) {
                 const float2_b av = float2_b{valid0 ? er0 : 0.0f, valid1 ? er1 : 0.0f};      // 255 opacity exp(power)
                 const float2_b om = float2_b{255.0f, 255.0f} - al;                           // 255 (1 - alpha)
                 const float2_b rcp1m = float2_b{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-                const float2_b Tk = T2;                          // transmittance in front of this entry
+                float2_b Tk = T2;                                // transmittance in front of this entry
+                if (REV) {
+                    // T_i = T_{i+1} / (1 - alpha_i): the hardware reciprocal (1 ulp) refined by one Newton step, so that the
+                    // quotient does not drift over a long list; entries the pixel skips leave T alone
+                    const float2_b e1 = __builtin_elementwise_fma(-om, rcp1m, float2_b{1.0f, 1.0f});
+                    const float2_b q = __builtin_elementwise_fma(e1, rcp1m, rcp1m) * 255.0f;
+                    const float2_b Tq = T2 * q;
+                    Tk = float2_b{valid0 ? Tq.x : T2.x, valid1 ? Tq.y : T2.y};
+                }
                 const float2_b w = al * Tk;                      // 255 alpha T
                 float2_b dsum = float2_b{pay[0], pay[0]} * dpix[0];   // (g . c_i) / 255 at the two pixels
 #pragma unroll
                 for (int c = 1; c < NCHP; ++c) dsum = __builtin_elementwise_fma(float2_b{pay[c], pay[c]}, dpix[c], dsum);
                 if (DEPTH_GRAD) dsum = __builtin_elementwise_fma(float2_b{b.z, b.z}, ddep2, dsum);
-                R2 = __builtin_elementwise_fma(-w, dsum, R2);    // what is left behind this entry
-                T2 = __builtin_elementwise_fma(w, float2_b{-kInv255, -kInv255}, Tk);
+                float2_b dL_dalpha;
+                if (REV) {
+                    // dL/dalpha / 255 = T_i ((g . c_i) - S_i) / 255;   S_{i-1} = S_i + alpha_i ((g . c_i) - S_i)
+                    // (the published recurrence, SURVEY A.6: nothing is ever formed as a difference of two totals)
+                    const float2_b diff = dsum - R2;
+                    dL_dalpha = Tk * diff;
+                    R2 = __builtin_elementwise_fma(al * kInv255, diff, R2);
+                    T2 = Tk;
+                } else {
+                    R2 = __builtin_elementwise_fma(-w, dsum, R2);    // what is left behind this entry
+                    T2 = __builtin_elementwise_fma(w, float2_b{-kInv255, -kInv255}, Tk);
+                    // dL/dalpha / 255 = T (g . c) / 255 - R / (255 (1 - alpha))
+                    dL_dalpha = __builtin_elementwise_fma(Tk, dsum, -(R2 * rcp1m));
+                }
                 if (!emit) continue;                             // another part's batch: only the state moves on
-                // dL/dalpha / 255 = T (g . c) / 255 - R / (255 (1 - alpha))
-                const float2_b dL_dalpha = __builtin_elementwise_fma(Tk, dsum, -(R2 * rcp1m));
                 const float2_b u = av * dL_dalpha;               // opacity exp(power) dL/dalpha: straight through the 0.99 clamp (A.6)
                 // moments of u over the lane's two pixels (same dy): sum u (dx, dy), u (dx^2, dx dy, dy^2), u
                 const float2_b ud = u * d2;
@@ -481,6 +536,9 @@ k_render_bwd(RenderBwdParams p) {
             wave_lds_fence_bwd();
         }
         if (burn_end) __builtin_amdgcn_s_setprio(0);
+        };   // walk_item
+        if (rev) walk_item(std::true_type{});
+        else walk_item(std::false_type{});
     }  // item loop
 }
 
@@ -541,6 +599,11 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     const bool det = deterministic_backward();
     p.rec_fixed = det ? (long long *)(grad + R.fixed) : nullptr;
     p.queue = (uint32_t *)(grad + R.fixed - 512);   // the zeroed slack behind the float records
+    p.item_flags = (const uint32_t *)(geom + L.item_flags);
+    {   // LSR_BWD_REV: 0 never walk back to front, 1 always, 2 (default) the items the forward flagged as steep
+        const int rm = env_int("LSR_BWD_REV", 2);
+        p.rev_mode = rm < 0 || rm > 2 ? 2 : rm;
+    }
     (void)gin;
     const int nch = (p.has_color ? 3 : 0) + d.feat_channels;
     const int nchp = nch <= 4 ? 4 : (nch <= 8 ? 8 : (nch <= 12 ? 12 : 36));

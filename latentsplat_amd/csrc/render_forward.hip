@@ -87,6 +87,8 @@ struct RenderFwdParams {
     int rec_f4;
     const uint32_t *tile_start, *half_count, *half_list;
     uint32_t *half_list_rw;       // RECORD instances: the same lists, written back with the sub-block bits refined (below)
+    uint32_t *item_flags;         // [2 V T] per half-tile item: kItemFlagSteep (lsr_internal.h), for the compositing backward; cleared per forward
+    uint32_t *header_rw;          // kHdrFlagsValid: set by the instances that fill in item_flags
     IndexPacking ip;              // how the list entries carry the Gaussian index and the sub-block bits
     float *out_color, *out_feat, *out_mask, *out_depth;
     float *final_T;
@@ -246,6 +248,9 @@ k_render_fwd(RenderFwdParams p) {
 
         uint32_t burn_end = 0u;
         if (prio_target && hn > prio_target) { burn_end = hn - prio_target; __builtin_amdgcn_s_setprio(3); }
+        // RECORD: lanes that staged an entry of opacity >= kSteepOpacity — a pixel of this item may have blended an alpha near
+        // the 0.99 clamp, and the backward then walks the item back to front (render_backward.hip); a scalar register pair
+        uint64_t steep = 0ull;
         for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
             if ((done0 & done1) == ~0ull) break;
 
@@ -258,6 +263,7 @@ k_render_fwd(RenderFwdParams p) {
             for (int b = 0; b < 8; ++b) s_list[b][lane] = null_off;
             const uint32_t e = base + lane;
             const uint32_t m = e < hn ? (((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) : 0u;   // sub-blocks of this half the entry can reach (never 0 for a list entry)
+            if (RECORD) steep |= __ballot(m != 0u && cur.b.y >= kSteepOpacity);
             if (m) {
                 const float4 a = cur.a, b = cur.b;
                 const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
@@ -389,6 +395,10 @@ k_render_fwd(RenderFwdParams p) {
             if (burn_end && base + LSR_WAVE >= burn_end) { __builtin_amdgcn_s_setprio(0); burn_end = 0u; }
         }
         if (burn_end) __builtin_amdgcn_s_setprio(0);
+        if (RECORD && lane == 0) {
+            if (steep) p.item_flags[2 * (size_t)vt + half] = kItemFlagSteep;
+            if (qi == 0u) p.header_rw[kHdrFlagsValid] = 1u;
+        }
 
         // background colour through the scalar cache (constant address space; the table was written by an
         // earlier launch) — as plain loads these were three waited-for vector loads per pixel row
@@ -487,6 +497,7 @@ __device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const 
     float kmax = kAlphaMax255;
     asm volatile("" : "+v"(kmax));
     uint64_t done = __ballot(!inside);
+    uint64_t steep = 0ull;    // lanes that staged an entry of opacity >= kSteepOpacity (see k_render_fwd)
 
     struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t w; };
     const uint32_t last = hn - 1u;
@@ -521,6 +532,7 @@ __device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const 
         const uint32_t e = base + lane;
         // the four sub-blocks of THIS row the entry can reach (bits 4 grow .. 4 grow + 3 of its half mask)
         const uint32_t m = e < hn ? (((((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) >> (4 * grow)) & 0xFu) : 0u;
+        steep |= __ballot(m != 0u && cur.b.y >= kSteepOpacity);
         if (m) {
             const float4 a = cur.a, b = cur.b;
             const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
@@ -582,6 +594,7 @@ __device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const 
         }
         wave_lds_fence();
     }
+    if (steep && lane == 0) p.item_flags[2 * (size_t)vt + half] = kItemFlagSteep;
     typedef const float __attribute__((address_space(4))) *kfloat_ptr;
     const kfloat_ptr vw = (kfloat_ptr)(p.views + (size_t)v * LSR_VIEW_FLOATS);
     if (inside) {
@@ -660,6 +673,7 @@ __device__ __forceinline__ void render_subblock_item(const RenderFwdParams &p, c
     float kmax = kAlphaMax255;
     asm volatile("" : "+v"(kmax));
     uint64_t done = __ballot(!inside);
+    uint64_t steep = 0ull;    // lanes that staged an entry of opacity >= kSteepOpacity (see k_render_fwd)
 
     struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t w; };
     const uint32_t last = hn - 1u;
@@ -693,6 +707,7 @@ __device__ __forceinline__ void render_subblock_item(const RenderFwdParams &p, c
         if (lane < 4) s_list[LSR_WAVE + lane] = null_off;       // the padding of the last group of four (row items use these words)
         const uint32_t e = base + lane;
         const bool m = e < hn && (((((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) >> sub) & 1u);
+        steep |= __ballot(m && cur.b.y >= kSteepOpacity);
         if (m) {
             const float4 a = cur.a, b = cur.b;
             const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
@@ -778,6 +793,7 @@ __device__ __forceinline__ void render_subblock_item(const RenderFwdParams &p, c
         }
         wave_lds_fence();
     }
+    if (steep && lane == 0) p.item_flags[2 * (size_t)vt + half] = kItemFlagSteep;
     // the rows' partial sums -> the pixel's sums (the same fixed order in every row)
     D = rows_sum(D);
 #pragma unroll
@@ -855,6 +871,7 @@ k_render_fwd_small(RenderFwdParams p) {
             if (qi >= num_items) break;
         }
         qi = __builtin_amdgcn_readfirstlane(qi);
+        if (qi == 0u && lane == 0) p.header_rw[kHdrFlagsValid] = 1u;
         if (qi < quad_end) {
             render_subblock_item<NCHP>(p, w, p.items[qi >> 3], (int)(qi & 7u));
         } else {
@@ -885,6 +902,8 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.half_count = (const uint32_t *)(geom + L.half_count);
     p.half_list = (const uint32_t *)(bin + B.half_list);
     p.half_list_rw = (uint32_t *)(const_cast<char *>(bin) + B.half_list);
+    p.item_flags = (uint32_t *)(const_cast<char *>(geom) + L.item_flags);
+    p.header_rw = (uint32_t *)(const_cast<char *>(geom) + L.header);
     p.ip = index_packing(d);
     p.out_color = out.color; p.out_feat = out.feature; p.out_mask = out.mask; p.out_depth = out.depth;
     p.final_T = (float *)(img + I.final_T); p.n_contrib = (uint32_t *)(img + I.n_contrib);

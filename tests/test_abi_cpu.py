@@ -27,7 +27,7 @@ def test_header_symbols_are_exported():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert set(names) == set(_lib.EXPORTS)
-    assert lib.lsr_abi_version() == 8
+    assert lib.lsr_abi_version() == 9
 
 
 def _dims(**kw):

@@ -214,11 +214,24 @@ print("HASH", h.hexdigest())
         # (LSR_FWD_RECORD=0 throughout: the half-tile forward kernel narrows the render lists to the sub-blocks an entry
         # contributed to when a backward follows, the row / sub-block kernels do not — the backward's float sums then
         # group differently; test_forward_for_backward_narrows_the_render_lists_losslessly holds that to its own contract)
-        env = dict(os.environ, LSR_FWD_QUAD="0", LSR_FWD_RECORD="0", **extra)
+        # (LSR_BWD_REV=0 throughout: which items the backward walks back to front depends on flags that only some forward
+        # kernels leave behind — round 6, tests/test_steep_alpha_gpu.py — and the two walk orders sum differently; the
+        # back-to-front walk gets its own two variants below)
+        env = dict(os.environ, LSR_FWD_QUAD="0", LSR_FWD_RECORD="0", LSR_BWD_REV="0", **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (name, r.stderr[-2000:])
         digests[name] = r.stdout.strip().splitlines()[-1]
     assert digests["default"].startswith("HASH ") and len(set(digests.values())) == 1, digests
+    # round 6: every item walked back to front — split between eight waves, four (the default here) or not at all: the
+    # same gradient records bit for bit (a part walks the batches BEHIND its share for the per-pixel state only)
+    rev = {}
+    for name, extra in {"rev_default": {}, "rev_unsplit": dict(LSR_BWD_PARTS="0"), "rev_eight_parts": dict(LSR_BWD_PARTS="3")}.items():
+        env = dict(os.environ, LSR_FWD_QUAD="0", LSR_FWD_RECORD="0", LSR_BWD_REV="1", **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        rev[name] = r.stdout.strip().splitlines()[-1]
+    assert rev["rev_default"].startswith("HASH ") and len(set(rev.values())) == 1, rev
+    assert rev["rev_default"] != digests["default"]      # (the two orders do differ in the last bits)
 
 
 @pytest.mark.parametrize("case", [

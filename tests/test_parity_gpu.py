@@ -231,9 +231,11 @@ def test_forward_shared_scene_equals_per_view(hip_device):
     _check_forward(bi, b)
 
 
-def _grad_case(hip_device, case, with_aux):
+def _grad_case(hip_device, case, with_aux, edit_scene=None):
     from latentsplat_amd.rasterizer import rasterize_views
     sc, H, W = _scene(case)
+    if edit_scene is not None:
+        edit_scene(sc)
     bi = util.boundary_inputs(sc, H, W, bg=(0.3, 0.1, 0.5))
     V = bi["V"]
     dev = hip_device

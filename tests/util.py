@@ -191,6 +191,13 @@ class HipRun:
                     out[v, y0:y0 + 8, x0:x0 + 16] = res
         return out
 
+    def item_flags(self):
+        """((V*T, 2) flags of the half-tile items, kHdrFlagsValid) as the forward compositing kernel left them."""
+        n = self.d.num_views * self.T * 2
+        f = self._view(self.geom, self.layout.geom_item_flags, n * 4, torch.int32).cpu().numpy().astype(np.int64).reshape(-1, 2)
+        hdr = self._view(self.geom, self.layout.geom_header, 32, torch.int32).cpu().numpy()
+        return f, int(hdr[6])
+
     def n_contrib(self):
         n = self.d.num_views * self.d.height * self.d.width
         return self._view(self.img, self.layout.img_n_contrib, n * 4, torch.int32).cpu().numpy().reshape(
