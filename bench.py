@@ -36,14 +36,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def build_inputs(G, V, size, device, seed):
+def build_inputs(G, V, size, device, seed, **scene_kw):
     """Scene-level inputs of one scene / V views, resident on the device: shared means (G,3),
     3x3 covariances, opacities and 4-channel latent features; per-view cameras in the (V,44) view
     table (built by the library's own kernel, scene scale 1/near included)."""
     from latentsplat_amd.rasterizer import build_view_table
     from latentsplat_amd.synthetic import make_scene
     sc = make_scene(G, image_size=size, views=V, color_sh_degree=None, feature_channels=4,
-                    feature_sh_degree=0, seed=seed).to(device)
+                    feature_sh_degree=0, seed=seed, **scene_kw).to(device)
     views = build_view_table(sc.extrinsics, sc.intrinsics, sc.near, sc.far, torch.zeros(3, device=device), True)
     features = (0.5 + 0.28209479177387814 * sc.feature_sh[..., 0]).contiguous()   # degree-0 latent SH
     return dict(views=views, means=sc.means.contiguous(), cov=sc.covariances.contiguous(),

@@ -23,7 +23,7 @@ namespace lsr {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t header, rec, bin, tile_count, tile_start, tile_cursor, item_flags, tile_order, half_count, sh_clamp, seg_keys, total;
+    size_t header, rec, bin, tile_count, tile_start, tile_cursor, item_flags, bin_queue, tile_order, half_count, sh_clamp, seg_keys, total;
     int rec_floats;
     uint32_t seg_cap;      // keys per (view, tile) segment of the single-pass binning; 0 = two-phase binning (k_scatter)
 };
@@ -40,6 +40,8 @@ struct BinLayout {
 // (k_preprocess_bwd turns the moments into dL/d mean, conic, opacity: the conic and the opacity
 // are constant over a Gaussian's pixels.)  16 floats (one 64-byte line) for <= 8 payload
 // channels, 32 for <= 12, 64 beyond.
+// per-SIMD-bin queue heads of the compositing kernels (experiment knobs LSR_FWD_BINQ / LSR_BWD_BINQ): room for 4096 bins
+constexpr size_t kBinQueueBytes = 4096 * 4;
 struct GradLayout {
     size_t rec, fixed, total;
     int rec_floats;
@@ -134,6 +136,7 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     // entry of opacity >= kSteepOpacity for this item, i.e. a pixel may have blended an alpha close to the 0.99 clamp; the
     // compositing backward then walks the item's list BACK TO FRONT (render_backward.hip)
     L.item_flags = o; o = align_up(o + 2 * VT * 4);
+    L.bin_queue = o; o += kBinQueueBytes;          // (cleared with the rest of the range)
     L.tile_start = o; o = align_up(o + (VT + 1) * 4);
     L.tile_order = o; o = align_up(o + 2 * VT * 4);   // work items (see kItem*), costliest first
     L.half_count = o; o = align_up(o + 2 * VT * 4);   // entries of the two half-tile render lists of every (view, tile)
@@ -182,7 +185,7 @@ inline GradLayout grad_layout(const lsr_dims &d) {
     // behind the float records: 512 zeroed bytes — the compositing backward's work-queue word (fixed - 512) and one all-zero
     // record line (fixed - 256) that the per-Gaussian backward kernels read in place of the records of CULLED (view,
     // Gaussian) slots: one cached line instead of a third of the record array
-    L.fixed = align_up(VG * (size_t)L.rec_floats * 4 + 512);   // [V*G][rec_floats] int64, deterministic mode only
+    L.fixed = align_up(VG * (size_t)L.rec_floats * 4 + 512 + kBinQueueBytes);   // [V*G][rec_floats] int64, deterministic mode only
     L.total = L.fixed + (deterministic_backward() ? align_up(VG * (size_t)L.rec_floats * 8) : 0);
     return L;
 }

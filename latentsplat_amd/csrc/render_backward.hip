@@ -52,6 +52,7 @@ struct RenderBwdParams {
     const uint32_t *items;        // work items of the forward (view*T + tile | half << 28), costliest first
     const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t *queue;              // work-queue head (zeroed with the gradient workspace)
+    uint32_t *bin_queue;          // per-SIMD-bin queue heads (LSR_BWD_BINQ=1, experiment), or nullptr: one global queue
     int prio_pct;                 // issue priority by progress: percentage of the launch's mean tile list (0 = off; see the kernel)
     const uint32_t *item_flags;   // [2 V T] kItemFlagSteep per half-tile item, written by the forward compositing kernel (lsr_internal.h)
     int rev_mode;                 // which items are walked BACK TO FRONT: 0 none, 1 all, 2 the steep ones (and all when the forward left no flags)
@@ -200,8 +201,16 @@ k_render_bwd(RenderBwdParams p) {
         } else {
             if (num_items <= slots) break;
             uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(p.queue, 1u);
-            qi = slots + __builtin_amdgcn_readfirstlane(t);
+            if (p.bin_queue) {
+                // per-SIMD-bin lists as in k_render_fwd (LSR_BWD_BINQ=1; measured no gain here: 0.570 -> 0.568 ms at 16 views x 300 k,
+                // +2.5 % on opaque scenes, +3 % at 10^6 Gaussians: off by default)
+                if (lane == 0) t = atomicAdd(p.bin_queue + bin, 1u);
+                const uint32_t k = (uint32_t)(WPB * WGS) / 4u + __builtin_amdgcn_readfirstlane(t);
+                qi = (k & 1u) ? (k + 1u) * simd_bins - 1u - bin : k * simd_bins + bin;
+            } else {
+                if (lane == 0) t = atomicAdd(p.queue, 1u);
+                qi = slots + __builtin_amdgcn_readfirstlane(t);
+            }
             if (qi >= num_items) break;
         }
         qi = __builtin_amdgcn_readfirstlane(qi);
@@ -599,6 +608,7 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     const bool det = deterministic_backward();
     p.rec_fixed = det ? (long long *)(grad + R.fixed) : nullptr;
     p.queue = (uint32_t *)(grad + R.fixed - 512);   // the zeroed slack behind the float records
+    p.bin_queue = (env_int("LSR_BWD_BINQ", 0) && 4 * p.num_cus <= (int)(kBinQueueBytes / 4)) ? (uint32_t *)(grad + R.fixed - 512 - kBinQueueBytes) : nullptr;
     p.item_flags = (const uint32_t *)(geom + L.item_flags);
     {   // LSR_BWD_REV: 0 never walk back to front, 1 always, 2 (default) the items the forward flagged as steep
         const int rm = env_int("LSR_BWD_REV", 2);

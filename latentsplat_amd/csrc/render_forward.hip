@@ -79,6 +79,7 @@ struct RenderFwdParams {
     uint32_t num_items;           // items of this launch (2 per (view, tile))
     uint32_t quad_items;          // k_render_fwd_small: leading (costliest) items rendered as sub-block items
     uint32_t *queue;              // work-queue head (zeroed per forward)
+    uint32_t *bin_queue;          // per-SIMD-bin queue heads (zeroed per forward), or nullptr: one global queue
     const uint32_t *header;       // geometry-workspace header (pair count: the launch's mean list length)
     int prio_pct;                 // issue priority by progress as in k_render_bwd (percentage of the mean tile list; 0 = off)
     unsigned long long *trace;    // debug builds (LSR_ENABLE_TRACE): per item {start clk, end clk, hw id, iterations << 32 | entries}
@@ -112,7 +113,10 @@ struct RenderFwdParams {
 // -1/255 (kept in a register pair instead).  Lossless for the backward by construction: an (entry, sub-block) without a
 // contributing pixel has alpha T = 0 everywhere on the sub-block, i.e. no gradient (the stopping entry of a pixel is not
 // blended and lies beyond the pixel's n_contrib).
-template <int NCHP, int WPB, bool RECORD = false>
+// EMU (timing experiments only, LSR_FWD_VARIANT 5 / 6; WRONG images): every item is walked by EMU waves, wave k taking the
+// k-th share of its batches from T = 1 — what a split along the list through the linearity of the composite would
+// execute, without its partial writes and combine pass (profiles/r06_ab_knobs.md: the bound of that design).
+template <int NCHP, int WPB, bool RECORD = false, int EMU = 0>
 __global__ void __launch_bounds__(LSR_WAVE * WPB, WPB == 14 ? 7 : ((RECORD && WPB == 12) ? 6 : 1))   // (2 x 14 waves: 72 registers, seven waves per SIMD; the RECORD instance of 2 x 12 must stay within six)
 k_render_fwd(RenderFwdParams p) {
     // Staged entries, one record per list entry: (x, y, a2, c2) (b2, log2(255 o), z / 255, -1 / 255) payload / 255 ...
@@ -147,7 +151,7 @@ k_render_fwd(RenderFwdParams p) {
 #pragma unroll
         for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    const uint32_t num_items = p.num_items;
+    const uint32_t num_items = EMU ? p.num_items * (uint32_t)EMU : p.num_items;
     const int coff = p.has_color ? 3 : 0;
     // RECORD: -1/255 lives in a register pair (the staged record's fourth word of its second quad collects the hit bits)
     float2_t kz2 = float2_t{-kInv255, -kInv255};
@@ -179,23 +183,41 @@ k_render_fwd(RenderFwdParams p) {
         } else {
             if (num_items <= slots) break;
             uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(p.queue, 1u);
-            qi = slots + __builtin_amdgcn_readfirstlane(t);
+            if (p.bin_queue) {
+                // per-SIMD-bin lists (round 6): the bin goes on with ITS ranks b, 2B-1-b, 2B+b, ... past the static first items
+                // instead of pulling from one global queue.  With the global queue the SIMDs of the 16-view launch end up with
+                // 8 +- 1 items — one item is a tenth of a SIMD's work, and the per-SIMD iteration totals (which set the
+                // launch time: every SIMD runs at 141 cycles per iteration from its first to its last item, item trace in
+                // profiles/r06_ab_knobs.md) spread by +-10 %; the bins' totals are balanced by construction
+                if (lane == 0) t = atomicAdd(p.bin_queue + bin, 1u);
+                const uint32_t k = (uint32_t)p.waves_per_cu / 4u + __builtin_amdgcn_readfirstlane(t);
+                qi = (k & 1u) ? (k + 1u) * simd_bins - 1u - bin : k * simd_bins + bin;
+            } else {
+                if (lane == 0) t = atomicAdd(p.queue, 1u);
+                qi = slots + __builtin_amdgcn_readfirstlane(t);
+            }
             if (qi >= num_items) break;
         }
 #ifdef LSR_ENABLE_TRACE
         const unsigned long long t_begin = p.trace ? __builtin_readcyclecounter() : 0ull;
+        unsigned long long t_first = 0ull, t_loop = 0ull;   // first batch staged / batch loop left
         uint32_t trace_iters = 0;   // lock-step iterations of this item
 #endif
         qi = __builtin_amdgcn_readfirstlane(qi);
-        const uint32_t item = p.items[qi];
+        const uint32_t item = p.items[EMU ? qi / (uint32_t)EMU : qi];
         const uint32_t vt = item & kItemTileMask, half = item >> kItemHalfShift;
         const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
         const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)half;
         const size_t vG = (size_t)v * p.G;
         const uint32_t tstart = p.tile_start[vt], tn = p.tile_start[vt + 1] - tstart;
-        const uint32_t hn = p.half_count[2 * (size_t)vt + half];
+        uint32_t hn = p.half_count[2 * (size_t)vt + half];
         const uint32_t *hlist = p.half_list + 2 * (size_t)tstart + (size_t)half * tn;
+        if (EMU) {   // this wave's share of the item's batches
+            const uint32_t nbat = (hn + LSR_WAVE - 1) / LSR_WAVE, part = qi % (uint32_t)EMU;
+            const uint32_t b0 = part * nbat / (uint32_t)EMU, b1 = (part + 1u) * nbat / (uint32_t)EMU;
+            hlist += b0 * LSR_WAVE;
+            hn = min(hn, b1 * LSR_WAVE) - min(hn, b0 * LSR_WAVE);
+        }
 
         // per-pixel state of the lane's two pixels as register pairs (pixel 0, pixel 1): the blend runs on
         // packed f32 instructions across the two pixels
@@ -292,6 +314,7 @@ k_render_fwd(RenderFwdParams p) {
             const uint32_t *lp = &s_list[grp][0];
 #ifdef LSR_ENABLE_TRACE
             trace_iters += nk;
+            if (p.trace && base == 0u) t_first = __builtin_readcyclecounter();
 #endif
             uint32_t hist = 0u;    // RECORD: one bit per iteration of the current chunk, newest in bit 0: this lane's pixels took part
             // RECORD: the list word of the NEXT iteration is read while this one computes (row 64 of a list is its pad word).
@@ -395,6 +418,9 @@ k_render_fwd(RenderFwdParams p) {
             if (burn_end && base + LSR_WAVE >= burn_end) { __builtin_amdgcn_s_setprio(0); burn_end = 0u; }
         }
         if (burn_end) __builtin_amdgcn_s_setprio(0);
+#ifdef LSR_ENABLE_TRACE
+        if (p.trace) t_loop = __builtin_readcyclecounter();
+#endif
         if (RECORD && lane == 0) {
             if (steep) p.item_flags[2 * (size_t)vt + half] = kItemFlagSteep;
             if (qi == 0u) p.header_rw[kHdrFlagsValid] = 1u;
@@ -432,10 +458,12 @@ k_render_fwd(RenderFwdParams p) {
             unsigned hwid, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            p.trace[4 * (size_t)qi + 0] = t_begin;
-            p.trace[4 * (size_t)qi + 1] = __builtin_readcyclecounter();
-            p.trace[4 * (size_t)qi + 2] = ((unsigned long long)xcc << 32) | hwid;
-            p.trace[4 * (size_t)qi + 3] = ((unsigned long long)trace_iters << 32) | hn;
+            p.trace[6 * (size_t)qi + 0] = t_begin;
+            p.trace[6 * (size_t)qi + 1] = __builtin_readcyclecounter();
+            p.trace[6 * (size_t)qi + 2] = ((unsigned long long)xcc << 32) | hwid;
+            p.trace[6 * (size_t)qi + 3] = ((unsigned long long)trace_iters << 32) | hn;
+            p.trace[6 * (size_t)qi + 4] = t_first;
+            p.trace[6 * (size_t)qi + 5] = t_loop;
         }
 #endif
     }  // persistent item loop
@@ -895,6 +923,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.items = (const uint32_t *)(geom + L.tile_order);
     p.num_items = 2u * (uint32_t)d.num_views * (uint32_t)p.T;
     p.queue = (uint32_t *)(geom + L.header) + kHdrQueueFwd;
+    p.bin_queue = nullptr;
     p.header = (const uint32_t *)(geom + L.header); p.prio_pct = 0;
     p.views = in.views;
     p.rec = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;
@@ -913,11 +942,11 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.trace = nullptr;
     p.quad_items = 0;
 #ifdef LSR_ENABLE_TRACE
-    const int64_t max_items = 2 * (int64_t)p.T * d.num_views;
+    const int64_t max_items = 2 * (int64_t)p.T * d.num_views * 4;     // (x 4: the EMU instances' units)
     const char *trace_path = getenv("LSR_TRACE");
     if (trace_path) {
-        (void)hipMalloc((void **)&p.trace, (size_t)max_items * 32);
-        (void)hipMemsetAsync(p.trace, 0, (size_t)max_items * 32, s);
+        (void)hipMalloc((void **)&p.trace, (size_t)max_items * 48);
+        (void)hipMemsetAsync(p.trace, 0, (size_t)max_items * 48, s);
     }
 #endif
     prof_begin(kStRenderFwd, s);
@@ -968,6 +997,20 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     if (record && nchp == 4 && variant == 0) LSR_RFR(4, 12, 24);
     else if (record && nchp == 8) LSR_RFR(8, 16, 16);
     else
+    // Per-SIMD-bin item lists instead of the global queue (see the kernel) for the 4-channel half-tile instances while the
+    // lists are short enough for an item to be a tenth of a SIMD's work.  Measured (profiles/r06_ab_knobs.md): 16 views x 300 k
+    // 0.2015 -> 0.1965 ms, the list-narrowing instance 0.2224 -> 0.2082; a scene of opaque 1-10 px splats 0.175 -> 0.162; 10^6
+    // Gaussians (6000-entry tile lists) +1 %, the 8-channel instances (configs[4]) +1.5 %: off there.  LSR_FWD_BINQ = 0 / 1 forces.
+    {
+        const int knob = env_int("LSR_FWD_BINQ", -1);
+        const bool on = knob >= 0 ? knob != 0 : (nchp == 4 && num_pairs <= 3000 * (int64_t)d.num_views * p.T);
+        if (on && 4 * p.num_cus <= (int)(kBinQueueBytes / 4)) p.bin_queue = (uint32_t *)(const_cast<char *>(geom) + L.bin_queue);
+    }
+    if (nchp == 4 && (variant == 5 || variant == 6)) {   // timing emulation of list splitting (see the kernel's EMU parameter)
+        p.waves_per_cu = 24;
+        if (variant == 5) hipLaunchKernelGGL((k_render_fwd<4, 12, false, 2>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+        else hipLaunchKernelGGL((k_render_fwd<4, 12, false, 4>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+    } else
     if (nchp == 4) { if (variant == 2) LSR_RF(4, 16, 16); else if (variant == 3) LSR_RF(4, 14, 28); else LSR_RF(4, 12, 24); }   // 2 x 12 waves per CU: 0.245 vs 0.281 ms per 16 views with 16
     // 7 / 8 channels (colour + 4 latent channels: the reference's configs[3] / [4] payload; 7.3 KB of LDS and 90 VGPRs per
     // wave).  Round 4 measured 2 x 10 waves per CU (what LDS and registers allow at most) and 2 x 8: configs[3] 0.1426 /
@@ -980,7 +1023,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     prof_end(kStRenderFwd, s);
 #ifdef LSR_ENABLE_TRACE
     if (trace_path) {  // debug only: dump per-item timing of this launch
-        std::vector<unsigned long long> host((size_t)max_items * 4);
+        std::vector<unsigned long long> host((size_t)max_items * 6);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(host.data(), p.trace, host.size() * 8, hipMemcpyDeviceToHost);
         if (FILE *f = fopen(trace_path, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }

@@ -20,7 +20,7 @@ import bench  # noqa: E402
 from latentsplat_amd import _lib  # noqa: E402
 from latentsplat_amd.rasterizer import rasterize_views  # noqa: E402
 
-DEFAULTS = {"LSR_BWD_PRIO_PCT": -1, "LSR_FWD_PRIO_PCT": -1, "LSR_FWD_RECORD": 1, "LSR_SEGMENTS": 1, "LSR_PRE_ITEMS": 8, "LSR_FOLD_SCAN": 1, "LSR_HOST_POLL": 1, "LSR_SORT_LPT": 1, "LSR_FUSE_SH": 1, "LSR_FWD_VARIANT": 0, "LSR_BWD_VARIANT": 0, "LSR_FWD_ROWS": -1}
+DEFAULTS = {"LSR_FWD_BINQ": -1, "LSR_BWD_BINQ": 0, "LSR_BWD_REV": 2, "LSR_BWD_PARTS": -1, "LSR_BWD_PRIO_PCT": -1, "LSR_FWD_PRIO_PCT": -1, "LSR_FWD_RECORD": 1, "LSR_SEGMENTS": 1, "LSR_PRE_ITEMS": 8, "LSR_FOLD_SCAN": 1, "LSR_HOST_POLL": 1, "LSR_SORT_LPT": 1, "LSR_FUSE_SH": 1, "LSR_FWD_VARIANT": 0, "LSR_BWD_VARIANT": 0, "LSR_FWD_ROWS": -1}
 
 
 def timed(fn, steps, dev):
@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--workloads", default="raster16,cfg3,cfg4")
     ap.add_argument("--gaussians", type=int, default=300_000, help="scene size of the raster16 workload")
+    ap.add_argument("--opacity-scale", type=float, default=1.0 / 3.0, help="raster16: opacities U(0, scale) (1: pixels run out of transmittance)")
+    ap.add_argument("--sigma", type=float, nargs=2, default=(0.3, 3.0), help="raster16: projected sigma range in pixels")
     ap.add_argument("sets", nargs="*")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -58,7 +60,7 @@ def main():
     wl = {}
     want = args.workloads.split(",")
     if "raster16" in want:
-        inp = bench.build_inputs(args.gaussians, 16, 256, dev, 1234)
+        inp = bench.build_inputs(args.gaussians, 16, 256, dev, 1234, opacity_scale=args.opacity_scale, sigma_px=tuple(args.sigma))
         gf = torch.randn((16, 4, 256, 256), device=dev)
 
         def r_fwd():

@@ -27,8 +27,15 @@ def main():
             for _ in range(3):
                 rasterize_views(inp["views"], 256, 256, 0, inp["means"], inp["cov"], inp["opac"], features=inp["features"])
         torch.cuda.synchronize()
-    raw = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)
+    raw = np.fromfile(path, dtype=np.uint64).reshape(-1, 6)
     raw = raw[raw[:, 1] > 0]
+    # (round 6) [4] = first batch staged, [5] = batch loop left: the item's prologue (metadata + the two dependent loads of
+    # its first batch) and epilogue (per-pixel stores)
+    pro = (raw[:, 4].astype(np.int64) - raw[:, 0].astype(np.int64))[raw[:, 4] > 0]
+    epi = (raw[:, 1].astype(np.int64) - raw[:, 5].astype(np.int64))[raw[:, 5] > 0]
+    if len(pro):
+        print(f"prologue (item picked -> first batch staged): mean {pro.mean():.0f} p50 {np.median(pro):.0f} p90 {np.percentile(pro, 90):.0f} cycles; "
+              f"epilogue (loop left -> stores issued): mean {epi.mean():.0f} p50 {np.median(epi):.0f} p90 {np.percentile(epi, 90):.0f}")
     t0, t1 = raw[:, 0].astype(np.int64), raw[:, 1].astype(np.int64)
     hw = raw[:, 2]
     iters, ents = (raw[:, 3] >> np.uint64(32)).astype(np.int64), (raw[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
