@@ -19,6 +19,7 @@ COLOR_NONE, COLOR_SH, COLOR_PRECOMP = 0, 1, 2
 FEAT_DIRECT, FEAT_SH = 0, 1
 SH_AXES_3DGS, SH_AXES_REFERENCE = 0, 1   # lsr_dims.color_sh_convention
 FWD_FOR_BACKWARD = 1                      # lsr_dims.forward_flags
+FWD_CLEARS_GRAD = 2
 MAX_SH_GROUP_FLOATS = 120   # C*Kf the fused latent-SH path supports (LDS budget of sh.hip)
 MAX_FEAT_CHANNELS = 32
 
@@ -45,7 +46,7 @@ class Inputs(C.Structure):
 
 class Outputs(C.Structure):
     _fields_ = [("color", C.c_void_p), ("feature", C.c_void_p), ("mask", C.c_void_p),
-                ("depth", C.c_void_p), ("radii", C.c_void_p)]
+                ("depth", C.c_void_p), ("radii", C.c_void_p), ("grad_ws", C.c_void_p)]
 
 
 class OutGrads(C.Structure):

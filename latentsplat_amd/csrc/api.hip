@@ -192,6 +192,7 @@ static int check_dims(const lsr_dims *d) {
     if (d->feat_channels > 0 && d->vs_feat != 0 && d->vs_feat != feat_elems * G) return LSR_EINVAL;
     if (d->color_sh_convention != LSR_SH_AXES_3DGS && d->color_sh_convention != LSR_SH_AXES_REFERENCE) return LSR_EINVAL;
     if (d->views_per_group < 0) return LSR_EINVAL;
+    if (d->forward_flags & ~(LSR_FWD_FOR_BACKWARD | LSR_FWD_CLEARS_GRAD)) return LSR_EINVAL;
     if (d->views_per_group > 1) {   // view groups: all inputs strided per group
         if (d->num_views % d->views_per_group != 0) return LSR_EINVAL;
         if (d->vs_means == 0 || d->vs_cov == 0 || d->vs_opac == 0) return LSR_EUNSUPPORTED;
@@ -219,6 +220,32 @@ static int sh_forward_inline(const lsr_dims &d, const lsr_inputs &in, char *geom
     return LSR_OK;
 }
 
+// The library's one side stream (per host thread and device; created on first use): only ever forked from and joined
+// back into the caller's stream with events inside one call, so the caller's stream order — and a hipGraph capture of
+// it — covers everything launched there.
+namespace {
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+bool side_stream(SideStream &out) {
+    static thread_local SideStream per_dev[64];
+    static thread_local bool failed[64] = {};
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || failed[dev]) { (void)hipGetLastError(); return false; }
+    SideStream &ss = per_dev[dev];
+    if (!ss.stream) {
+        if (hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            failed[dev] = true;
+            ss = SideStream();
+            return false;
+        }
+    }
+    out = ss;
+    return true;
+}
+}  // namespace
+
 // Binning + forward compositing on `s`.
 // (Round 3 also carried an in-call pipeline that ran the binning of one half of the views beside the compositing of
 // the other half on a side stream: bit-identical, never faster — both halves are issue-bound — and deleted in
@@ -226,8 +253,26 @@ static int sh_forward_inline(const lsr_dims &d, const lsr_inputs &in, char *geom
 static int forward_tail(const lsr_dims &d, const lsr_inputs &in, char *geom, char *bin, char *img, int64_t num_pairs,
                         int32_t max_tile_pairs, const lsr_outputs &out, hipStream_t s, bool device_counts, bool seg,
                         bool speculative = false) {
+    // LSR_FWD_CLEARS_GRAD: the backward's gradient workspace is zeroed BESIDE the compositing kernel, on a side stream forked
+    // in front of it and joined behind it.  The compositing kernel is bound by instruction issue and leaves register space for
+    // one more wave per SIMD (6 x 80 of 512 VGPRs) and three quarters of the HBM bandwidth; the streaming clear (0.05 ms per
+    // forward + backward step at 16 views x 300 k when it runs alone in front of the compositing backward) costs it 0.011 ms.
+    // Measured (profiles/r06_ab_knobs.md section 5): forward + backward 1.0775 -> 1.056 ms; forked in front of the per-tile
+    // sort as well, the sort pays what the clear saves (0.068 -> 0.098 ms: 1.089); the compositing waves storing the zeros
+    // themselves, a few KB per batch: 1.058.  LSR_CLEAR_BESIDE=0: the clear runs behind the compositing kernel on `s`.
+    const bool clears = (d.forward_flags & LSR_FWD_CLEARS_GRAD) != 0 && d.num_gaussians > 0;
+    SideStream side;
+    const bool beside = clears && env_int("LSR_CLEAR_BESIDE", 1) != 0 && side_stream(side);
     LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts, seg, speculative));
+    if (beside) {
+        LSR_HIP(hipEventRecord(side.fork, s));
+        LSR_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
+        LSR_HIP(launch_clear_grad(d, out.radii, (char *)out.grad_ws, side.stream));
+        LSR_HIP(hipEventRecord(side.join, side.stream));
+    }
     LSR_STAGE("render_forward", s, launch_render_forward(d, in, geom, bin, num_pairs, img, out, s));
+    if (beside) LSR_HIP(hipStreamWaitEvent(s, side.join, 0));
+    else if (clears) LSR_HIP(launch_clear_grad(d, out.radii, (char *)out.grad_ws, s));
     return LSR_OK;
 }
 
@@ -523,6 +568,7 @@ int lsr_forward_render(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     if (d->color_mode != LSR_COLOR_NONE && !out->color) return LSR_ENULL;
     if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
     if (num_pairs < 0 || max_tile_pairs < 0) return LSR_EINVAL;
+    if ((d->forward_flags & LSR_FWD_CLEARS_GRAD) && d->num_gaussians > 0 && !out->grad_ws) return LSR_ENULL;
     hipStream_t s = (hipStream_t)stream;
     // binning + compositing.  Single-pass binning iff lsr_forward_prepare used it (the same pure function of the dims);
     // `max_tile_pairs` tells launch_binning whether any tile outgrew its key segment and needs the fallback scatter
@@ -548,6 +594,7 @@ int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     if (d->color_mode != LSR_COLOR_NONE && !out->color) return LSR_ENULL;
     if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
     if (pair_capacity < 1 || pair_capacity >= ((int64_t)1 << 32) || max_tile_hint < 0) return LSR_EINVAL;
+    if ((d->forward_flags & LSR_FWD_CLEARS_GRAD) && d->num_gaussians > 0 && !out->grad_ws) return LSR_ENULL;
     hipStream_t s = (hipStream_t)stream;
     char *geom = (char *)geom_ws;
     // the same stage sequence as prepare + render; nothing between the launches waits for the device.  Single-pass
@@ -571,6 +618,7 @@ int lsr_forward_speculative(const lsr_dims *d, const lsr_inputs *in, void *geom_
     if (d->color_mode != LSR_COLOR_NONE && !out->color) return LSR_ENULL;
     if (d->feat_channels > 0 && !out->feature) return LSR_ENULL;
     if (pair_capacity < 1 || pair_capacity >= ((int64_t)1 << 32) || max_tile_hint < 1) return LSR_EINVAL;
+    if ((d->forward_flags & LSR_FWD_CLEARS_GRAD) && d->num_gaussians > 0 && !out->grad_ws) return LSR_ENULL;
     hipStream_t s = (hipStream_t)stream;
     char *geom = (char *)geom_ws;
     // Everything is launched at once with the launch structure of the SYNCHRONOUS forward for (pair_capacity,
@@ -631,8 +679,8 @@ int lsr_backward(const lsr_dims *d, const lsr_inputs *in, const void *geom_ws, c
     if (d->feat_channels > 0 && !gin->features) return LSR_ENULL;
     if (num_pairs > 0 && !bin_ws) return LSR_ENULL;
     hipStream_t s = (hipStream_t)stream;
-    // zero the packed gradient records the compositing backward accumulates into
-    LSR_HIP(launch_clear_grad(*d, radii, (char *)grad_ws, s));
+    // zero the packed gradient records the compositing backward accumulates into (unless the forward did: LSR_FWD_CLEARS_GRAD)
+    if (!(d->forward_flags & LSR_FWD_CLEARS_GRAD)) LSR_HIP(launch_clear_grad(*d, radii, (char *)grad_ws, s));
     if (num_pairs > 0)
         LSR_STAGE("render_backward", s, launch_render_backward(*d, *in, (const char *)geom_ws, (const char *)bin_ws, num_pairs,
                                        (const char *)img_ws, *fwd, *gout, (char *)grad_ws, *gin, s));

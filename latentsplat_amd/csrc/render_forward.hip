@@ -994,9 +994,6 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
         const int prio_knob = env_int("LSR_FWD_PRIO_PCT", -1);
         p.prio_pct = prio_knob >= 0 ? prio_knob : ((record && nchp == 8) ? 18 : 0);
     }
-    if (record && nchp == 4 && variant == 0) LSR_RFR(4, 12, 24);
-    else if (record && nchp == 8) LSR_RFR(8, 16, 16);
-    else
     // Per-SIMD-bin item lists instead of the global queue (see the kernel) for the 4-channel half-tile instances while the
     // lists are short enough for an item to be a tenth of a SIMD's work.  Measured (profiles/r06_ab_knobs.md): 16 views x 300 k
     // 0.2015 -> 0.1965 ms, the list-narrowing instance 0.2224 -> 0.2082; a scene of opaque 1-10 px splats 0.175 -> 0.162; 10^6
@@ -1006,6 +1003,9 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
         const bool on = knob >= 0 ? knob != 0 : (nchp == 4 && num_pairs <= 3000 * (int64_t)d.num_views * p.T);
         if (on && 4 * p.num_cus <= (int)(kBinQueueBytes / 4)) p.bin_queue = (uint32_t *)(const_cast<char *>(geom) + L.bin_queue);
     }
+    if (record && nchp == 4 && variant == 0) LSR_RFR(4, 12, 24);
+    else if (record && nchp == 8) LSR_RFR(8, 16, 16);
+    else
     if (nchp == 4 && (variant == 5 || variant == 6)) {   // timing emulation of list splitting (see the kernel's EMU parameter)
         p.waves_per_cu = 24;
         if (variant == 5) hipLaunchKernelGGL((k_render_fwd<4, 12, false, 2>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);

@@ -139,6 +139,8 @@ def get_color_sh_convention() -> str:
 # that needs more than was provided is simply run again through the exact path (and raises the estimate).
 # LSR_SPECULATIVE=0 turns it off.
 _SPECULATE = __import__("os").environ.get("LSR_SPECULATIVE", "1") != "0"
+# LSR_CLEAR_IN_FORWARD=0: lsr_backward clears its gradient workspace itself (the pre-v9 behaviour)
+_FWD_CLEARS_GRAD = __import__("os").environ.get("LSR_CLEAR_IN_FORWARD", "1") != "0"
 _ESTIMATES: dict = {}      # shape key -> [pairs, longest tile list] (decaying maxima of the recent calls)
 SPECULATION_STATS = dict(speculative=0, reruns=0, exact=0)
 
@@ -156,7 +158,7 @@ def _tier_hint(longest: float) -> int:
 class _Plan:
     """Everything one forward call hands to the matching backward."""
     __slots__ = ("dims", "geom", "bin", "img", "num_pairs", "radii", "V", "G", "H", "W", "C",
-                 "color_mode", "K")
+                 "color_mode", "K", "gradws")
 
 
 class _RasterizeViews(torch.autograd.Function):
@@ -224,9 +226,10 @@ class _RasterizeViews(torch.autograd.Function):
                  cov_elems, _lib.FEAT_SH if feat_sh else _lib.FEAT_DIRECT, max(int(feat_sh_degree), 0), Kf,
                  1 if (shs is not None and shs_channel_major) else 0, vpg if vpg > 1 else 0,
                  _COLOR_SH_CONVENTION,
-                 # a backward will follow: the forward narrows the render lists to where every entry contributed
+                 # a backward will follow: the forward narrows the render lists to where every entry contributed and
+                 # zeroes the backward's gradient workspace on the side (ABI v9: lsr_backward then skips its clear)
                  # (grad_mode: torch.is_grad_enabled() of the CALLER — inside Function.forward it is always off)
-                 _lib.FWD_FOR_BACKWARD if (grad_mode and any(ctx.needs_input_grad)) else 0)
+                 (_lib.FWD_FOR_BACKWARD | (_lib.FWD_CLEARS_GRAD if _FWD_CLEARS_GRAD else 0)) if (grad_mode and any(ctx.needs_input_grad) and G > 0) else 0)
         inp = Inputs(_ptr(views), _ptr(means3D), _ptr(cov3D), _ptr(opacities), _ptr(color), _ptr(features))
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         u8 = dict(dtype=torch.uint8, device=dev)
@@ -246,7 +249,9 @@ class _RasterizeViews(torch.autograd.Function):
             out_feat = torch.empty((V, Cf, H, W), **f32) if Cf else None
             out_mask = torch.empty((V, H, W), **f32)
             out_depth = torch.empty((V, H, W), **f32)
-            outs = Outputs(_ptr(out_color), _ptr(out_feat), _ptr(out_mask), _ptr(out_depth), _ptr(radii))
+            gradws = (torch.empty(lib.lsr_grad_workspace_bytes(C.byref(d)), **u8)
+                      if d.forward_flags & _lib.FWD_CLEARS_GRAD else None)
+            outs = Outputs(_ptr(out_color), _ptr(out_feat), _ptr(out_mask), _ptr(out_depth), _ptr(radii), _ptr(gradws))
             if pair_capacity > 0:
                 # latency mode: no host synchronisation; the pair count stays on the device
                 # (last_forward_status() reads it back when the caller wants to check for overflow)
@@ -304,7 +309,7 @@ class _RasterizeViews(torch.autograd.Function):
                                        f"with the host's {npairs.value}")
         plan = _Plan()
         plan.dims, plan.geom, plan.bin, plan.img = d, geom, binws, img
-        plan.num_pairs, plan.radii = layout_pairs, radii
+        plan.num_pairs, plan.radii, plan.gradws = layout_pairs, radii, gradws
         plan.V, plan.G, plan.H, plan.W, plan.C, plan.color_mode, plan.K = V, G, H, W, Cf, color_mode, K
         ctx.plan = plan
         LAST_STATS.update(num_pairs=None if pair_capacity > 0 else npairs.value, max_tile_pairs=maxtile.value, views=V,
@@ -360,7 +365,14 @@ class _RasterizeViews(torch.autograd.Function):
         d_feat = torch.empty_like(features) if has_f else None
         want_m2d = ctx.m2d_shape is not None and ctx.needs_input_grad[2]
         d_m2d = torch.empty((V, G, 3), **f32) if want_m2d else None   # 12 B per (view, Gaussian) nobody reads otherwise
-        gradws = torch.empty(lib.lsr_grad_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
+        # the gradient workspace the forward zeroed; a second backward over the same graph (retain_graph) gets a fresh one
+        # and has lsr_backward clear it itself (dims without the flag)
+        gradws, plan.gradws = plan.gradws, None
+        if gradws is None:
+            if d.forward_flags & _lib.FWD_CLEARS_GRAD:
+                d = Dims.from_buffer_copy(d)
+                d.forward_flags &= ~_lib.FWD_CLEARS_GRAD
+            gradws = torch.empty(lib.lsr_grad_workspace_bytes(C.byref(d)), dtype=torch.uint8, device=dev)
         gout = OutGrads(_ptr(g_color), _ptr(g_feat), _ptr(g_mask), _ptr(g_depth))
         fwd = Outputs(_ptr(f_color) if f_color.numel() else None, _ptr(f_feat) if f_feat.numel() else None,
                       None, _ptr(f_depth), None)

@@ -135,3 +135,46 @@ def test_ordinary_scenes_in_either_walk_order(hip_device, name, rev):
         tp._grad_case(hip_device, tp.GRAD_CASES[name], True)
     finally:
         _lib.set_knob("LSR_BWD_REV", 2)
+
+
+@pytest.mark.parametrize("views,G", [(16, 60_000), (3, 20_000)])
+def test_forward_zeroes_the_gradient_workspace(hip_device, views, G):
+    """ABI v9, LSR_FWD_CLEARS_GRAD: a forward that a backward follows zeroes the backward's gradient workspace beside its sort
+    and compositing kernels (a side stream forked and joined inside the call) and lsr_backward skips its own clear.  The
+    workspace is allocated over memory poisoned with NaNs; the gradients must equal those of a second backward over the same
+    graph (which clears a fresh workspace itself) and those of the path that clears on the caller's stream."""
+    from latentsplat_amd import _lib
+    from latentsplat_amd.rasterizer import rasterize_views
+    dev = hip_device
+    sc = util.make_scene(G, image_size=256, views=views, color_sh_degree=None, feature_channels=4)
+    bi = util.boundary_inputs(sc, 256, 256)
+    vt = util.view_table(bi, dev)
+    t = {k: bi[k].to(dev) for k in ("means", "cov6", "opac", "features")}
+    gen = torch.Generator().manual_seed(3)
+    gf = torch.randn((views, 4, 256, 256), generator=gen).to(dev)
+
+    def run(twice):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+        poison = torch.full((96 << 20,), float("nan"), device=dev)     # 384 MB of NaNs back into the caching allocator
+        del poison
+        out = rasterize_views(vt, 256, 256, 0, leaves["means"], leaves["cov6"], leaves["opac"], features=leaves["features"])
+        out[1].backward(gf, retain_graph=twice)
+        first = {k: v.grad.clone() for k, v in leaves.items()}
+        if twice:
+            for v in leaves.values():
+                v.grad = None
+            out[1].backward(gf)
+            return first, {k: v.grad.clone() for k, v in leaves.items()}
+        return first, None
+
+    a, b = run(True)
+    try:
+        _lib.set_knob("LSR_CLEAR_BESIDE", 0)
+        c, _ = run(False)
+    finally:
+        _lib.set_knob("LSR_CLEAR_BESIDE", 1)
+    for k in a:
+        assert torch.isfinite(a[k]).all(), k
+        scale = max(1.0, float(a[k].abs().max()))
+        assert float((a[k] - b[k]).abs().max()) <= 2e-5 * scale, k     # (float atomics: order of the sums)
+        assert float((a[k] - c[k]).abs().max()) <= 2e-5 * scale, k
