@@ -81,6 +81,16 @@ def cpu_baseline(G, size, seed, budget_s=12.0):
                 fwdbwd_value=nb / el_b, fwdbwd_sample=f"{nb} forward+backward passes of that view")
 
 
+def kernel_source_hash():
+    """First 16 hex digits of sha256(render_forward.hip + lsr_blend.h): what profiles/traffic_render_forward.json is tied to."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("render_forward.hip", "lsr_blend.h"):
+        with open(os.path.join(ROOT, "latentsplat_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def parity_gate(G, V, size, seed, dev):
     """"parity gates reported next to every timing".  OUTSIDE every timed region (part of the
     cpu_baseline leg: rank 0, N = 1): the bench workload — the same seeded scene, all V views in ONE call through the C ABI,
@@ -199,15 +209,21 @@ def rank_seed(base, rank):
     return base + rank
 
 
-def decoder_step_timing(dev, steps=40, scenes=1):
+def decoder_step_timing(dev, steps=40, scenes=1, encoder_shaped=False):
     """BASELINE configs[3] shape through the decoder surface: DecoderSplattingCUDA.forward
     (+ backward of an MSE-like loss on colour and latent mean) for batch_size 1 x 4 target views,
     G = 393 216 Gaussians (2 context views x 256^2 x 3), colour SH degree 4 + 4-channel latent SH
-    degree 2 — the call the reference's training_step makes (model_wrapper.py:361-371)."""
+    degree 2 — the call the reference's training_step makes (model_wrapper.py:361-371).
+    encoder_shaped: the Gaussians the reference's encoder really emits (synthetic.make_encoder_scene: pixel-aligned, three per
+    ray of two context views, in ray order: encoder_epipolar.py:184-236, gaussian_adapter.py:75-114) instead of make_scene's
+    random cloud."""
     from latentsplat_amd import decoder as dec
-    from latentsplat_amd.synthetic import make_scene
-    scs = [make_scene(393_216, image_size=256, views=4, color_sh_degree=4, feature_channels=4,
-                      feature_sh_degree=2, seed=4321 + i).to(dev) for i in range(scenes)]
+    from latentsplat_amd.synthetic import make_encoder_scene, make_scene
+    if encoder_shaped:
+        scs = [make_encoder_scene(seed=4321 + i).to(dev) for i in range(scenes)]
+    else:
+        scs = [make_scene(393_216, image_size=256, views=4, color_sh_degree=4, feature_channels=4,
+                          feature_sh_degree=2, seed=4321 + i).to(dev) for i in range(scenes)]
     st = lambda name: torch.stack([getattr(sc, name) for sc in scs])
     leaf = lambda name: st(name).contiguous().requires_grad_(True)
     gauss = dec.Gaussians(leaf("means"), leaf("covariances"), leaf("opacities"), leaf("color_sh"), leaf("feature_sh"))
@@ -231,15 +247,17 @@ def decoder_step_timing(dev, steps=40, scenes=1):
     from latentsplat_amd import rasterizer as rz
     for name, fn in (("forward", fwd), ("forward_backward", fwdbwd)):
         before = dict(rz.SPECULATION_STATS)
-        # (the better of two timed regions: one of the round's runs caught a single ~30 ms stall inside this 40-step region —
-        # 1.51 instead of 0.77-0.79 ms per step in every other run; the headline region is 200 steps and is timed once)
-        el = min(timed_region(fn, steps, 10, None, lambda: torch.cuda.synchronize(dev)) for _ in range(2))
+        # two timed regions, BOTH reported (`ms_per_step_regions`); `ms_per_step` is the first, as the headline's single region
+        # is (round 5 reported the better of the two after one run caught a single ~30 ms stall inside a 40-step region)
+        els = [timed_region(fn, steps, 10, None, lambda: torch.cuda.synchronize(dev)) for _ in range(2)]
+        el = els[0]
         # which host protocol the calls of this leg (warm-up included) took: speculative launches, exact (two-half) forwards,
         # speculative launches that had to be re-run — a leg that re-runs shows up here, not just as a slow number
-        res[name] = dict(ms_per_step=1e3 * el / steps, views_per_s=4 * scenes * steps / el,
+        res[name] = dict(ms_per_step=1e3 * el / steps, ms_per_step_regions=[1e3 * e / steps for e in els], views_per_s=4 * scenes * steps / el,
                          host_protocol={k: rz.SPECULATION_STATS[k] - before[k] for k in before})   # (both regions and their warm-ups)
     res["config"] = (f"configs[{3 if scenes == 1 else 4}] per-GPU shape: {scenes} scene(s) x 4 views, 393216 Gaussians each, "
-                     "colour SH deg 4 + 4-ch latent SH deg 2, 256x256")
+                     "colour SH deg 4 + 4-ch latent SH deg 2, 256x256; "
+                     + ("encoder-shaped scene (pixel-aligned, 3 per ray of 2 context views, ray order)" if encoder_shaped else "random cloud"))
     # per-kernel times of the same step (hipEvents inside the library), and the SH kernels against the HBM roofline:
     # the path's only kernels that exist because of the reference's payload (degree-4 colour + latent harmonics).
     # Algorithmic bytes per launch (all scenes): coefficients (75 + 36 floats per Gaussian) read once per scene,
@@ -738,15 +756,23 @@ def main():
         achieved = render_bytes / (render_ms_per_launch * 1e-3) / 1e9
         traffic, tinfo = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_render_forward.json")
+        tstale = None
         if os.path.exists(tpath):
             try:
                 tinfo = json.load(open(tpath))
                 traffic = tinfo.get("hbm_bytes_per_launch")
             except Exception:
                 traffic, tinfo = None, None
+            # the counters were taken on a specific build of the kernel: the file carries the hash of render_forward.hip it was
+            # measured with (tools/pmc_summary.py); a kernel edited since then reports no traffic rather than a stale one
+            if tinfo is not None:
+                have = kernel_source_hash()
+                if tinfo.get("kernel_source_sha16") != have:
+                    tstale = f"measured on render_forward.hip {tinfo.get('kernel_source_sha16')}, this build is {have}: re-run tools/collect_profile.sh"
+                    traffic = None
         roofline = dict(bound="hbm", kernel="k_render_fwd", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic,
-                        traffic_source=None if tinfo is None else tinfo.get("source_commit"),
+                        traffic_source=None if tinfo is None else (tstale or tinfo.get("source_commit")),
                         algorithmic_bytes_per_launch=render_bytes, launch_ms=render_ms_per_launch)
         # The kernel is bound by f32 VALU issue, not by HBM: report that ceiling next to the required
         # HBM figure.  Instruction counts come from the committed PMC pass (same workload), the
@@ -824,6 +850,9 @@ def main():
         torch.cuda.empty_cache()
         dec_step = decoder_step_timing(dev)
         dec_step["batch4"] = decoder_step_timing(dev, scenes=4)      # configs[4]: batch_size 4 per GPU
+        # the same two steps on the Gaussian distribution the reference's encoder emits
+        dec_step["encoder_shaped"] = decoder_step_timing(dev, encoder_shaped=True)
+        dec_step["encoder_shaped"]["batch4"] = decoder_step_timing(dev, scenes=4, encoder_shaped=True)
         adapter_step = adapter_step_timing(dev)
         latent_step = latent_step_timing(dev)
         path_step = path_step_timing(dev)
@@ -883,9 +912,12 @@ def main():
             line["kernel_ms_fwdbwd"] = {k: r4(v) for k, v in fb["kernel_ms_per_launch"].items() if v}
         line["per_rank_ms_per_step"] = [r4(x) for x in per_rank_fwd]
         if dec_step is not None:
-            line["decoder_step"] = {"cfg3_1x4": [r4(dec_step["forward"]["ms_per_step"]), r4(dec_step["forward_backward"]["ms_per_step"])],
-                                    "cfg4_4x4": [r4(dec_step["batch4"]["forward"]["ms_per_step"]), r4(dec_step["batch4"]["forward_backward"]["ms_per_step"])],
-                                    "unit": "ms per step [forward, forward+backward]"}
+            both = lambda d: [[r4(x) for x in d["forward"]["ms_per_step_regions"]], [r4(x) for x in d["forward_backward"]["ms_per_step_regions"]]]
+            enc = dec_step["encoder_shaped"]
+            line["decoder_step"] = {"cfg3_1x4": both(dec_step), "cfg4_4x4": both(dec_step["batch4"]),
+                                    "cfg3_encoder_shaped": both(enc), "cfg4_encoder_shaped": both(enc["batch4"]),
+                                    "unit": "ms per step [[forward: region 1, region 2], [forward+backward: region 1, region 2]]; "
+                                            "encoder_shaped: pixel-aligned Gaussians in ray order instead of a random cloud"}
             shr = lambda d: {k: [v["ms"], v["frac"]] for k, v in (d.get("sh_roofline") or {}).items()}
             line["decoder_step"]["sh_roofline"] = {"cfg3": shr(dec_step), "cfg4": shr(dec_step["batch4"]),
                                                    "unit": "[ms per launch, lower-bound fraction of the 8 TB/s HBM peak]"}
@@ -893,6 +925,7 @@ def main():
             # `preprocess` is the fused projection + SH payload kernel there)
             line["decoder_step"]["cfg3_kernel_ms"] = dec_step.get("kernel_ms")
             line["decoder_step"]["cfg4_kernel_ms"] = dec_step["batch4"].get("kernel_ms")
+            line["decoder_step"]["cfg4_encoder_shaped_kernel_ms"] = enc["batch4"].get("kernel_ms")
         if path_step is not None:
             line["path_step"] = pick(path_step, ("forward_ms", "forward_backward_ms"))
         line["full"] = None if side is None else os.path.relpath(side, ROOT)

@@ -128,6 +128,13 @@ typedef struct lsr_dims {
                                0.05 ms of the forward + backward step) — and lsr_backward, handed dims with the same bit,
                                skips its clear.  Set it for BOTH calls or
                                neither.  Other bits must be 0 (LSR_EINVAL). */
+    int32_t seg_cap_hint;   /* (ABI v9) 0, or the longest tile list (in (Gaussian, tile) pairs) the caller expects — e.g. the
+                               `max_tile_pairs` of an earlier call of the same shape plus a margin.  Sizes the per-(view, tile)
+                               key segments of the single-pass binning, which are REAL device memory at the end of geom_ws
+                               (V * T * capacity * 8 bytes: 268 MB for 16 views of 256 x 256 at the default capacity of 8192,
+                               134 MB with a hint of 4096).  A list that outgrows its segment is binned again by the
+                               fallback scatter: correct, slower.  Part of the workspace layout: hand the SAME value to
+                               lsr_geom_workspace_bytes and to every call that touches the workspaces of a forward. */
 } lsr_dims;
 #define LSR_FWD_FOR_BACKWARD 1
 #define LSR_FWD_CLEARS_GRAD 2

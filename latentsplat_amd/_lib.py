@@ -36,7 +36,7 @@ class Dims(C.Structure):
                 ("vs_feat", C.c_int64), ("cov_elems", C.c_int32), ("feat_mode", C.c_int32),
                 ("feat_sh_degree", C.c_int32), ("feat_sh_coeffs", C.c_int32),
                 ("color_sh_channel_major", C.c_int32), ("views_per_group", C.c_int32),
-                ("color_sh_convention", C.c_int32), ("forward_flags", C.c_int32)]
+                ("color_sh_convention", C.c_int32), ("forward_flags", C.c_int32), ("seg_cap_hint", C.c_int32)]
 
 
 class Inputs(C.Structure):

@@ -10,6 +10,7 @@ using namespace lsr;
 
 #include <sched.h>
 
+#include <algorithm>
 #include <chrono>
 #include <mutex>
 #include <vector>
@@ -86,9 +87,10 @@ bool lsr::projection_contraction() {
 // A pure function of the dims and two knobs, so that every stage of a call (and lsr_geom_workspace_bytes before it) agrees.
 //   * byte tile coordinates and at most 1024 tiles per view: the projection kernel's LDS tile histogram (4 views per
 //     workgroup) and its 12-byte binning records;
-//   * as many keys as fit LSR_SEG_BUDGET_MB (default 512 MB of address space at the end of the geometry workspace — the
-//     segments are written sparsely: only P * 8 bytes of them are ever touched), at most 8192 (the second sort tier) and
-//     never more than the scene has Gaussians (a tile list cannot be longer).
+//   * the caller's hint (lsr_dims::seg_cap_hint: the longest list it expects, e.g. from an earlier call of the shape) rounded
+//     up to 64 keys, else 8192 (the second sort tier); halved while the segments exceed LSR_SEG_BUDGET_MB (default 512 MB of
+//     REAL device memory at the end of the geometry workspace, P * 8 bytes of it ever written) or V * T * capacity reaches
+//     2^32 (the kernels index the segments with 32 bits); never more than the scene has Gaussians (a list cannot be longer).
 uint32_t lsr::segment_capacity(const lsr_dims &d) {
     if (!env_int("LSR_SEGMENTS", 1) || d.num_gaussians <= 0) return 0u;
     const int64_t T = num_tiles(d);
@@ -97,8 +99,9 @@ uint32_t lsr::segment_capacity(const lsr_dims &d) {
     const int64_t VT = (int64_t)d.num_views * T;
     const int64_t budget = (int64_t)env_int("LSR_SEG_BUDGET_MB", 512) << 20;
     int64_t cap = 8192;
-    while (cap > 1024 && VT * cap * 8 > budget) cap >>= 1;
-    if (VT * cap * 8 > budget) return 0u;
+    if (d.seg_cap_hint > 0) cap = std::min<int64_t>(8192, std::max<int64_t>(256, ((int64_t)d.seg_cap_hint + 63) / 64 * 64));
+    while (cap > 1024 && (VT * cap * 8 > budget || VT * cap >= ((int64_t)1 << 32))) cap = (cap / 2 + 63) / 64 * 64;
+    if (VT * cap * 8 > budget || VT * cap >= ((int64_t)1 << 32)) return 0u;
     const int64_t g64 = ((int64_t)d.num_gaussians + 63) / 64 * 64;
     if (g64 < cap) cap = g64;
     // LSR_SEG_CAP (tests): a smaller capacity than the policy's, to exercise the overflow path on small scenes
@@ -193,6 +196,7 @@ static int check_dims(const lsr_dims *d) {
     if (d->color_sh_convention != LSR_SH_AXES_3DGS && d->color_sh_convention != LSR_SH_AXES_REFERENCE) return LSR_EINVAL;
     if (d->views_per_group < 0) return LSR_EINVAL;
     if (d->forward_flags & ~(LSR_FWD_FOR_BACKWARD | LSR_FWD_CLEARS_GRAD)) return LSR_EINVAL;
+    if (d->seg_cap_hint < 0) return LSR_EINVAL;
     if (d->views_per_group > 1) {   // view groups: all inputs strided per group
         if (d->num_views % d->views_per_group != 0) return LSR_EINVAL;
         if (d->vs_means == 0 || d->vs_cov == 0 || d->vs_opac == 0) return LSR_EUNSUPPORTED;

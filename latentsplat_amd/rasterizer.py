@@ -141,8 +141,29 @@ def get_color_sh_convention() -> str:
 _SPECULATE = __import__("os").environ.get("LSR_SPECULATIVE", "1") != "0"
 # LSR_CLEAR_IN_FORWARD=0: lsr_backward clears its gradient workspace itself (the pre-v9 behaviour)
 _FWD_CLEARS_GRAD = __import__("os").environ.get("LSR_CLEAR_IN_FORWARD", "1") != "0"
-_ESTIMATES: dict = {}      # shape key -> [pairs, longest tile list] (decaying maxima of the recent calls)
+# shape key -> (pairs, longest tile list): decaying maxima of the recent calls of the shape.  Bounded (the 64 most recently
+# used shapes: G changes from step to step under densification) and guarded (forwards may run on several host threads).
+_ESTIMATES: "__import__('collections').OrderedDict" = __import__("collections").OrderedDict()
+_ESTIMATES_LOCK = __import__("threading").Lock()
+_ESTIMATES_MAX = 64
 SPECULATION_STATS = dict(speculative=0, reruns=0, exact=0)
+
+
+def _estimate_get(key):
+    with _ESTIMATES_LOCK:
+        est = _ESTIMATES.get(key)
+        if est is not None:
+            _ESTIMATES.move_to_end(key)
+        return est
+
+
+def _estimate_update(key, pairs: int, longest: int) -> None:
+    with _ESTIMATES_LOCK:
+        old = _ESTIMATES.get(key, (0, 0))
+        _ESTIMATES[key] = (max(pairs, int(0.95 * old[0])), max(longest, int(0.95 * old[1])))
+        _ESTIMATES.move_to_end(key)
+        while len(_ESTIMATES) > _ESTIMATES_MAX:
+            _ESTIMATES.popitem(last=False)
 
 
 def _tier_hint(longest: float) -> int:
@@ -222,6 +243,10 @@ class _RasterizeViews(torch.autograd.Function):
         if vpg > 1 and len(slices) != sum(t is not None for t in (means3D, cov3D, opacities, color, features)):
             raise LsrError("with per-scene inputs (leading dim < number of views) every per-Gaussian input must "
                            "carry the scene dimension")
+        # what earlier calls of this shape needed (speculative workspace sizes; the capacity of the key segments: real
+        # device memory, lsr_dims.seg_cap_hint — 1.3 x the longest recent tile list instead of the default 8192 keys)
+        shape_key = (dev.index, V, G, H, W, Cf, color_mode, K, Kf, vpg, cov_elems, strides)
+        est = _estimate_get(shape_key) if (_SPECULATE and G > 0) else None
         d = Dims(V, G, H, W, Cf, color_mode, int(sh_degree), K, *strides,
                  cov_elems, _lib.FEAT_SH if feat_sh else _lib.FEAT_DIRECT, max(int(feat_sh_degree), 0), Kf,
                  1 if (shs is not None and shs_channel_major) else 0, vpg if vpg > 1 else 0,
@@ -229,7 +254,8 @@ class _RasterizeViews(torch.autograd.Function):
                  # a backward will follow: the forward narrows the render lists to where every entry contributed and
                  # zeroes the backward's gradient workspace on the side (ABI v9: lsr_backward then skips its clear)
                  # (grad_mode: torch.is_grad_enabled() of the CALLER — inside Function.forward it is always off)
-                 (_lib.FWD_FOR_BACKWARD | (_lib.FWD_CLEARS_GRAD if _FWD_CLEARS_GRAD else 0)) if (grad_mode and any(ctx.needs_input_grad) and G > 0) else 0)
+                 (_lib.FWD_FOR_BACKWARD | (_lib.FWD_CLEARS_GRAD if _FWD_CLEARS_GRAD else 0)) if (grad_mode and any(ctx.needs_input_grad) and G > 0) else 0,
+                 min(int(1.3 * est[1]) + 64, 2 ** 31 - 1) if (est is not None and est[1] > 0) else 0)
         inp = Inputs(_ptr(views), _ptr(means3D), _ptr(cov3D), _ptr(opacities), _ptr(color), _ptr(features))
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         u8 = dict(dtype=torch.uint8, device=dev)
@@ -262,11 +288,10 @@ class _RasterizeViews(torch.autograd.Function):
                                                   npairs.value, maxtile.value, C.byref(outs), stream),
                            "lsr_forward_nosync")
             else:
-                shape_key = (dev.index, V, G, H, W, Cf, color_mode, K, Kf, vpg, cov_elems, strides)
-                est = _ESTIMATES.get(shape_key) if (_SPECULATE and not debug and G > 0) else None
                 done = False
-                if est is not None and est[0] > 0:
-                    cap, hint = int(1.25 * est[0]) + 4096, _tier_hint(est[1])
+                cap, hint = (int(1.25 * est[0]) + 4096, _tier_hint(est[1])) if est is not None else (0, 0)
+                # (a capacity the 32-bit offsets of the speculative / no-sync forward cannot address: the exact path)
+                if est is not None and est[0] > 0 and not debug and cap < 2 ** 32:
                     binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), cap, hint), **u8)
                     ov = C.c_int32(0)
                     _lib.check(lib.lsr_forward_speculative(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img), cap, hint,
@@ -293,8 +318,7 @@ class _RasterizeViews(torch.autograd.Function):
                         lib.lsr_forward_abandon(stream)
                         raise
                 if _SPECULATE:
-                    old = _ESTIMATES.get(shape_key, (0, 0))
-                    _ESTIMATES[shape_key] = (max(npairs.value, int(0.95 * old[0])), max(maxtile.value, int(0.95 * old[1])))
+                    _estimate_update(shape_key, npairs.value, maxtile.value)
             if debug:
                 torch.cuda.synchronize(dev)
                 if pair_capacity <= 0:

@@ -66,6 +66,12 @@ def test_key_segments_in_the_geometry_workspace():
     huge = _dims(num_gaussians=1000, height=2048, width=2048)
     per_tile = (lib.lsr_geom_workspace_bytes(C.byref(huge)) - g_small) / (2 * (128 * 128 - 16))
     assert per_tile < 1024 * 8 / 4                        # far less than a segment per tile
+    # round 6 (ABI v9): the caller's hint (the longest tile list it expects) sizes the segments: real device memory
+    hinted = _dims(num_gaussians=100_000, seg_cap_hint=3000)
+    g_hint = lib.lsr_geom_workspace_bytes(C.byref(hinted))
+    assert g_big - g_hint == tiles * (8192 - 3008) * 8    # 3000 rounded up to 64 keys
+    assert lib.lsr_geom_workspace_bytes(C.byref(_dims(num_gaussians=100_000, seg_cap_hint=10))) == g_big - tiles * (8192 - 256) * 8
+    assert lib.lsr_geom_workspace_bytes(C.byref(_dims(num_gaussians=100_000, seg_cap_hint=10 ** 6))) == g_big
 
 
 def test_speculative_sort_tier_hint():
@@ -79,6 +85,7 @@ def test_speculative_sort_tier_hint():
     dict(color_mode=1, sh_degree=5, sh_coeffs=36), dict(color_mode=1, sh_degree=2, sh_coeffs=4),
     dict(vs_means=7), dict(vs_feat=5), dict(cov_elems=7), dict(feat_mode=2),
     dict(feat_mode=1, feat_sh_degree=1, feat_sh_coeffs=3), dict(color_sh_convention=2),
+    dict(forward_flags=4), dict(seg_cap_hint=-1),
 ])
 def test_invalid_dims_are_rejected(bad):
     lib = _lib.load()

@@ -103,7 +103,7 @@ def test_cfg3_decoder_forward_backward_against_oracle(hip_device, cfg3_scene):
         util.assert_close_except_fragile(out.feature_posterior.mean[0, v].detach().cpu().numpy(), o["feature"], o, 1e-4, f"cfg3 latent mean[view {v}]")
         util.assert_close_except_fragile(out.mask[0, v].detach().cpu().numpy(), o["mask"], o, 1e-4, f"cfg3 mask[view {v}]")
         dscale = max(1.0, float(np.abs(o["depth"]).max()))
-        util.assert_close_except_fragile(out.depth[0, v].detach().cpu().numpy(), o["depth"], o, 1e-4 * dscale, f"cfg3 depth[view {v}]")
+        util.assert_close_except_fragile(out.depth[0, v].detach().cpu().numpy(), o["depth"], o, 1e-4 * dscale, f"cfg3 depth[view {v}] (tol 1e-4 of the largest depth)", scale=dscale)
         b = util.orc.backward(view, n(m), n(c6), n(op), n(sh), None, n(ft), o, g_color[v].numpy(), g_feat[v].numpy())
         torch.autograd.backward([m, c6, op, ft, sh], [torch.from_numpy(np.ascontiguousarray(b[k]))
                                                        for k in ("means3D", "cov3D", "opacities", "features", "shs")])
@@ -183,3 +183,71 @@ def test_cfg4_view_groups_full_size(hip_device):
         assert torch.equal(a.feature_posterior.mean, out.feature_posterior.mean.detach())
         lin = 2.0 * a.feature_posterior.mean - 3.0 * b.feature_posterior.mean + (1.0 - 2.0 + 3.0) * 0.5 * a.mask[:, :, None]
         assert float((ab.feature_posterior.mean - lin).abs().max()) < 3e-4
+
+
+def test_encoder_shaped_scenes_full_size(hip_device):
+    """Round 6: the Gaussian distribution the reference's encoder really emits (latentsplat_amd.synthetic.make_encoder_scene:
+    pixel-aligned, three per ray of two context views, in ray order: /root/reference/src/model/encoder/encoder_epipolar.py:184-236,
+    common/gaussian_adapter.py:75-114) at configs[4]'s per-GPU batch — 4 scenes x 4 views as view groups of one decoder call, the
+    workload `bench.py`'s `decoder_step.cfg{3,4}_encoder_shaped` legs time.  One view of EVERY scene against the oracle
+    (images at the 1e-4 bar, sorted tile lists of one view bit for bit through the C ABI), the per-scene call bit for bit,
+    and the gradients of the scene-level inputs of one scene against the oracle's for one upstream-gradient view."""
+    from latentsplat_amd.synthetic import make_encoder_scene
+    dev = hip_device
+    scenes = [make_encoder_scene(seed=700 + s) for s in range(4)]
+    d = _decoder(dev)
+    gauss, rest = _decoder_args(scenes, dev, requires_grad=True)
+    out = d.forward(gauss, *rest)
+    assert out.color.shape == (4, 4, 3, SIZE, SIZE)
+    # gradients: upstream gradient on ONE view of scene 1 only, so that the oracle's backward of that view is the whole answer
+    gen = torch.Generator().manual_seed(29)
+    g_color = torch.zeros((4, 4, 3, SIZE, SIZE))
+    g_feat = torch.zeros((4, 4, 4, SIZE, SIZE))
+    S, V = 1, 2
+    g_color[S, V] = torch.randn((3, SIZE, SIZE), generator=gen)
+    g_feat[S, V] = torch.randn((4, SIZE, SIZE), generator=gen)
+    torch.autograd.backward([out.color, out.feature_posterior.mean], [g_color.to(dev), g_feat.to(dev)])
+    for s, v in ((0, 3), (1, 2), (2, 1), (3, 0)):
+        o = _oracle_forward_device_cameras(scenes[s], dev, (0.0, 0.0, 0.0), v)
+        col, lat = out.color[s, v].detach().cpu().numpy(), out.feature_posterior.mean[s, v].detach().cpu().numpy()
+        util.assert_close_except_fragile(col, o["color"], o, 1e-4, f"encoder-shaped colour[scene {s} view {v}]")
+        util.assert_close_except_fragile(lat, o["feature"], o, 1e-4, f"encoder-shaped latent mean[scene {s} view {v}]")
+        util.assert_close_except_fragile(out.mask[s, v].detach().cpu().numpy(), o["mask"], o, 1e-4, f"encoder-shaped mask[scene {s} view {v}]")
+        if s == S:
+            # chain the oracle's backward of this view through the host statement of the fused pre-pass (as the configs[3] test)
+            sc = scenes[s]
+            from latentsplat_amd.rasterizer import build_view_table
+            views_cpu = build_view_table(sc.extrinsics.to(dev), sc.intrinsics.to(dev), sc.near.to(dev), sc.far.to(dev),
+                                         torch.zeros(3, device=dev), True).cpu()
+            leaves = [t.clone().requires_grad_(True) for t in (sc.means, sc.covariances, sc.opacities[:, None], sc.color_sh, sc.feature_sh)]
+            m, c6, op, sh, _, ft = util.to_boundary(views_cpu, v, leaves[0], leaves[1], leaves[2], leaves[3], None, None, leaves[4], True)
+            vw = views_cpu[v]
+            view = util.orc.View(SIZE, SIZE, float(vw[35]), float(vw[36]), vw[37:40].numpy(), vw[0:16].numpy().reshape(4, 4),
+                                 vw[16:32].numpy().reshape(4, 4), vw[32:35].numpy(), 4)
+            n = lambda t: None if t is None else t.detach().contiguous().numpy()
+            b = util.orc.backward(view, n(m), n(c6), n(op), n(sh), None, n(ft), o, g_color[s, v].numpy(), g_feat[s, v].numpy(), None, None)
+            torch.autograd.backward([m, c6, op, sh, ft],
+                                    [torch.from_numpy(np.ascontiguousarray(b[k])).reshape(t.shape).float()
+                                     for k, t in (("means3D", m), ("cov3D", c6), ("opacities", op), ("shs", sh), ("features", ft))])
+            direct, behind = util.fragile_gaussians(o, SIZE)
+            for name, leaf, got in (("means", leaves[0], gauss.means.grad[s]), ("covariances", leaves[1], gauss.covariances.grad[s]),
+                                    ("opacities", leaves[2], gauss.opacities.grad[s][:, None]),
+                                    ("color_harmonics", leaves[3], gauss.color_harmonics.grad[s]),
+                                    ("feature_harmonics", leaves[4], gauss.feature_harmonics.grad[s])):
+                util.assert_grad_close_except_fragile(got.detach().cpu().numpy(), leaf.grad.numpy(), direct, behind, 1e-4,
+                                                      f"encoder-shaped dL/d{name}", clean_tol=5e-5)
+    # the per-scene call (configs[3] shape) of one scene: bit for bit the view-group call's images
+    g1, r1 = _decoder_args([scenes[2]], dev)
+    with torch.no_grad():
+        o1 = d.forward(g1, *r1)
+    assert torch.equal(o1.color[0], out.color[2]) and torch.equal(o1.mask[0], out.mask[2])
+    assert torch.equal(o1.feature_posterior.mean[0], out.feature_posterior.mean[2])
+    # sorted tile lists of one view of one scene, bit for bit through the C ABI
+    sc = scenes[0]
+    bi = util.boundary_inputs(sc, SIZE, SIZE)
+    run = util.HipRun(bi, dev, shared_means=True)
+    o = util.oracle_forward(bi, 1)
+    T = run.T
+    ts, pl = run.tile_start(), run.point_list()
+    np.testing.assert_array_equal(np.diff(ts[T:2 * T + 1]), o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0])
+    np.testing.assert_array_equal(pl[ts[T]:ts[2 * T]], o["point_list"])

@@ -54,7 +54,7 @@ def _check_forward(bi, run, views=None):
         # units of the deepest visible Gaussian, not of the blended image — tests/fuzz_parity.py found the difference in a
         # low-opacity scene)
         zmax = float(o["gdepth"][vis].max(initial=1.0))
-        util.assert_close_except_fragile(run.depth_out[v].cpu().numpy(), o["depth"], o, ABS_TOL * dscale, "depth", flip_bound=2e-2 * max(dscale, zmax))
+        util.assert_close_except_fragile(run.depth_out[v].cpu().numpy(), o["depth"], o, ABS_TOL * dscale, "depth (tol 1e-4 of the largest depth)", flip_bound=2e-2 * max(dscale, zmax), scale=dscale)
         # the per-pixel list prefix kept for the backward pass may differ only where exp rounding
         # flips a decision: every mismatching pixel must be one the oracle flagged as fragile
         mism = np.flatnonzero(ncontrib[v].reshape(-1) != o["n_considered"].astype(np.int64).reshape(-1))

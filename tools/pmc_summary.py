@@ -14,6 +14,16 @@ def short(name):
     return name[:60]
 
 
+def _kernel_source_hash():
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("render_forward.hip", "lsr_blend.h"):
+        with open(os.path.join(root, "latentsplat_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def write_traffic_json(root, acc, path, kernel="lsr::k_render_fwd<4"):
     """profiles/traffic_render_forward.json: HBM bytes per launch of the dominant kernel, read by
     bench.py for roofline.traffic."""
@@ -37,6 +47,8 @@ def write_traffic_json(root, acc, path, kernel="lsr::k_render_fwd<4"):
             "hbm_bytes_per_launch": (fetch + write) * 1024,
             "hbm_bytes_per_launch_guide_2x": (2 * fetch + write) * 1024,
             "source_commit": os.environ.get("LSR_PROFILE_COMMIT"),
+            # the build these counters belong to: bench.py reports the traffic only while the kernel source still hashes to this
+            "kernel_source_sha16": _kernel_source_hash(),
             "valu_insts_per_launch": c.get("SQ_INSTS_VALU"),
             "valu_trans_insts_per_launch": c.get("SQ_INSTS_VALU_TRANS_F32"),
             "valu_active_quad_cycles_per_launch": c.get("SQ_ACTIVE_INST_VALU"),
