@@ -120,7 +120,11 @@ typedef struct lsr_dims {
                                forward compositing kernel then records on which 4x4-pixel sub-blocks every list entry
                                actually contributed and narrows the render lists' sub-block bits to those (identical
                                images; the backward evaluates ~14 % fewer (entry, sub-block) pairs, the forward pays
-                               one LDS atomic per loop iteration).  Ignored by lsr_backward itself.
+                               one LDS atomic per loop iteration).  Ignored by lsr_backward itself.  Coverage: the 4- and
+                               8-channel half-tile instances (and, for the item flags of lsr_layout.geom_item_flags, the
+                               small-batch row / sub-block kernels); forwards of 9-32 payload channels and of scenes beyond
+                               2^24 Gaussians ignore the bit — identical results, the backward then evaluates the
+                               footprint-box masks and walks every item back to front.
                                (ABI v9) bit 1, LSR_FWD_CLEARS_GRAD: the forward zeroes the gradient workspace of the
                                lsr_backward that follows (lsr_outputs.grad_ws, sized by lsr_grad_workspace_bytes) — beside
                                its per-tile sort and compositing kernels, on a library-owned side stream forked from and
