@@ -23,7 +23,7 @@ namespace lsr {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct GeomLayout {
-    size_t header, rec, bin, tile_count, tile_start, tile_cursor, item_flags, bin_queue, tile_order, half_count, sh_clamp, seg_keys, total;
+    size_t header, rec, bin, tile_count, tile_start, tile_cursor, item_flags, bin_queue, item_cost, tile_order2, tile_order, half_count, sh_clamp, seg_keys, total;
     int rec_floats;
     uint32_t seg_cap;      // keys per (view, tile) segment of the single-pass binning; 0 = two-phase binning (k_scatter)
 };
@@ -42,6 +42,13 @@ struct BinLayout {
 // channels, 32 for <= 12, 64 beyond.
 // per-SIMD-bin queue heads of the compositing kernels (experiment knobs LSR_FWD_BINQ / LSR_BWD_BINQ): room for 4096 bins
 constexpr size_t kBinQueueBytes = 4096 * 4;
+// Work items are handed to the compositing waves costliest first.  The tile scan orders them by the tile's pair count (all it
+// has).  A forward that a backward follows knows better when it is done: the RECORD compositing kernel has counted the lock-step
+// iterations it spent on every item, and k_order_items (render_forward.hip, one workgroup behind it) re-orders the items by that
+// count, in kCostClasses classes of two iterations, for the compositing BACKWARD: 0.570 -> 0.535 ms at 16 views x 300 k for 5 us
+// of ordering (profiles/r06_ab_knobs.md section 6).
+constexpr int kCostClasses = 1024;
+constexpr uint32_t kMaxReorderItems = 16384;      // calls with more items keep the tile scan's order (many items per wave slot: balanced anyway)
 struct GradLayout {
     size_t rec, fixed, total;
     int rec_floats;
@@ -139,6 +146,8 @@ inline GeomLayout geom_layout(const lsr_dims &d) {
     L.bin_queue = o; o += kBinQueueBytes;          // (cleared with the rest of the range)
     L.tile_start = o; o = align_up(o + (VT + 1) * 4);
     L.tile_order = o; o = align_up(o + 2 * VT * 4);   // work items (see kItem*), costliest first
+    L.item_cost = o; o = align_up(o + 2 * VT * 4);    // per item (2 (view T + tile) + half): lock-step iterations the RECORD forward spent on it
+    L.tile_order2 = o; o = align_up(o + 2 * VT * 4);  // the work items again, ordered by that cost for the backward (header word kHdrOrder2Valid)
     L.half_count = o; o = align_up(o + 2 * VT * 4);   // entries of the two half-tile render lists of every (view, tile)
     L.sh_clamp = o; o = align_up(o + VG);             // per (view, Gaussian): colour channels clamped at 0 (sh.hip)
     L.seg_cap = segment_capacity(d);
@@ -231,7 +240,8 @@ inline int wave_slots(int cus) { return cus * 4 * 4; }   // (at 4 resident compo
 int env_int(const char *name, int fallback);        // api.hip: latched on first use
 // header words of the geometry workspace (kHdrQueueFwd: work-queue head of the forward compositing kernel)
 enum { kHdrPairs = 0, kHdrMaxTile = 1, kHdrNumItems = 3, kHdrOverflow = 4, kHdrPreDone = 5,
-       kHdrFlagsValid = 6 /* the forward compositing kernel of this call filled in GeomLayout::item_flags */, kHdrQueueFwd = 8,
+       kHdrFlagsValid = 6 /* the forward compositing kernel of this call filled in GeomLayout::item_flags */,
+       kHdrQueueFwd = 8, kHdrOrder2Valid = 9 /* GeomLayout::tile_order2 holds the work items ordered by true cost */,
        kHdrLongTiles = 16 /* + 0, + 1: number of tiles beyond the first sort tier / beyond the second */ };
 
 // ---- optional per-stage hipEvent timing (api.hip); no-ops unless lsr_profile_enable(1) ----

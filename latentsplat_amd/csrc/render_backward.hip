@@ -50,6 +50,7 @@ struct RenderBwdParams {
     int H, W, gx, T, G, C, has_color;
     int num_cus;                  // workgroups of 4*WPS waves (one per compute unit)
     const uint32_t *items;        // work items of the forward (view*T + tile | half << 28), costliest first
+    const uint32_t *items2;       // the same items ordered by their true cost (k_sort_tiles; valid when header[kHdrOrder2Valid])
     const uint32_t *header;       // geometry-workspace header (item count)
     uint32_t *queue;              // work-queue head (zeroed with the gradient workspace)
     uint32_t *bin_queue;          // per-SIMD-bin queue heads (LSR_BWD_BINQ=1, experiment), or nullptr: one global queue
@@ -191,6 +192,7 @@ k_render_bwd(RenderBwdParams p) {
     uint32_t prio_target = p.prio_pct ? (uint32_t)(((uint64_t)p.header[kHdrPairs] * (uint32_t)p.prio_pct) / (50ull * (uint64_t)max(p.header[kHdrNumItems], 1u))) : 0u;
     if (prio_target < 3u * LSR_WAVE) prio_target = 0u;
     const bool flags_valid = p.rev_mode == 2 && p.header[kHdrFlagsValid] != 0u;
+    const uint32_t *items = p.header[kHdrOrder2Valid] ? p.items2 : p.items;   // (uniform: a scalar load)
     bool first = true;
     for (;;) {
         uint32_t qi;
@@ -214,7 +216,7 @@ k_render_bwd(RenderBwdParams p) {
             if (qi >= num_items) break;
         }
         qi = __builtin_amdgcn_readfirstlane(qi);
-        const uint32_t item = p.items[qi >> parts_log2];
+        const uint32_t item = items[qi >> parts_log2];
         const uint32_t part = qi & ((1u << parts_log2) - 1u);
         const uint32_t vt = item & kItemTileMask, half = item >> kItemHalfShift;
         const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
@@ -595,6 +597,7 @@ hipError_t launch_render_backward(const lsr_dims &d, const lsr_inputs &in, const
     p.C = d.feat_channels; p.has_color = d.color_mode != LSR_COLOR_NONE;
     p.num_cus = device_cus();
     p.items = (const uint32_t *)(geom + L.tile_order);
+    p.items2 = (const uint32_t *)(geom + L.tile_order2);
     p.header = (const uint32_t *)(geom + L.header);
     p.views = in.views;
     p.geo = (const float4 *)(geom + L.rec); p.rec_f4 = L.rec_floats / 4;

@@ -88,6 +88,7 @@ struct RenderFwdParams {
     int rec_f4;
     const uint32_t *tile_start, *half_count, *half_list;
     uint32_t *half_list_rw;       // RECORD instances: the same lists, written back with the sub-block bits refined (below)
+    uint32_t *item_cost;          // RECORD instances: [2 V T] lock-step iterations spent on the item (for k_order_items), or nullptr
     uint32_t *item_flags;         // [2 V T] per half-tile item: kItemFlagSteep (lsr_internal.h), for the compositing backward; cleared per forward
     uint32_t *header_rw;          // kHdrFlagsValid: set by the instances that fill in item_flags
     IndexPacking ip;              // how the list entries carry the Gaussian index and the sub-block bits
@@ -273,6 +274,7 @@ k_render_fwd(RenderFwdParams p) {
         // RECORD: lanes that staged an entry of opacity >= kSteepOpacity — a pixel of this item may have blended an alpha near
         // the 0.99 clamp, and the backward then walks the item back to front (render_backward.hip); a scalar register pair
         uint64_t steep = 0ull;
+        uint32_t spent = 0u;      // RECORD: lock-step iterations of this item (its cost, for the backward's work order)
         for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
             if ((done0 & done1) == ~0ull) break;
 
@@ -307,6 +309,7 @@ k_render_fwd(RenderFwdParams p) {
                 }
             }
             nk = __builtin_amdgcn_readfirstlane(nk);
+            if (RECORD) spent += nk;
             wave_lds_fence();  // staged records and lists are visible to this wave's reads below
 
             // Lane group g walks the list of ITS sub-block, front to back; shorter lists are padded with the
@@ -422,6 +425,7 @@ k_render_fwd(RenderFwdParams p) {
         if (p.trace) t_loop = __builtin_readcyclecounter();
 #endif
         if (RECORD && lane == 0) {
+            if (p.item_cost) p.item_cost[2 * (size_t)vt + half] = spent;
             if (steep) p.item_flags[2 * (size_t)vt + half] = kItemFlagSteep;
             if (qi == 0u) p.header_rw[kHdrFlagsValid] = 1u;
         }
@@ -467,6 +471,49 @@ k_render_fwd(RenderFwdParams p) {
         }
 #endif
     }  // persistent item loop
+}
+
+// Work order of the compositing BACKWARD (round 6): one workgroup turns the costs the RECORD forward wrote (lock-step iterations
+// per item) into tile_order2 — the items costliest first, a counting sort over kCostClasses classes of two iterations in LDS —
+// and raises header[kHdrOrder2Valid].  The tile scan's order (by the tile's pair count, both halves adjacent) misjudges an
+// item by up to +-25 %; with the true cost the backward's longest-processing-time-first queue ends 6-8 % earlier.
+constexpr int kOrderThreads = 1024;
+__global__ void __launch_bounds__(kOrderThreads)
+k_order_items(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order2, uint32_t *header, uint32_t num_items) {
+    __shared__ uint32_t s_cnt[kCostClasses], s_wsum[kOrderThreads / LSR_WAVE];
+    const int tid = threadIdx.x, lane = tid & (LSR_WAVE - 1), wid = tid / LSR_WAVE;
+    static_assert(kCostClasses == kOrderThreads, "one class per thread in the scan");
+    s_cnt[tid] = 0u;
+    __syncthreads();
+    constexpr int kPer = kMaxReorderItems / kOrderThreads;
+    uint32_t cls[kPer], rnk[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)q * kOrderThreads;
+        cls[q] = 0u; rnk[q] = 0u;
+        if (i < num_items) {
+            cls[q] = kCostClasses - 1u - min((uint32_t)kCostClasses - 1u, cost[i] >> 1);     // class 0 = the costliest
+            rnk[q] = atomicAdd(&s_cnt[cls[q]], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t mine = s_cnt[tid];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < LSR_WAVE; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == LSR_WAVE - 1) s_wsum[wid] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (int w = 0; w < wid; ++w) run += s_wsum[w];
+    __syncthreads();
+    s_cnt[tid] = run;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)q * kOrderThreads;
+        if (i < num_items) order2[s_cnt[cls[q]] + rnk[q]] = (i >> 1) | ((i & 1u) << kItemHalfShift);
+    }
+    if (tid == 0) header[kHdrOrder2Valid] = 1u;
 }
 
 // ---- small view batches (round 4): one wave = one ROW of four sub-blocks (16 x 4 pixels), one pixel per lane ----
@@ -931,6 +978,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     p.half_count = (const uint32_t *)(geom + L.half_count);
     p.half_list = (const uint32_t *)(bin + B.half_list);
     p.half_list_rw = (uint32_t *)(const_cast<char *>(bin) + B.half_list);
+    p.item_cost = nullptr;
     p.item_flags = (uint32_t *)(const_cast<char *>(geom) + L.item_flags);
     p.header_rw = (uint32_t *)(const_cast<char *>(geom) + L.header);
     p.ip = index_packing(d);
@@ -1003,6 +1051,11 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
         const bool on = knob >= 0 ? knob != 0 : (nchp == 4 && num_pairs <= 3000 * (int64_t)d.num_views * p.T);
         if (on && 4 * p.num_cus <= (int)(kBinQueueBytes / 4)) p.bin_queue = (uint32_t *)(const_cast<char *>(geom) + L.bin_queue);
     }
+    // the backward's work order from the RECORD forward's own iteration counts (k_order_items), when an item is a sizeable
+    // part of a wave slot's work in the backward (more items than its 16 x CUs slots, at most kMaxReorderItems).  LSR_REORDER=0: off
+    const bool reorder = record && (nchp == 8 || (nchp == 4 && variant == 0)) && p.num_items > 16u * (uint32_t)p.num_cus &&
+                         p.num_items <= kMaxReorderItems && env_int("LSR_REORDER", 1) != 0;
+    if (reorder) p.item_cost = (uint32_t *)(const_cast<char *>(geom) + L.item_cost);
     if (record && nchp == 4 && variant == 0) LSR_RFR(4, 12, 24);
     else if (record && nchp == 8) LSR_RFR(8, 16, 16);
     else
@@ -1020,6 +1073,9 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     else LSR_RF(36, 4, 8);
 #undef LSR_RF
 #undef LSR_RFR
+    if (reorder)
+        hipLaunchKernelGGL(k_order_items, dim3(1), dim3(kOrderThreads), 0, s, (const uint32_t *)p.item_cost,
+                           (uint32_t *)(const_cast<char *>(geom) + L.tile_order2), p.header_rw, p.num_items);
     prof_end(kStRenderFwd, s);
 #ifdef LSR_ENABLE_TRACE
     if (trace_path) {  // debug only: dump per-item timing of this launch
