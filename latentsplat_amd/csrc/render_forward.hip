@@ -88,7 +88,7 @@ struct RenderFwdParams {
     int rec_f4;
     const uint32_t *tile_start, *half_count, *half_list;
     uint32_t *half_list_rw;       // RECORD instances: the same lists, written back with the sub-block bits refined (below)
-    uint32_t *item_cost;          // RECORD instances: [2 V T] lock-step iterations spent on the item (for k_order_items), or nullptr
+    uint32_t *item_cost;          // RECORD instances: [2 V T] lock-step iterations the backward will spend on the item (for k_order_items), or nullptr
     uint32_t *item_flags;         // [2 V T] per half-tile item: kItemFlagSteep (lsr_internal.h), for the compositing backward; cleared per forward
     uint32_t *header_rw;          // kHdrFlagsValid: set by the instances that fill in item_flags
     IndexPacking ip;              // how the list entries carry the Gaussian index and the sub-block bits
@@ -274,7 +274,7 @@ k_render_fwd(RenderFwdParams p) {
         // RECORD: lanes that staged an entry of opacity >= kSteepOpacity — a pixel of this item may have blended an alpha near
         // the 0.99 clamp, and the backward then walks the item back to front (render_backward.hip); a scalar register pair
         uint64_t steep = 0ull;
-        uint32_t spent = 0u;      // RECORD: lock-step iterations of this item (its cost, for the backward's work order)
+        uint32_t spent = 0u;      // RECORD: lock-step iterations the BACKWARD will spend on this item (its place in the backward's work order)
         for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
             if ((done0 & done1) == ~0ull) break;
 
@@ -309,7 +309,6 @@ k_render_fwd(RenderFwdParams p) {
                 }
             }
             nk = __builtin_amdgcn_readfirstlane(nk);
-            if (RECORD) spent += nk;
             wave_lds_fence();  // staged records and lists are visible to this wave's reads below
 
             // Lane group g walks the list of ITS sub-block, front to back; shorter lists are padded with the
@@ -412,9 +411,16 @@ k_render_fwd(RenderFwdParams p) {
             wave_lds_fence();  // WAR on the LDS slice before the next batch is staged
             if (RECORD) {
                 // the staged entry's sub-block bits <- the sub-blocks it contributed to (a subset of them)
+                uint32_t hits = 0u;
                 if (m) {
-                    const uint32_t hits = ((const uint32_t *)&s_ent[lane][1])[3] & 0xFFu;
+                    hits = ((const uint32_t *)&s_ent[lane][1])[3] & 0xFFu;
                     if (hits != m) p.half_list_rw[(hlist - p.half_list) + e] = (cur.w & kListIndexMask) | (hits << kListBitsShift);
+                }
+                if (p.item_cost) {     // the iterations the BACKWARD will spend on this batch: its longest narrowed sub-block list
+                    uint32_t longest = 0u;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) longest = max(longest, (uint32_t)__builtin_popcountll(__ballot((hits >> g) & 1u)));
+                    spent += longest;
                 }
                 wave_lds_fence();
             }

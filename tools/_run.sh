@@ -1,4 +1,10 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3
-cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r06f/stats -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-latency > /dev/null 2>&1; cd $GRAFT_REPO_ROOT
-python tools/rocpd_summary.py gpurun_out/r06f/stats/b_results.db "x" 2>/dev/null | grep -i "order\|render_fwd<4, 12, true\|clear16\|render_bwd<4" ; rm -rf gpurun_out/r06f/stats
+mkdir -p gpurun_out/r06f
+show() { python - "$1" <<'PY'
+import json,sys
+for l in open(sys.argv[1]):
+    r=json.loads(l)
+    print(r['round'], r['workload'], r['knobs'], 'fwd', r['fwd_ms'], 'fb', r['fwdbwd_ms'], 'k_bwd', r['kernels_fwdbwd'].get('render_backward'), 'k_fwd(rec)', r['kernels_fwdbwd'].get('render_forward'))
+PY
+}
+timeout 900 python tools/ab_knobs.py --rounds 3 --workloads raster16,cfg4 '{"LSR_REORDER":0}' > gpurun_out/r06f/ab.jsonl 2> gpurun_out/r06f/ab.err; show gpurun_out/r06f/ab.jsonl
