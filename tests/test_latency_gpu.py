@@ -107,6 +107,47 @@ def test_graph_capture_and_replay(hip_device):
     util.assert_close_except_fragile(out[0][0].cpu().numpy(), o["color"], o, 1e-4, "graph replay colour")
 
 
+def test_graph_capture_of_forward_and_backward(hip_device):
+    """Round 6: a training-mode no-sync forward forks the gradient-workspace clear onto the library's side stream (beside the
+    compositing kernel) and joins it back inside the call, and orders the backward's work items with one more small kernel:
+    a hipGraph capture of forward + backward records all of it and replays to the eager gradients (float-atomic order only)."""
+    from latentsplat_amd.rasterizer import last_forward_status
+    dev = hip_device
+    bi, views, t, size = _inputs(dev, G=8000, size=64)
+    g = torch.randn((2, 3, size, size), generator=torch.Generator().manual_seed(2)).to(dev)
+    with torch.no_grad():
+        _render(views, t, size, 2)
+    P = last_forward_status()["num_pairs"]
+    kw = dict(pair_capacity=2 * P, max_tile_hint=2048)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+
+    def step():
+        out = _render(views, leaf, size, 2, **kw)
+        ((out[0] * g).sum() + (out[1] ** 2).sum()).backward()
+
+    step()                                   # eager reference
+    ref = {k: v.grad.clone() for k, v in leaf.items()}
+    side = torch.cuda.Stream(dev)            # warm-up on a side stream, as torch.cuda.graph asks for
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for v in leaf.values():
+            v.grad = None
+        step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for v in leaf.values():
+        v.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize(dev)
+    for k, v in leaf.items():
+        scale = max(1.0, float(ref[k].abs().max()))
+        assert torch.isfinite(v.grad).all(), k
+        assert float((v.grad - ref[k]).abs().max()) <= 1e-5 * scale, k
+
+
 def test_deterministic_backward_mode(hip_device):
     """LSR_DETERMINISTIC=1 (read once per process, hence a subprocess): the cross-tile gradient sums use
     64-bit fixed-point atomics, so two runs give bitwise identical gradients, which agree with the
