@@ -120,8 +120,15 @@ def parity_gate(G, V, size, seed, dev):
             err = np.abs(got - want).reshape(got.shape[0], -1).max(0)
             worst = max(worst, float(err[~fragile].max()))
             over += int((err[~fragile] > 1e-4).sum())
+    # the timed path bins only the pairs that can reach a pixel (ABI v9 LSR_FWD_REACHED_ONLY, the autograd op's default): the same
+    # call with the bit set must give the images, final_T / n_contrib and half-tile list lengths of the published-list run above
+    from latentsplat_amd import _lib
+    red = util.HipRun(bi, dev, shared_means=True, forward_flags=_lib.FWD_REACHED_ONLY)
+    same = bool(torch.equal(red.feat_out, run.feat_out) and torch.equal(red.mask_out, run.mask_out) and torch.equal(red.depth_out, run.depth_out)
+                and np.array_equal(red.n_contrib(), run.n_contrib()) and np.array_equal(red.half_count(), run.half_count()) and red.P < run.P)
     return dict(lists_bit_exact=exact, max_abs_err=worst, pixels_over_tol=over, fragile_pixels_excluded=frag_px,
-                views_checked=checked, pairs_checked=pairs, tol=1e-4, ok=bool(exact and over == 0),
+                reached_only_bitwise_equal=same, pairs_published=int(run.P), pairs_binned=int(red.P),
+                views_checked=checked, pairs_checked=pairs, tol=1e-4, ok=bool(exact and over == 0 and same),
                 what=f"{V}-view call of the bench scene through the C ABI vs oracle/raster_oracle.c (outside the timed regions)")
 
 
@@ -732,10 +739,22 @@ def main():
                   kernel_ms_per_launch={k: (ms / n if n else None) for k, (ms, n) in prof_fb.items()})
 
     # ---- workload statistics for the byte model (outside the timed region) ----
+    # (P of the byte model is the PUBLISHED algorithm's pair count — SURVEY §8(d): the sum of the tile rectangles' areas — whatever
+    # the product path bins: since round 6 it drops the quarter of those pairs that cannot reach a pixel before they are
+    # counted (ABI v9 LSR_FWD_REACHED_ONLY); `pairs_binned` is what it really keyed and sorted)
+    from latentsplat_amd import rasterizer as _rz
+    from latentsplat_amd.rasterizer import LAST_STATS
     (color, feat, mask, depth, radii), _ = fwd(False)
     torch.cuda.synchronize(dev)
+    P_binned = int(LAST_STATS["num_pairs"])
+    reached = _rz._REACHED_ONLY
+    _rz.set_reached_only(False)
+    try:
+        (color, feat, mask, depth, radii), _ = fwd(False)
+        torch.cuda.synchronize(dev)
+    finally:
+        _rz.set_reached_only(reached)
     g_vis = int((radii > 0).sum().item())
-    from latentsplat_amd.rasterizer import LAST_STATS
     P = int(LAST_STATS["num_pairs"])  # sum of tile-rectangle areas over the step's V views
     C = 4
     b_in = 12 + 24 + 4 + 4 * C
@@ -821,7 +840,7 @@ def main():
         # of a step share ONE scene, so `frac_shared_scene` charges them once per step — the honest figure for this launch
         B_fwd_shared = G * b_in + g_vis * b_rec + P * 16 + P * b_rec + V * S * S * b_out
         path = dict(algorithmic_bytes_per_view=B_fwd_step / V, achieved=B_fwd_step / step_s / 1e9,
-                    frac=B_fwd_step / step_s / 1e9 / HBM_PEAK_GBS, pairs_per_view=P / V,
+                    frac=B_fwd_step / step_s / 1e9 / HBM_PEAK_GBS, pairs_per_view=P / V, pairs_binned_per_view=P_binned / V,
                     visible_fraction=g_vis / (V * G), frac_shared_scene=B_fwd_shared / step_s / 1e9 / HBM_PEAK_GBS,
                     algorithmic_bytes_per_view_shared_scene=B_fwd_shared / V)
         if fb is not None:
@@ -903,8 +922,8 @@ def main():
         line["fwdbwd"] = pick(fb, ("views_per_s", "ms_per_view", "ms_per_step"))
         line["roofline_bwd"] = pick(roofline_bwd, ("kernel", "achieved", "frac", "algorithmic_bytes_per_launch", "launch_ms"))
         # (not through r4: the error is ~1e-6 and would print as 0.0)
-        line["parity_gate"] = None if gate is None else {k: gate[k] for k in ("ok", "lists_bit_exact", "max_abs_err", "pixels_over_tol", "fragile_pixels_excluded", "views_checked", "tol")}
-        line["roofline_path"] = pick(path, ("algorithmic_bytes_per_view", "achieved", "frac", "frac_shared_scene", "pairs_per_view"))
+        line["parity_gate"] = None if gate is None else {k: gate[k] for k in ("ok", "lists_bit_exact", "reached_only_bitwise_equal", "max_abs_err", "pixels_over_tol", "fragile_pixels_excluded", "views_checked", "tol")}
+        line["roofline_path"] = pick(path, ("algorithmic_bytes_per_view", "achieved", "frac", "frac_shared_scene", "pairs_per_view", "pairs_binned_per_view"))
         line["roofline_path_fwdbwd"] = pick(path_fb, ("algorithmic_bytes_per_view", "achieved", "frac", "frac_shared_scene"))
         line["roofline_valu"] = pick(roofline_valu, ("valu_insts_per_launch", "frac"))
         line["kernel_ms"] = {k: r4(v) for k, v in full["kernel_ms_per_launch"].items() if v}

@@ -131,7 +131,20 @@ typedef struct lsr_dims {
                                joined back into `stream` with events inside the call (graph-capturable; 16 views x 300 k:
                                0.05 ms of the forward + backward step) — and lsr_backward, handed dims with the same bit,
                                skips its clear.  Set it for BOTH calls or
-                               neither.  Other bits must be 0 (LSR_EINVAL). */
+                               neither.
+                               (ABI v9) bit 2, LSR_FWD_REACHED_ONLY: the binning keeps only the (Gaussian, tile) pairs whose
+                               alpha >= 1/255 footprint box reaches the tile at all.  The published algorithm pairs a Gaussian
+                               with every tile of the 3-sigma square around it; a quarter of those pairs (bench scene; a third
+                               for the reference's encoder-shaped scenes) cannot touch a pixel, and the half-tile render lists
+                               the compositing kernels walk never held them.  With the bit set they are not counted, keyed or
+                               sorted either: images, n_contrib, the render lists and the gradients are the same bit for bit
+                               (tests/test_reached_only_gpu.py); what changes is what NO consumer of this path reads —
+                               num_pairs, tile_start and bin_point_list describe the reduced lists (the canonical list with
+                               the unreachable pairs removed, order kept) instead of the published ones.  0 keeps the
+                               published lists (the bit-exact index contract; the default of the C ABI); the autograd op sets
+                               it (LSR_REACHED_ONLY=0: not).  Ignored beyond 2^24 Gaussians (no footprint codes).  Hand the
+                               same value to every call of a forward and to its lsr_backward.
+                               Other bits must be 0 (LSR_EINVAL). */
     int32_t seg_cap_hint;   /* (ABI v9) 0, or the longest tile list (in (Gaussian, tile) pairs) the caller expects — e.g. the
                                `max_tile_pairs` of an earlier call of the same shape plus a margin.  Sizes the per-(view, tile)
                                key segments of the single-pass binning, which are REAL device memory at the end of geom_ws
@@ -142,6 +155,7 @@ typedef struct lsr_dims {
 } lsr_dims;
 #define LSR_FWD_FOR_BACKWARD 1
 #define LSR_FWD_CLEARS_GRAD 2
+#define LSR_FWD_REACHED_ONLY 4
 
 typedef struct lsr_inputs {
     const float *views;      /* [V][LSR_VIEW_FLOATS] */

@@ -20,6 +20,7 @@ FEAT_DIRECT, FEAT_SH = 0, 1
 SH_AXES_3DGS, SH_AXES_REFERENCE = 0, 1   # lsr_dims.color_sh_convention
 FWD_FOR_BACKWARD = 1                      # lsr_dims.forward_flags
 FWD_CLEARS_GRAD = 2
+FWD_REACHED_ONLY = 4
 MAX_SH_GROUP_FLOATS = 120   # C*Kf the fused latent-SH path supports (LDS budget of sh.hip)
 MAX_FEAT_CHANNELS = 32
 

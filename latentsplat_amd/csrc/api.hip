@@ -195,7 +195,7 @@ static int check_dims(const lsr_dims *d) {
     if (d->feat_channels > 0 && d->vs_feat != 0 && d->vs_feat != feat_elems * G) return LSR_EINVAL;
     if (d->color_sh_convention != LSR_SH_AXES_3DGS && d->color_sh_convention != LSR_SH_AXES_REFERENCE) return LSR_EINVAL;
     if (d->views_per_group < 0) return LSR_EINVAL;
-    if (d->forward_flags & ~(LSR_FWD_FOR_BACKWARD | LSR_FWD_CLEARS_GRAD)) return LSR_EINVAL;
+    if (d->forward_flags & ~(LSR_FWD_FOR_BACKWARD | LSR_FWD_CLEARS_GRAD | LSR_FWD_REACHED_ONLY)) return LSR_EINVAL;
     if (d->seg_cap_hint < 0) return LSR_EINVAL;
     if (d->views_per_group > 1) {   // view groups: all inputs strided per group
         if (d->num_views % d->views_per_group != 0) return LSR_EINVAL;

@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(kScatThreads, NARROW ? 8 : 6)   // (the wide-c
 k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
           const uint32_t *__restrict__ tile_start, uint32_t *__restrict__ tile_cursor,
           uint64_t *__restrict__ keys, uint32_t capacity, uint32_t chunks, int items, uint32_t key_shift, unsigned long long *trace,
-          const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ header, uint32_t over_cap) {
+          const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ header, uint32_t over_cap, int skip_none) {
+    // (skip_none: LSR_FWD_REACHED_ONLY — pairs whose footprint box misses the tile were not counted by the projection kernel)
     if (over_cap && header[kHdrMaxTile] <= over_cap) return;   // (uniform) no overfull tile in this call
 #ifdef LSR_ENABLE_TRACE
 #define LSR_STAMP(k) do { if (trace && threadIdx.x == 0) trace[8 * (size_t)blockIdx.x + (k)] = wall_clock64(); } while (0)
@@ -118,6 +119,7 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
             for (int y = y0; y < y1; ++y)
                 for (int x = x0; x < x1; ++x) {
                     if (over_cap && tcv[y * gx + x] <= over_cap) continue;
+                    if (skip_none && span_code(span[it], x - x0, y - y0) == kCodeNone) continue;
                     atomicAdd(&s_cnt[y * gx + x], 1u);
                 }
         }
@@ -146,10 +148,11 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
             for (int x = x0; x < x1; ++x) {
                 const int t = y * gx + x;
                 if (over_cap && tcv[t] <= over_cap) continue;
+                const uint32_t code = key_shift ? span_code(sp, x - x0, y - y0) : 0u;   // (no room for a code beside a 32-bit index)
+                if (skip_none && code == kCodeNone) continue;
                 uint32_t pos;
                 if (LDS_RESERVE) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
                 else pos = ts[t] + atomicAdd(&cur[t], 1u);
-                const uint32_t code = key_shift ? span_code(sp, x - x0, y - y0) : 0u;   // (no room for a code beside a 32-bit index)
                 // The position is CLAMPED to the workspace (one v_min; a store under a per-lane bounds test cost 17 % of
                 // this kernel): in the no-sync forward tile_scan clamps the offsets to the capacity, in the synchronous one
                 // the capacity is the host's early pair count — if that ever came out short, the surplus pairs land
@@ -658,7 +661,7 @@ hipError_t launch_binning(const lsr_dims &d, char *geom, char *bin, int64_t num_
 #define LSR_SCAT2(LDSR, NRW, SHM)                                                                         \
     hipLaunchKernelGGL((k_scatter<LDSR, NRW>), grid, dim3(kScatThreads), SHM, s, d.num_gaussians, gx, T, \
                        (const char *)(geom + L.bin), ts, (uint32_t *)(geom + L.tile_cursor), keys, capacity, chunks, items, index_packing(d).key_shift, strace, \
-                       (const uint32_t *)(geom + L.tile_count), (const uint32_t *)(geom + L.header), over_cap)
+                       (const uint32_t *)(geom + L.tile_count), (const uint32_t *)(geom + L.header), over_cap, reached_only(d) ? 1 : 0)
 #define LSR_SCAT(LDSR, SHM) do { if (narrow_bins(d)) LSR_SCAT2(LDSR, true, SHM); else LSR_SCAT2(LDSR, false, SHM); } while (0)
         if (lds) LSR_SCAT(true, (size_t)T * 8);
         else LSR_SCAT(false, 0);

@@ -228,6 +228,8 @@ struct IndexPacking {
     uint32_t index_mask;     // list entry & index_mask = Gaussian index
     uint32_t all_bits;       // OR-ed onto a list entry's 8 sub-block bits (0xFF when the entries carry none)
 };
+// LSR_FWD_REACHED_ONLY: the binning drops the pairs whose footprint code is kCodeNone (needs the codes: up to 2^24 Gaussians)
+__host__ __device__ inline bool reached_only(const lsr_dims &d) { return (d.forward_flags & LSR_FWD_REACHED_ONLY) != 0 && d.num_gaussians <= (1 << 24); }
 inline IndexPacking index_packing(const lsr_dims &d) {
     return d.num_gaussians > kMaxGaussians ? IndexPacking{0u, 0xFFFFFFFFu, 0xFFu} : IndexPacking{(uint32_t)kKeyIndexShift, kListIndexMask, 0u};
 }

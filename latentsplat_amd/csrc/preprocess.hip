@@ -70,6 +70,7 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
     const float *opac = in.opacities + sl * d.vs_opac;
     constexpr int coff = COLOR_MODE == LSR_COLOR_NONE ? 0 : 3;
     const bool direct_feat = d.feat_mode == LSR_FEAT_DIRECT;
+    const bool skip_none = reached_only(d);
 
     // kItems Gaussians per thread (at most kPreItems / VB: 2048 (Gaussian, view) items per block and histogram flush;
     // fewer when the call is small, so that a single view still fills the machine: launch_preprocess)
@@ -141,6 +142,8 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
 
             const float4 rr0 = make_float4(px, py, conic_a, conic_b);
             const float4 rr1 = make_float4(conic_c, opacity, ok ? tz : 0.0f, 0.0f);   // view z 0 marks a culled record
+            // footprint span for the half-tile render lists (k_scatter / k_sort_tiles); not part of the bit-exact contract
+            const uint32_t span = ok ? footprint_cells(px, py, conic_a, conic_b, conic_c, opacity, rminx, rminy) : kSpanNone;
             if (ok) {
                 if (!staged) {
                     float4 *R = (float4 *)(rec + o * (size_t)RF);
@@ -151,13 +154,13 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
                 // estimate — quadrants reached per entry — was measured to schedule no better)
                 for (int y = rminy; y < rmaxy; ++y)
                     for (int x = rminx; x < rmaxx; ++x) {
+                        // (LSR_FWD_REACHED_ONLY: a pair whose footprint box misses the tile is not a pair)
+                        if (skip_none && span_code(span, x - rminx, y - rminy) == kCodeNone) continue;
                         if (LDS_HIST) atomicAdd(&hist[y * gx + x], 1u);
                         else atomicAdd(&tc[y * gx + x], 1u);
                     }
             }
             if (in_range) {
-                // footprint span for the half-tile render lists (k_scatter / k_sort_tiles); not part of the bit-exact contract
-                const uint32_t span = ok ? footprint_cells(px, py, conic_a, conic_b, conic_c, opacity, rminx, rminy) : kSpanNone;
                 radii[o] = ok ? (int32_t)my_radius : 0;
                 const float out_depth = ok ? tz : 0.0f;
                 if (narrow) {
@@ -282,8 +285,9 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
                 for (int y = y0; y < y1; ++y)
                     for (int x = x0; x < x1; ++x) {
                         const int t = y * gx + x;
-                        const uint32_t slot = atomicAdd(&cur[t], 1u);
                         const uint32_t code = seg.key_shift ? span_code(sp, x - x0, y - y0) : 0u;
+                        if (skip_none && code == kCodeNone) continue;      // (not counted in pass 1 either)
+                        const uint32_t slot = atomicAdd(&cur[t], 1u);
                         // position in the tile's segment, CLAMPED (not tested): the surplus keys of an overfull segment land
                         // on its last slot; such a tile is binned again by the fallback scatter
                         const uint32_t pos = (seg0 + (uint32_t)t) * cap + min(slot + s_delta[t], cap - 1u);

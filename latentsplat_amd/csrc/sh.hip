@@ -302,6 +302,7 @@ k_preprocess_sh(ShParams pk, PreShArgs a) {
     const bool cax = d.color_sh_convention == LSR_SH_AXES_REFERENCE;
     const int ce = d.cov_elems;
     const int RF = p.RF;
+    const bool skip_none = reached_only(d);
     const size_t slot0 = (size_t)blockIdx.y * pk.gs.slots;             // first (view, Gaussian) slot of this group
     const int view0 = blockIdx.y * (pk.gs.slots ? V : 0);               // first view of this group in the call
     int32_t *radii = a.radii + slot0;
@@ -350,13 +351,16 @@ k_preprocess_sh(ShParams pk, PreShArgs a) {
                                                        r3 * scale2, r4 * scale2, r5 * scale2, d.width, d.height, gx, gy, active);
             const bool ok = pj.ok;
             const size_t o = (size_t)v * G + ii;
+            const uint32_t span = ok ? footprint_cells(pj.px, pj.py, pj.conic_a, pj.conic_b, pj.conic_c, opacity, pj.rminx, pj.rminy) : kSpanNone;
             if (ok) {
                 uint32_t *hist = a.lds_hist ? s_hist + v * T : tile_count + (size_t)v * T;
                 for (int y = pj.rminy; y < pj.rmaxy; ++y)
-                    for (int x = pj.rminx; x < pj.rmaxx; ++x) atomicAdd(&hist[y * gx + x], 1u);
+                    for (int x = pj.rminx; x < pj.rmaxx; ++x) {
+                        if (skip_none && span_code(span, x - pj.rminx, y - pj.rminy) == kCodeNone) continue;   // LSR_FWD_REACHED_ONLY
+                        atomicAdd(&hist[y * gx + x], 1u);
+                    }
             }
             if (active) {
-                const uint32_t span = ok ? footprint_cells(pj.px, pj.py, pj.conic_a, pj.conic_b, pj.conic_c, opacity, pj.rminx, pj.rminy) : kSpanNone;
                 radii[o] = ok ? (int32_t)pj.radius : 0;
                 const float out_depth = ok ? pj.tz : 0.0f;
                 if (a.narrow) {
@@ -491,8 +495,9 @@ k_preprocess_sh(ShParams pk, PreShArgs a) {
                 for (int y = y0; y < y1; ++y)
                     for (int x = x0; x < x1; ++x) {
                         const int t = y * gx + x;
-                        const uint32_t slot = atomicAdd(&cur[t], 1u);
                         const uint32_t code = a.seg.key_shift ? span_code(sp, x - x0, y - y0) : 0u;
+                        if (skip_none && code == kCodeNone) continue;
+                        const uint32_t slot = atomicAdd(&cur[t], 1u);
                         const uint32_t pos = (seg0 + (uint32_t)t) * cap + min(slot + s_delta[t], cap - 1u);
                         if (slot < buf) { s_key[slot] = key | code; s_pos[slot] = pos; }
                         else a.seg.keys[pos] = key | code;

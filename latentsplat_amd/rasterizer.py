@@ -139,6 +139,18 @@ def get_color_sh_convention() -> str:
 # that needs more than was provided is simply run again through the exact path (and raises the estimate).
 # LSR_SPECULATIVE=0 turns it off.
 _SPECULATE = __import__("os").environ.get("LSR_SPECULATIVE", "1") != "0"
+# LSR_REACHED_ONLY=0: the binning keeps the published algorithm's pairs (every tile of the 3-sigma square), so that
+# num_pairs / tile offsets / the canonical sorted list are the published ones; by default (ABI v9 LSR_FWD_REACHED_ONLY) only pairs
+# whose alpha >= 1/255 footprint reaches the tile are counted, keyed and sorted — identical images, render lists and gradients
+_REACHED_ONLY = __import__("os").environ.get("LSR_REACHED_ONLY", "1") != "0"
+
+
+def set_reached_only(on: bool) -> None:
+    """Whether subsequent forwards bin only the pairs that can reach a pixel (default) or the published algorithm's pairs."""
+    global _REACHED_ONLY
+    _REACHED_ONLY = bool(on)
+
+
 # LSR_CLEAR_IN_FORWARD=0: lsr_backward clears its gradient workspace itself (the pre-v9 behaviour)
 _FWD_CLEARS_GRAD = __import__("os").environ.get("LSR_CLEAR_IN_FORWARD", "1") != "0"
 # shape key -> (pairs, longest tile list): decaying maxima of the recent calls of the shape.  Bounded (the 64 most recently
@@ -245,7 +257,7 @@ class _RasterizeViews(torch.autograd.Function):
                            "carry the scene dimension")
         # what earlier calls of this shape needed (speculative workspace sizes; the capacity of the key segments: real
         # device memory, lsr_dims.seg_cap_hint — 1.3 x the longest recent tile list instead of the default 8192 keys)
-        shape_key = (dev.index, V, G, H, W, Cf, color_mode, K, Kf, vpg, cov_elems, strides)
+        shape_key = (dev.index, V, G, H, W, Cf, color_mode, K, Kf, vpg, cov_elems, strides, _REACHED_ONLY)
         est = _estimate_get(shape_key) if (_SPECULATE and G > 0) else None
         d = Dims(V, G, H, W, Cf, color_mode, int(sh_degree), K, *strides,
                  cov_elems, _lib.FEAT_SH if feat_sh else _lib.FEAT_DIRECT, max(int(feat_sh_degree), 0), Kf,
@@ -254,8 +266,11 @@ class _RasterizeViews(torch.autograd.Function):
                  # a backward will follow: the forward narrows the render lists to where every entry contributed and
                  # zeroes the backward's gradient workspace on the side (ABI v9: lsr_backward then skips its clear)
                  # (grad_mode: torch.is_grad_enabled() of the CALLER — inside Function.forward it is always off)
-                 (_lib.FWD_FOR_BACKWARD | (_lib.FWD_CLEARS_GRAD if _FWD_CLEARS_GRAD else 0)) if (grad_mode and any(ctx.needs_input_grad) and G > 0) else 0,
-                 min(int(1.3 * est[1]) + 64, 2 ** 31 - 1) if (est is not None and est[1] > 0) else 0)
+                 ((_lib.FWD_FOR_BACKWARD | (_lib.FWD_CLEARS_GRAD if _FWD_CLEARS_GRAD else 0)) if (grad_mode and any(ctx.needs_input_grad) and G > 0) else 0)
+                 | (_lib.FWD_REACHED_ONLY if _REACHED_ONLY else 0),
+                 # (never below the sort-tier hint of the speculative forward: a launch structure chosen for lists of up to `hint`
+                 # keys would otherwise include the fallback scatter for segments shorter than that)
+                 min(max(int(1.3 * est[1]) + 64, _tier_hint(est[1])), 2 ** 31 - 1) if (est is not None and est[1] > 0) else 0)
         inp = Inputs(_ptr(views), _ptr(means3D), _ptr(cov3D), _ptr(opacities), _ptr(color), _ptr(features))
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         u8 = dict(dtype=torch.uint8, device=dev)

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--gaussians", type=int, default=300_000, help="scene size of the raster16 workload")
     ap.add_argument("--opacity-scale", type=float, default=1.0 / 3.0, help="raster16: opacities U(0, scale) (1: pixels run out of transmittance)")
     ap.add_argument("--sigma", type=float, nargs=2, default=(0.3, 3.0), help="raster16: projected sigma range in pixels")
+    ap.add_argument("--encoder-shaped", action="store_true", help="cfg3 / cfg4: pixel-aligned scenes in ray order (synthetic.make_encoder_scene)")
     ap.add_argument("sets", nargs="*")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -87,9 +88,12 @@ def main():
         if name not in want:
             continue
         from latentsplat_amd import decoder as dec
-        from latentsplat_amd.synthetic import make_scene
-        scs = [make_scene(393_216, image_size=256, views=4, color_sh_degree=4, feature_channels=4, feature_sh_degree=2,
-                          seed=4321 + i).to(dev) for i in range(scenes)]
+        from latentsplat_amd.synthetic import make_encoder_scene, make_scene
+        if args.encoder_shaped:
+            scs = [make_encoder_scene(seed=4321 + i).to(dev) for i in range(scenes)]
+        else:
+            scs = [make_scene(393_216, image_size=256, views=4, color_sh_degree=4, feature_channels=4, feature_sh_degree=2,
+                              seed=4321 + i).to(dev) for i in range(scenes)]
         st = lambda n: torch.stack([getattr(sc, n) for sc in scs])
         leaf = lambda n: st(n).contiguous().requires_grad_(True)
         gauss = dec.Gaussians(leaf("means"), leaf("covariances"), leaf("opacities"), leaf("color_sh"), leaf("feature_sh"))
