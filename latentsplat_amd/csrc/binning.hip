@@ -116,10 +116,10 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
         for (int it = 0; it < kScatItems; ++it) {
             int x0, y0, x1, y1;
             unpack(it, x0, y0, x1, y1);
+            if (skip_none) reached_rect(span[it], x0, y0, x1, y1);
             for (int y = y0; y < y1; ++y)
                 for (int x = x0; x < x1; ++x) {
                     if (over_cap && tcv[y * gx + x] <= over_cap) continue;
-                    if (skip_none && span_code(span[it], x - x0, y - y0) == kCodeNone) continue;
                     atomicAdd(&s_cnt[y * gx + x], 1u);
                 }
         }
@@ -144,12 +144,13 @@ k_scatter(int G, int gx, int T, const char *__restrict__ binrec,
         // key = depth bits << 32 | index << 8 | sub-block code of THIS tile (lsr_internal.h)
         const uint64_t key = ((uint64_t)__float_as_uint(dep[it]) << 32) | (i << key_shift);
         const uint32_t sp = span[it];
-        for (int y = y0; y < y1; ++y)
-            for (int x = x0; x < x1; ++x) {
+        int ex0 = x0, ey0 = y0, ex1 = x1, ey1 = y1;
+        if (skip_none) reached_rect(sp, ex0, ey0, ex1, ey1);
+        for (int y = ey0; y < ey1; ++y)
+            for (int x = ex0; x < ex1; ++x) {
                 const int t = y * gx + x;
                 if (over_cap && tcv[t] <= over_cap) continue;
                 const uint32_t code = key_shift ? span_code(sp, x - x0, y - y0) : 0u;   // (no room for a code beside a 32-bit index)
-                if (skip_none && code == kCodeNone) continue;
                 uint32_t pos;
                 if (LDS_RESERVE) pos = s_base[t] + atomicAdd(&s_cnt[t], 1u);
                 else pos = ts[t] + atomicAdd(&cur[t], 1u);

@@ -78,6 +78,16 @@ __device__ __forceinline__ uint32_t span_code(uint32_t span, int dx, int dy) {
     const bool some = x0 <= x1 && c0 <= c1 && r0 <= r1;      // (c0 can exceed 3, c1 / r1 can be negative: all "none")
     return some ? (uint32_t)(c0 | (c1 << 2) | (r0 << 4) | (r1 << 6)) : kCodeNone;
 }
+// LSR_FWD_REACHED_ONLY: the tiles of the rectangle [x0, x1) x [y0, y1) the footprint span reaches form a sub-rectangle (the span is
+// an axis-aligned box of 4-pixel cells, four cells to a tile): tile offset dx is reached iff X0 >> 2 <= dx <= X1 >> 2 — exactly
+// the pairs whose span_code is not kCodeNone.  Shrinks the rectangle in place (empty when the span is kSpanNone).
+__device__ __forceinline__ void reached_rect(uint32_t span, int &x0, int &y0, int &x1, int &y1) {
+    const int sx0 = (int)(span & 0xFFu), sx1 = (int)((span >> 8) & 0xFFu), sy0 = (int)((span >> 16) & 0xFFu), sy1 = (int)(span >> 24);
+    const int nx1 = sx1 == 255 ? x1 : min(x1, x0 + (sx1 >> 2) + 1), ny1 = sy1 == 255 ? y1 : min(y1, y0 + (sy1 >> 2) + 1);
+    x0 += sx0 >> 2; y0 += sy0 >> 2;
+    x1 = sx0 <= sx1 ? nx1 : x0;       // (first cell beyond the last: a footprint between two pixel centres reaches nothing)
+    y1 = sy0 <= sy1 ? ny1 : y0;
+}
 // 16-bit mask of the tile's 4x4-pixel sub-blocks a code stands for; bit (4*row + col) <-> sub-block with origin (4*col, 4*row)
 __device__ __forceinline__ uint32_t code_mask(uint32_t code) {
     const uint32_t c0 = code & 3u, c1 = (code >> 2) & 3u, r0 = (code >> 4) & 3u, r1 = (code >> 6) & 3u;

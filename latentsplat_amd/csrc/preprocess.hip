@@ -152,10 +152,11 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
                 }
                 // per-tile pair counts (also the compositing kernels' scheduling key: a finer work
                 // estimate — quadrants reached per entry — was measured to schedule no better)
-                for (int y = rminy; y < rmaxy; ++y)
-                    for (int x = rminx; x < rmaxx; ++x) {
-                        // (LSR_FWD_REACHED_ONLY: a pair whose footprint box misses the tile is not a pair)
-                        if (skip_none && span_code(span, x - rminx, y - rminy) == kCodeNone) continue;
+                // (LSR_FWD_REACHED_ONLY: only the tiles of the rectangle the footprint box reaches are pairs)
+                int hx0 = rminx, hy0 = rminy, hx1 = rmaxx, hy1 = rmaxy;
+                if (skip_none) reached_rect(span, hx0, hy0, hx1, hy1);
+                for (int y = hy0; y < hy1; ++y)
+                    for (int x = hx0; x < hx1; ++x) {
                         if (LDS_HIST) atomicAdd(&hist[y * gx + x], 1u);
                         else atomicAdd(&tc[y * gx + x], 1u);
                     }
@@ -282,11 +283,12 @@ k_preprocess(lsr_dims d, lsr_inputs in, float *__restrict__ rec, int RF, char *_
                 const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff, y1 = rc >> 24;
                 const uint64_t key = ((uint64_t)br[it].y << 32) | ((uint32_t)i << seg.key_shift);
                 const uint32_t sp = br[it].z;
-                for (int y = y0; y < y1; ++y)
-                    for (int x = x0; x < x1; ++x) {
+                int ex0 = x0, ey0 = y0, ex1 = x1, ey1 = y1;
+                if (skip_none) reached_rect(sp, ex0, ey0, ex1, ey1);      // (the pairs pass 1 counted)
+                for (int y = ey0; y < ey1; ++y)
+                    for (int x = ex0; x < ex1; ++x) {
                         const int t = y * gx + x;
                         const uint32_t code = seg.key_shift ? span_code(sp, x - x0, y - y0) : 0u;
-                        if (skip_none && code == kCodeNone) continue;      // (not counted in pass 1 either)
                         const uint32_t slot = atomicAdd(&cur[t], 1u);
                         // position in the tile's segment, CLAMPED (not tested): the surplus keys of an overfull segment land
                         // on its last slot; such a tile is binned again by the fallback scatter

@@ -354,11 +354,10 @@ k_preprocess_sh(ShParams pk, PreShArgs a) {
             const uint32_t span = ok ? footprint_cells(pj.px, pj.py, pj.conic_a, pj.conic_b, pj.conic_c, opacity, pj.rminx, pj.rminy) : kSpanNone;
             if (ok) {
                 uint32_t *hist = a.lds_hist ? s_hist + v * T : tile_count + (size_t)v * T;
-                for (int y = pj.rminy; y < pj.rmaxy; ++y)
-                    for (int x = pj.rminx; x < pj.rmaxx; ++x) {
-                        if (skip_none && span_code(span, x - pj.rminx, y - pj.rminy) == kCodeNone) continue;   // LSR_FWD_REACHED_ONLY
-                        atomicAdd(&hist[y * gx + x], 1u);
-                    }
+                int hx0 = pj.rminx, hy0 = pj.rminy, hx1 = pj.rmaxx, hy1 = pj.rmaxy;
+                if (skip_none) reached_rect(span, hx0, hy0, hx1, hy1);      // LSR_FWD_REACHED_ONLY
+                for (int y = hy0; y < hy1; ++y)
+                    for (int x = hx0; x < hx1; ++x) atomicAdd(&hist[y * gx + x], 1u);
             }
             if (active) {
                 radii[o] = ok ? (int32_t)pj.radius : 0;
@@ -492,11 +491,12 @@ k_preprocess_sh(ShParams pk, PreShArgs a) {
                 const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff, y1 = rc >> 24;
                 const uint64_t key = ((uint64_t)br[k].y << 32) | ((uint32_t)i << a.seg.key_shift);
                 const uint32_t sp = br[k].z;
-                for (int y = y0; y < y1; ++y)
-                    for (int x = x0; x < x1; ++x) {
+                int ex0 = x0, ey0 = y0, ex1 = x1, ey1 = y1;
+                if (skip_none) reached_rect(sp, ex0, ey0, ex1, ey1);
+                for (int y = ey0; y < ey1; ++y)
+                    for (int x = ex0; x < ex1; ++x) {
                         const int t = y * gx + x;
                         const uint32_t code = a.seg.key_shift ? span_code(sp, x - x0, y - y0) : 0u;
-                        if (skip_none && code == kCodeNone) continue;
                         const uint32_t slot = atomicAdd(&cur[t], 1u);
                         const uint32_t pos = (seg0 + (uint32_t)t) * cap + min(slot + s_delta[t], cap - 1u);
                         if (slot < buf) { s_key[slot] = key | code; s_pos[slot] = pos; }

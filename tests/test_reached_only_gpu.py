@@ -44,21 +44,27 @@ def test_reached_only_binning_equals_the_published_lists_minus_the_unreachable_p
         red = util.HipRun(bi, hip_device, forward_flags=_lib.FWD_REACHED_ONLY)
     finally:
         _lib.set_knob("LSR_SEGMENTS", 1)
-    for a, b in ((full.color_out, red.color_out), (full.feat_out, red.feat_out), (full.mask_out, red.mask_out), (full.depth_out, red.depth_out)):
-        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
-    assert torch.equal(full.radii, red.radii)
-    np.testing.assert_array_equal(full.n_contrib(), red.n_contrib())
-    np.testing.assert_array_equal(full.final_T(), red.final_T())
-    np.testing.assert_array_equal(full.half_count(), red.half_count())
     assert 0 < red.P < full.P
+    compare_runs(full, red)
+
+
+def compare_runs(full, red):
+    """`red` (LSR_FWD_REACHED_ONLY) against `full` (published lists), both tests.util.HipRun of the same inputs."""
+    for a, b in ((full.color_out, red.color_out), (full.feat_out, red.feat_out), (full.mask_out, red.mask_out), (full.depth_out, red.depth_out)):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), "reached-only: images differ"
+    assert torch.equal(full.radii, red.radii), "reached-only: radii differ"
+    np.testing.assert_array_equal(full.n_contrib(), red.n_contrib(), err_msg="reached-only: n_contrib")
+    np.testing.assert_array_equal(full.final_T(), red.final_T(), err_msg="reached-only: final_T")
+    np.testing.assert_array_equal(full.half_count(), red.half_count(), err_msg="reached-only: half-list lengths")
+    assert red.P <= full.P
     lf, lr = _lists(full), _lists(red)
     dropped = 0
     for (canon, hf), (kept, hr) in zip(lf, lr):
         for h in range(2):
-            np.testing.assert_array_equal(hf[h], hr[h])                      # the render lists: bit for bit
+            np.testing.assert_array_equal(hf[h], hr[h], err_msg="reached-only: sorted tile lists (half-tile render lists)")   # bit for bit
         reach = np.zeros(0, np.int64) if len(canon) == 0 else np.unique(np.concatenate([x & 0x00FFFFFF for x in hf]).astype(np.int64))
         want = canon[np.isin(canon, reach)]                                   # the published list minus the pairs no half list holds
-        np.testing.assert_array_equal(kept, want)
+        np.testing.assert_array_equal(kept, want, err_msg="reached-only: sorted tile lists (canonical minus unreachable)")
         dropped += len(canon) - len(kept)
     assert dropped == full.P - red.P
 
