@@ -268,15 +268,22 @@ static int forward_tail(const lsr_dims &d, const lsr_inputs &in, char *geom, cha
     SideStream side;
     const bool beside = clears && env_int("LSR_CLEAR_BESIDE", 1) != 0 && side_stream(side);
     LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts, seg, speculative));
+    bool forked = false;
     if (beside) {
         LSR_HIP(hipEventRecord(side.fork, s));
         LSR_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
-        LSR_HIP(launch_clear_grad(d, out.radii, (char *)out.grad_ws, side.stream));
-        LSR_HIP(hipEventRecord(side.join, side.stream));
+        forked = true;      // from here on the side stream is joined back whatever happens (the workspace is the caller's)
+        hipError_t e = launch_clear_grad(d, out.radii, (char *)out.grad_ws, side.stream);
+        if (e == hipSuccess) e = hipEventRecord(side.join, side.stream);
+        if (e != hipSuccess) { (void)hipStreamSynchronize(side.stream); return fail_hip(e); }
     }
-    LSR_STAGE("render_forward", s, launch_render_forward(d, in, geom, bin, num_pairs, img, out, s));
-    if (beside) LSR_HIP(hipStreamWaitEvent(s, side.join, 0));
-    else if (clears) LSR_HIP(launch_clear_grad(d, out.radii, (char *)out.grad_ws, s));
+    const hipError_t er = launch_render_forward(d, in, geom, bin, num_pairs, img, out, s);
+    if (forked) {
+        const hipError_t ej = hipStreamWaitEvent(s, side.join, 0);
+        if (ej != hipSuccess) { (void)hipStreamSynchronize(side.stream); return fail_hip(ej); }
+    }
+    LSR_STAGE("render_forward", s, er);
+    if (clears && !forked) LSR_HIP(launch_clear_grad(d, out.radii, (char *)out.grad_ws, s));
     return LSR_OK;
 }
 
