@@ -7,9 +7,18 @@
 //   R_i = sum_{j>i} w_j (g . c_j)  [+ T_final (g . bg - g_mask)]  =  (g . C_rendered) - prefix_i,
 // seeded from the rendered images of the matching forward; with d_i = g . c_i
 //   dL/dalpha_i = T_i d_i - R_i / (1 - alpha_i),      R_i = R_{i-1} - w_i d_i,   T_{i+1} = T_i (1 - alpha_i)
-// i.e. one dot product and one multiply (payload gradient) per channel.  Cancellation in R only
-// matters when the remaining contribution is already ~1e-7 of the pixel's total — far below the
-// 1e-4 tolerance.
+// i.e. one dot product and one multiply (payload gradient) per channel.
+// Where the forward order is NOT good enough (round 6): R_i is a difference of two float32 totals, and dL/dalpha_i divides it
+// by (1 - alpha_i).  Behind an entry at the 0.99 alpha clamp R_i is 1 % of the total and the division multiplies its rounding
+// by 100: one or two ulps of the total became 1e-4 of dL/dalpha (profiles/r05_fuzz_parity.md: seed 203 draw 1738).  The forward
+// compositing kernels therefore flag every item in which they staged an entry of opacity >= kSteepOpacity (GeomLayout::
+// item_flags), and flagged items are walked BACK TO FRONT with the published recurrence, which never forms
+// the difference:  T_i = T_{i+1} / (1 - alpha_i),   dL/dalpha_i = T_i ((g . c_i) - S_i),   S_{i-1} = S_i + alpha_i ((g . c_i) - S_i),
+// S_n = g . bg - g_mask  (S_i = R_i / T_{i+1}: the unattenuated composite of everything behind entry i).  Same items, lists,
+// staging, reduction and flush; the batches and the per-sub-block lists are simply visited in reverse (`walk_item<REV>`).
+// Unflagged items — every item of a scene with opacities below 0.75 — keep the forward-order arithmetic bit for bit.
+// The items come in the order k_order_items (render_forward.hip) derived from the RECORD forward's per-item count of the
+// iterations THIS kernel spends on them (header word kHdrOrder2Valid), else in the tile scan's order.
 //
 // Per (entry, pixel) the kernel recomputes alpha with the forward's exact arithmetic (exponent domain, units of
 // 255 alpha: lsr_blend.h) and emits the
