@@ -1016,7 +1016,14 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     // LSR_FWD_ROWS = 0 / 1 forces the choice of the kernel, LSR_FWD_QUAD = 0 / 1 no / only sub-block items.
     const int rows_knob = env_int("LSR_FWD_ROWS", -1), quad_knob = env_int("LSR_FWD_QUAD", -1);
     const uint64_t slots = (uint64_t)p.num_cus * 24u;
-    const bool small = (nchp == 4 || nchp == 8) && (quad_knob == 1 || (rows_knob >= 0 ? rows_knob != 0 : 2ull * p.num_items <= slots));
+    // ... except for forwards that a backward follows once a quarter of the wave slots have an item (3+ views of 256 x 256): the
+    // half-tile kernel's RECORD instance narrows the render lists for the backward, which the row / sub-block items cannot, and
+    // the backward gains more than the forward loses — compositing forward + backward, rows vs half tiles (ms): 4 views of the
+    // bench scene 0.287 vs 0.283, 6 views 0.433 vs 0.420, configs[3] 0.430 vs 0.423; where pixels run out of transmittance the
+    // narrowing removes everything behind the stop: opaque splats 4 / 6 views 0.249 vs 0.218 / 0.314 vs 0.256, encoder-shaped
+    // configs[3] 0.656 vs 0.588 (step 1.013 -> 0.944).  (2 views: 0.207 vs 0.212 / 0.198 vs 0.175; 1 view: sub-block items win.)
+    const bool for_bwd = (d.forward_flags & LSR_FWD_FOR_BACKWARD) != 0 && p.ip.all_bits == 0u && env_int("LSR_FWD_RECORD", 1) != 0;
+    const bool small = (nchp == 4 || nchp == 8) && (quad_knob == 1 || (rows_knob >= 0 ? rows_knob != 0 : (2ull * p.num_items <= slots && !(for_bwd && 4ull * p.num_items >= slots))));
     if (small) {
         p.waves_per_cu = 24;
         // Sub-block items for ALL items or none.  (Measured: the costliest (slots - 2 items) / 6 items as sub-block items next

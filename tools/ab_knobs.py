@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--workloads", default="raster16,cfg3,cfg4")
     ap.add_argument("--gaussians", type=int, default=300_000, help="scene size of the raster16 workload")
+    ap.add_argument("--views", type=int, default=16, help="views of the raster16 workload")
     ap.add_argument("--opacity-scale", type=float, default=1.0 / 3.0, help="raster16: opacities U(0, scale) (1: pixels run out of transmittance)")
     ap.add_argument("--sigma", type=float, nargs=2, default=(0.3, 3.0), help="raster16: projected sigma range in pixels")
     ap.add_argument("--encoder-shaped", action="store_true", help="cfg3 / cfg4: pixel-aligned scenes in ray order (synthetic.make_encoder_scene)")
@@ -61,8 +62,8 @@ def main():
     wl = {}
     want = args.workloads.split(",")
     if "raster16" in want:
-        inp = bench.build_inputs(args.gaussians, 16, 256, dev, 1234, opacity_scale=args.opacity_scale, sigma_px=tuple(args.sigma))
-        gf = torch.randn((16, 4, 256, 256), device=dev)
+        inp = bench.build_inputs(args.gaussians, args.views, 256, dev, 1234, opacity_scale=args.opacity_scale, sigma_px=tuple(args.sigma))
+        gf = torch.randn((args.views, 4, 256, 256), device=dev)
 
         def r_fwd():
             with torch.no_grad():
