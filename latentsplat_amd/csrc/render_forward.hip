@@ -548,7 +548,10 @@ struct SmallWave {
 
 // ROW item: one wave = one row of four sub-blocks (16 x 4 pixels) of a half tile; 16-lane groups, one pixel per lane, the
 // two-pixel kernel's arithmetic per pixel (bitwise identical outputs).
-template <int NCHP>
+// REC (forwards a backward follows): the wave notes which of its row's four sub-blocks blended each entry and clears the
+// other bits of ITS nibble of the entry's list word (atomically: the half tile's other row wave owns the other nibble) —
+// the narrowing of k_render_fwd's RECORD instance, per row.
+template <int NCHP, bool REC>
 __device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const SmallWave<NCHP> &w_, uint32_t item, int grow) {
     constexpr int kEnt = SmallWave<NCHP>::kEnt;
     const int lane = w_.lane, coff = w_.coff;
@@ -579,6 +582,8 @@ __device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const 
     asm volatile("" : "+v"(kmax));
     uint64_t done = __ballot(!inside);
     uint64_t steep = 0ull;    // lanes that staged an entry of opacity >= kSteepOpacity (see k_render_fwd)
+    float kz = -kInv255;      // REC: -1/255 lives in a register (the staged record's word collects the hit bits)
+    asm volatile("" : "+v"(kz));
 
     struct StageRec { float4 a, b, pay[NCHP / 4]; uint32_t w; };
     const uint32_t last = hn - 1u;
@@ -603,7 +608,8 @@ __device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const 
         nxt = load_rec(w_ahead);
         w_ahead = load_ent(LSR_WAVE + lane);
     }
-    for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
+    uint32_t base = 0;
+    for (; base < hn; base += LSR_WAVE) {
         if (done == ~0ull) break;
         const StageRec cur = nxt;
         nxt = load_rec(w_ahead);
@@ -618,7 +624,7 @@ __device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const 
             const float4 a = cur.a, b = cur.b;
             const FoldedConic f = fold_conic(a.z, a.w, b.x, b.y);
             s_ent[lane][0] = make_float4(a.x, a.y, f.a2, f.c2);
-            s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z * kInv255, -kInv255);
+            s_ent[lane][1] = make_float4(f.b2, f.l2o, b.z * kInv255, REC ? 0.0f : -kInv255);   // (REC: hit bits, none yet)
 #pragma unroll
             for (int c4 = 0; c4 < NCHP / 4; ++c4)
                 s_ent[lane][2 + c4] = make_float4(cur.pay[c4].x * kInv255, cur.pay[c4].y * kInv255, cur.pay[c4].z * kInv255, cur.pay[c4].w * kInv255);
@@ -636,10 +642,13 @@ __device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const 
         nk = __builtin_amdgcn_readfirstlane(nk);
         wave_lds_fence();
         const uint32_t *lp = &s_list[gcol][0];
-        for (uint32_t i = 0; i < nk; ++i) {
+        uint32_t hist = 0u;    // REC: one bit per iteration of the current chunk, newest in bit 0: this lane's pixel blended the entry
+        auto entry_step = [&](uint32_t i) {
             const uint32_t off = lp[i];
             const float4 *E = (const float4 *)(ent_base + off);
-            const float4 a = E[0], b = E[1];
+            const float4 a = E[0];
+            float4 b = E[1];
+            if (REC) b.w = kz;
             float pay[NCHP];
 #pragma unroll
             for (int c4 = 0; c4 < NCHP / 4; ++c4) {
@@ -660,7 +669,12 @@ __device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const 
             const float tT = __builtin_fmaf(aT, b.w, T);                      // T (1 - alpha)   (b.w = -1 / 255)
             const uint64_t room = __ballot(tT >= LSR_T_EPS);
             const uint64_t stop = ok & ~room;
-            const float w = __builtin_amdgcn_inverse_ballot_w64(ok & room) ? aT : 0.0f;
+            const uint64_t hit = ok & room;
+            const float w = __builtin_amdgcn_inverse_ballot_w64(hit) ? aT : 0.0f;
+            if (REC) {   // hist = 2 hist + (this lane's pixel blended the entry): one add-with-carry, the carry-in being the lane mask
+                uint64_t carry_out;
+                asm volatile("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(hist), "=s"(carry_out) : "s"(hit));
+            }
 #pragma unroll
             for (int c = 0; c < NCHP; ++c) acc[c] = __builtin_fmaf(pay[c], w, acc[c]);
             D = __builtin_fmaf(b.z, w, D);                                    // depth += (z / 255) w'
@@ -672,8 +686,45 @@ __device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const 
                 pxx = st ? __builtin_nanf("") : pxx;
                 done |= stop;
             }
+        };
+        if (!REC) {
+            for (uint32_t i = 0; i < nk; ++i) entry_step(i);
+        } else {
+            // chunks of 32 iterations (the history register); after a chunk the sixteen lanes of a group OR their histories
+            // and lane j marks the group's bit on the records of the entries of iterations j and j + 16
+            const int l16 = lane & 15;
+            const uint32_t gbit = 1u << gcol;
+            for (uint32_t c0 = 0; c0 < nk; c0 += 32u) {
+                const uint32_t c1 = min(nk, c0 + 32u);
+                hist = 0u;
+                for (uint32_t i = c0; i < c1; ++i) entry_step(i);
+                hist |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hist, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+                hist |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hist, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+                hist |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hist, 0x141, 0xf, 0xf, false);   // row_half_mirror
+                hist |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hist, 0x140, 0xf, 0xf, false);   // row_mirror
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint32_t i = c0 + (uint32_t)(l16 + 16 * r);
+                    if (i < c1 && ((hist >> (c1 - 1u - i)) & 1u)) atomicOr((unsigned int *)(ent_base + lp[i] + 28), gbit);
+                }
+            }
         }
         wave_lds_fence();
+        if (REC) {
+            // this row's nibble of the entry's list word <- the sub-blocks of the row it contributed to (a subset)
+            if (m) {
+                const uint32_t hits = ((const uint32_t *)&s_ent[lane][1])[3] & 0xFu;
+                if (hits != m) atomicAnd((unsigned int *)&p.half_list_rw[(hlist - p.half_list) + e], ~(((m & ~hits) << (4 * grow)) << kListBitsShift));
+            }
+            wave_lds_fence();
+        }
+    }
+    if (REC) {
+        // every pixel of the row is finished: the entries behind blend nothing here — without this the other row's longer walk
+        // would leave this row's sub-blocks their footprint-box bits there, and the backward's lock-step batches their length
+        const uint32_t nib = 0xFu << (4 * grow + kListBitsShift);
+        for (uint32_t e = base + (uint32_t)lane; e < hn; e += LSR_WAVE)
+            if (hlist[e] & nib) atomicAnd((unsigned int *)&p.half_list_rw[(hlist - p.half_list) + e], ~nib);
     }
     if (steep && lane == 0) p.item_flags[2 * (size_t)vt + half] = kItemFlagSteep;
     typedef const float __attribute__((address_space(4))) *kfloat_ptr;
@@ -779,7 +830,8 @@ __device__ __forceinline__ void render_subblock_item(const RenderFwdParams &p, c
         nxt = load_rec(w_ahead);
         w_ahead = load_ent(LSR_WAVE + lane);
     }
-    for (uint32_t base = 0; base < hn; base += LSR_WAVE) {
+    uint32_t base = 0;
+    for (; base < hn; base += LSR_WAVE) {
         if (done == ~0ull) break;
         const StageRec cur = nxt;
         nxt = load_rec(w_ahead);
@@ -902,8 +954,8 @@ __device__ __forceinline__ void render_subblock_item(const RenderFwdParams &p, c
 
 // The launch for small view batches: the p.quad_items costliest half-tile items are rendered as eight SUB-BLOCK items
 // each, the others as two ROW items each.  The launcher asks for all or none (see there); the mix is an experiment knob.
-template <int NCHP, int WPB>
-__global__ void __launch_bounds__(LSR_WAVE * WPB)
+template <int NCHP, int WPB, bool REC = false>
+__global__ void __launch_bounds__(LSR_WAVE * WPB, (REC && WPB == 12) ? 6 : 1)   // (the REC instances must stay within six waves per SIMD: 2 x 12 per CU)
 k_render_fwd_small(RenderFwdParams p) {
     constexpr int kEnt = SmallWave<NCHP>::kEnt;
     struct Lds {
@@ -957,7 +1009,7 @@ k_render_fwd_small(RenderFwdParams p) {
             render_subblock_item<NCHP>(p, w, p.items[qi >> 3], (int)(qi & 7u));
         } else {
             const uint32_t r = qi - quad_end;
-            render_row_item<NCHP>(p, w, p.items[p.quad_items + (r >> 1)], (int)(r & 1u));
+            render_row_item<NCHP, REC>(p, w, p.items[p.quad_items + (r >> 1)], (int)(r & 1u));
         }
     }
 }
@@ -1016,14 +1068,12 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
     // LSR_FWD_ROWS = 0 / 1 forces the choice of the kernel, LSR_FWD_QUAD = 0 / 1 no / only sub-block items.
     const int rows_knob = env_int("LSR_FWD_ROWS", -1), quad_knob = env_int("LSR_FWD_QUAD", -1);
     const uint64_t slots = (uint64_t)p.num_cus * 24u;
-    // ... except for forwards that a backward follows once a quarter of the wave slots have an item (3+ views of 256 x 256): the
-    // half-tile kernel's RECORD instance narrows the render lists for the backward, which the row / sub-block items cannot, and
-    // the backward gains more than the forward loses — compositing forward + backward, rows vs half tiles (ms): 4 views of the
-    // bench scene 0.287 vs 0.283, 6 views 0.433 vs 0.420, configs[3] 0.430 vs 0.423; where pixels run out of transmittance the
-    // narrowing removes everything behind the stop: opaque splats 4 / 6 views 0.249 vs 0.218 / 0.314 vs 0.256, encoder-shaped
-    // configs[3] 0.656 vs 0.588 (step 1.013 -> 0.944).  (2 views: 0.207 vs 0.212 / 0.198 vs 0.175; 1 view: sub-block items win.)
+    // Forwards that a backward follows narrow the render lists for it while they composite: row items do it per row
+    // (render_row_item REC), sub-block items cannot (eight waves share an entry's word and one view's backward gains little).
+    // LSR_FWD_ROWREC = 0: the round-6a policy (3+ views of 256 x 256 take the half-tile RECORD kernel instead of row items).
     const bool for_bwd = (d.forward_flags & LSR_FWD_FOR_BACKWARD) != 0 && p.ip.all_bits == 0u && env_int("LSR_FWD_RECORD", 1) != 0;
-    const bool small = (nchp == 4 || nchp == 8) && (quad_knob == 1 || (rows_knob >= 0 ? rows_knob != 0 : (2ull * p.num_items <= slots && !(for_bwd && 4ull * p.num_items >= slots))));
+    const bool row_rec = env_int("LSR_FWD_ROWREC", 1) != 0;
+    const bool small = (nchp == 4 || nchp == 8) && (quad_knob == 1 || (rows_knob >= 0 ? rows_knob != 0 : (2ull * p.num_items <= slots && !(for_bwd && !row_rec && 4ull * p.num_items >= slots))));
     if (small) {
         p.waves_per_cu = 24;
         // Sub-block items for ALL items or none.  (Measured: the costliest (slots - 2 items) / 6 items as sub-block items next
@@ -1033,8 +1083,14 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
         const int forced = env_int("LSR_FWD_QUAD_ITEMS", -1);
         p.quad_items = quad_knob == 0 ? 0u : ((quad_knob == 1 || 8ull * p.num_items <= slots) ? p.num_items : 0u);
         if (forced >= 0) p.quad_items = std::min<uint32_t>(p.num_items, (uint32_t)forced);
-        if (nchp == 4) hipLaunchKernelGGL((k_render_fwd_small<4, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
-        else hipLaunchKernelGGL((k_render_fwd_small<8, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+        const bool rec = for_bwd && row_rec && p.quad_items == 0u;
+        if (nchp == 4) {
+            if (rec) hipLaunchKernelGGL((k_render_fwd_small<4, 12, true>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+            else hipLaunchKernelGGL((k_render_fwd_small<4, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+        } else {
+            if (rec) hipLaunchKernelGGL((k_render_fwd_small<8, 12, true>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+            else hipLaunchKernelGGL((k_render_fwd_small<8, 12>), dim3(p.num_cus * 2), dim3(LSR_WAVE * 12), 0, s, p);
+        }
         prof_end(kStRenderFwd, s);
         return hipGetLastError();
     }

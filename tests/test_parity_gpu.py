@@ -620,11 +620,13 @@ def test_single_pass_binning_equals_two_phase_and_falls_back_on_overflow(hip_dev
     dict(G=14_000, size=(80, 112), views=3, color_sh_degree=2, feature_channels=4),                  # 7 channels, ragged image
     dict(G=4_000, size=64, views=4, color_sh_degree=None, feature_channels=4, sigma_px=(3.0, 25.0), opacity_scale=1.0),   # long lists, pixels that run out of transmittance
 ])
-def test_forward_for_backward_narrows_the_render_lists_losslessly(hip_device, case):
+@pytest.mark.parametrize("rows", [0, 1])
+def test_forward_for_backward_narrows_the_render_lists_losslessly(hip_device, case, rows):
     """Round 5: a forward that a backward will follow (lsr_dims.forward_flags, set by the autograd op) records on which
     sub-blocks every list entry contributed and narrows the entry's sub-block bits in the half-tile render list to those.
     The images are untouched, the narrowed bits are a subset of the footprint-box bits, and the gradients the backward
-    computes from the narrowed lists are those from the original lists (up to the order of float sums)."""
+    computes from the narrowed lists are those from the original lists (up to the order of float sums).  rows = 1 (round 6):
+    the row items of small view batches narrow their own nibble of every entry's bits."""
     from latentsplat_amd import _lib
     from latentsplat_amd.rasterizer import rasterize_views
     case = dict(case)
@@ -634,7 +636,8 @@ def test_forward_for_backward_narrows_the_render_lists_losslessly(hip_device, ca
     bi = util.boundary_inputs(sc, H, W, bg=(0.3, 0.2, 0.1))
     dev = hip_device
     try:
-        _lib.set_knob("LSR_FWD_ROWS", 0)          # the half-tile kernel (the one that records) whatever the batch size
+        _lib.set_knob("LSR_FWD_ROWS", rows)       # the half-tile kernel / the row items whatever the batch size
+        _lib.set_knob("LSR_FWD_QUAD", 0)
         plain = util.HipRun(bi, dev)
         rec = util.HipRun(bi, dev, forward_flags=_lib.FWD_FOR_BACKWARD)
         for a, b in ((plain.color_out, rec.color_out), (plain.feat_out, rec.feat_out), (plain.mask_out, rec.mask_out), (plain.depth_out, rec.depth_out)):
@@ -654,6 +657,11 @@ def test_forward_for_backward_narrows_the_render_lists_losslessly(hip_device, ca
                 before += int(sum(bin(int(x)).count("1") for x in (a >> 24)))
                 after += int(sum(bin(int(x)).count("1") for x in (b >> 24)))
         assert after < 0.97 * before, (before, after)
+        if rows:   # a row stops when ITS 64 pixels are finished and clears what lies behind: never less narrowing than the half-tile kernel's
+            _lib.set_knob("LSR_FWD_ROWS", 0)
+            hh = util.HipRun(bi, dev, forward_flags=_lib.FWD_FOR_BACKWARD).half_list()
+            _lib.set_knob("LSR_FWD_ROWS", 1)
+            assert not ((hr >> 24) & ~(hh >> 24)).any(), "row-item narrowing must be at least the half-tile kernel's"
         # gradients through the autograd op, with and without the narrowing
         views = util.view_table(bi, dev)
         t = {k: (None if bi[k] is None else bi[k].to(dev)) for k in ("means", "cov6", "opac", "shs", "features")}
@@ -673,4 +681,5 @@ def test_forward_for_backward_narrows_the_render_lists_losslessly(hip_device, ca
             assert float((grads[1][k] - grads[0][k]).abs().max()) <= 2e-5 * scale, k
     finally:
         _lib.set_knob("LSR_FWD_ROWS", -1)
+        _lib.set_knob("LSR_FWD_QUAD", -1)
         _lib.set_knob("LSR_FWD_RECORD", 1)
