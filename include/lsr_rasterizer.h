@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define LSR_ABI_VERSION 9
+#define LSR_ABI_VERSION 10
 #define LSR_TILE 16            /* tile edge in pixels (16x16 = the published algorithm's tile) */
 #define LSR_MAX_FEAT_CHANNELS 32
 #define LSR_MAX_SH_DEGREE 4
@@ -144,6 +144,9 @@ typedef struct lsr_dims {
                                published lists (the bit-exact index contract; the default of the C ABI); the autograd op sets
                                it (LSR_REACHED_ONLY=0: not).  Ignored beyond 2^24 Gaussians (no footprint codes).  Hand the
                                same value to every call of a forward and to its lsr_backward.
+                               (ABI v10) bit 3, LSR_FWD_FRONT_DONE: lsr_forward_front has already launched the front half of
+                               this forward (below); only lsr_forward_nosync / lsr_forward_speculative read it, every other
+                               call ignores it.
                                Other bits must be 0 (LSR_EINVAL). */
     int32_t seg_cap_hint;   /* (ABI v9) 0, or the longest tile list (in (Gaussian, tile) pairs) the caller expects — e.g. the
                                `max_tile_pairs` of an earlier call of the same shape plus a margin.  Sizes the per-(view, tile)
@@ -156,6 +159,7 @@ typedef struct lsr_dims {
 #define LSR_FWD_FOR_BACKWARD 1
 #define LSR_FWD_CLEARS_GRAD 2
 #define LSR_FWD_REACHED_ONLY 4
+#define LSR_FWD_FRONT_DONE 8
 
 typedef struct lsr_inputs {
     const float *views;      /* [V][LSR_VIEW_FLOATS] */
@@ -317,6 +321,19 @@ int lsr_forward_speculative(const lsr_dims *d, const lsr_inputs *in, void *geom_
                             int64_t pair_capacity, int32_t max_tile_hint, const lsr_outputs *out,
                             int64_t *num_pairs_host, int32_t *max_tile_pairs_host, int32_t *overflow_host,
                             lsr_stream_t stream);
+
+/* ---- the FRONT HALF of a no-sync / speculative forward, launched early (ABI v10).  A caller that still has host work to do
+ * before it can make the full call — allocating the outputs, the image and binning workspaces: nine allocations, ~25 us of
+ * Python in the autograd op — hands over what the front half needs (dims, inputs, geom_ws, radii, the `pair_capacity` of the
+ * call to come) and the device starts on the projection / key emission / tile scan while the host goes on.  The full call
+ * then follows on the SAME host thread and stream with the same dims + LSR_FWD_FRONT_DONE, the same geom_ws,
+ * `out->radii` == radii and the same pair_capacity, and launches the rest.  Results are those of the one-call form bit for
+ * bit (the same launches in the same stream order).  A call with LSR_FWD_FRONT_DONE that does not match the thread's pending
+ * front half (other geom_ws / capacity, or none pending) returns LSR_EINVAL and launches nothing.  No allocation, no host
+ * wait: graph-capturable like lsr_forward_nosync.  A synchronised call into an idle device: V = 1 0.128 -> 0.120 ms, V = 4
+ * 0.201 -> 0.193 (profiles/r06_ab_knobs.md section 12); costs back-to-back callers one more C call (~5 us of host time). */
+int lsr_forward_front(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii, int64_t pair_capacity,
+                      lsr_stream_t stream);
 
 /* Pair count, longest tile list and overflow flag (0/1) of the most recent forward that used
  * geom_ws.  Copies 32 bytes to the host and synchronises `stream`. */

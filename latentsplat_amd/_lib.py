@@ -21,6 +21,7 @@ SH_AXES_3DGS, SH_AXES_REFERENCE = 0, 1   # lsr_dims.color_sh_convention
 FWD_FOR_BACKWARD = 1                      # lsr_dims.forward_flags
 FWD_CLEARS_GRAD = 2
 FWD_REACHED_ONLY = 4
+FWD_FRONT_DONE = 8      # (ABI v10) lsr_forward_front has launched the front half of this forward
 MAX_SH_GROUP_FLOATS = 120   # C*Kf the fused latent-SH path supports (LDS budget of sh.hip)
 MAX_FEAT_CHANNELS = 32
 
@@ -120,7 +121,7 @@ PLY_VERTEX_FLOATS = 17
 EXPORTS = (
     "lsr_abi_version", "lsr_error_string", "lsr_last_hip_error", "lsr_geom_workspace_bytes",
     "lsr_image_workspace_bytes", "lsr_binning_workspace_bytes", "lsr_grad_workspace_bytes",
-    "lsr_get_layout", "lsr_build_views", "lsr_pack_view", "lsr_forward_prepare", "lsr_forward_render", "lsr_forward_nosync", "lsr_forward_speculative",
+    "lsr_get_layout", "lsr_build_views", "lsr_pack_view", "lsr_forward_prepare", "lsr_forward_render", "lsr_forward_nosync", "lsr_forward_speculative", "lsr_forward_front",
     "lsr_forward_status", "lsr_forward_abandon", "lsr_backward",
     "lsr_profile_enable", "lsr_profile_num_stages", "lsr_profile_stage_name", "lsr_profile_read",
     "lsr_debug_set_knob", "lsr_set_projection_contraction", "lsr_get_projection_contraction",
@@ -129,7 +130,7 @@ EXPORTS = (
 )
 
 _lib = None
-ABI_VERSION = 9     # include/lsr_rasterizer.h LSR_ABI_VERSION
+ABI_VERSION = 10    # include/lsr_rasterizer.h LSR_ABI_VERSION
 
 
 def build(force: bool = False) -> str:
@@ -192,6 +193,8 @@ def load():
     lib.lsr_forward_speculative.restype = C.c_int
     lib.lsr_forward_speculative.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, P, I64, I32, C.POINTER(Outputs),
                                             C.POINTER(I64), C.POINTER(I32), C.POINTER(I32), P]
+    lib.lsr_forward_front.restype = C.c_int
+    lib.lsr_forward_front.argtypes = [C.POINTER(Dims), C.POINTER(Inputs), P, P, I64, P]
     lib.lsr_forward_abandon.restype = C.c_int
     lib.lsr_forward_abandon.argtypes = [P]
     lib.lsr_forward_status.restype = C.c_int

@@ -195,7 +195,7 @@ static int check_dims(const lsr_dims *d) {
     if (d->feat_channels > 0 && d->vs_feat != 0 && d->vs_feat != feat_elems * G) return LSR_EINVAL;
     if (d->color_sh_convention != LSR_SH_AXES_3DGS && d->color_sh_convention != LSR_SH_AXES_REFERENCE) return LSR_EINVAL;
     if (d->views_per_group < 0) return LSR_EINVAL;
-    if (d->forward_flags & ~(LSR_FWD_FOR_BACKWARD | LSR_FWD_CLEARS_GRAD | LSR_FWD_REACHED_ONLY)) return LSR_EINVAL;
+    if (d->forward_flags & ~(LSR_FWD_FOR_BACKWARD | LSR_FWD_CLEARS_GRAD | LSR_FWD_REACHED_ONLY | LSR_FWD_FRONT_DONE)) return LSR_EINVAL;
     if (d->seg_cap_hint < 0) return LSR_EINVAL;
     if (d->views_per_group > 1) {   // view groups: all inputs strided per group
         if (d->num_views % d->views_per_group != 0) return LSR_EINVAL;
@@ -535,6 +535,41 @@ int launch_front(const lsr_dims &d, const lsr_inputs &in, char *geom, int32_t *r
 }
 }  // namespace
 
+// lsr_forward_front: the front half launched ahead of the full call (ABI v10).  What the full call has to find again:
+namespace {
+struct PendingFront { const void *geom = nullptr; const void *radii = nullptr; int64_t capacity = 0; uint32_t seq = 0; hipStream_t stream = nullptr; };
+thread_local PendingFront g_front;
+// the full call's half of the handshake: true + the sequence number of the pending front half, which is consumed
+bool take_front(const void *geom, const void *radii, int64_t capacity, hipStream_t s, uint32_t &seq) {
+    const PendingFront f = g_front;
+    g_front = PendingFront();
+    if (!f.geom || f.geom != geom || f.radii != radii || f.capacity != capacity || f.stream != s) return false;
+    seq = f.seq;
+    return true;
+}
+}  // namespace
+
+int lsr_forward_front(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii, int64_t pair_capacity,
+                      lsr_stream_t stream) {
+    g_last_hip_error = 0;
+    g_front = PendingFront();
+    int rc = check_dims(d);
+    if (rc) return rc;
+    rc = check_inputs(d, in);
+    if (rc) return rc;
+    if (!geom_ws) return LSR_ENULL;
+    if (d->num_gaussians > 0 && !radii) return LSR_ENULL;
+    if (pair_capacity < 1 || pair_capacity >= ((int64_t)1 << 32)) return LSR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    HostWords hw;
+    host_words(hw);
+    const uint32_t seq = next_seq();
+    rc = launch_front(*d, *in, (char *)geom_ws, radii, &hw, seq, (uint32_t)pair_capacity, s);
+    if (rc) return rc;
+    g_front.geom = geom_ws; g_front.radii = radii; g_front.capacity = pair_capacity; g_front.seq = seq; g_front.stream = s;
+    return LSR_OK;
+}
+
 int lsr_forward_prepare(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, int32_t *radii,
                         int64_t *num_pairs_host, int32_t *max_tile_pairs_host, lsr_stream_t stream) {
     g_last_hip_error = 0;
@@ -611,8 +646,13 @@ int lsr_forward_nosync(const lsr_dims *d, const lsr_inputs *in, void *geom_ws, v
     // the same stage sequence as prepare + render; nothing between the launches waits for the device.  Single-pass
     // binning whenever the dims allow it; the fallback scatter for tiles that outgrow their key segments is always
     // launched here (its workgroups leave at once when the device's longest list fits)
-    rc = launch_front(*d, *in, geom, out->radii, nullptr, 0u, (uint32_t)pair_capacity, s);
-    if (rc) return rc;
+    if (d->forward_flags & LSR_FWD_FRONT_DONE) {       // (launched by lsr_forward_front: the counts also went to the host words, unread)
+        uint32_t seq;
+        if (!take_front(geom_ws, out->radii, pair_capacity, s, seq)) return LSR_EINVAL;
+    } else {
+        rc = launch_front(*d, *in, geom, out->radii, nullptr, 0u, (uint32_t)pair_capacity, s);
+        if (rc) return rc;
+    }
     return forward_tail(*d, *in, geom, (char *)bin_ws, (char *)img_ws, pair_capacity, max_tile_hint, *out, s, true, segment_capacity(*d) != 0u);
 }
 
@@ -640,9 +680,14 @@ int lsr_forward_speculative(const lsr_dims *d, const lsr_inputs *in, void *geom_
     // incomplete images and is reported as overflow.
     HostWords hw;
     host_words(hw);
-    const uint32_t seq = next_seq();
-    rc = launch_front(*d, *in, geom, out->radii, &hw, seq, (uint32_t)pair_capacity, s);
-    if (rc) return rc;
+    uint32_t seq;
+    if (d->forward_flags & LSR_FWD_FRONT_DONE) {
+        if (!take_front(geom_ws, out->radii, pair_capacity, s, seq)) return LSR_EINVAL;
+    } else {
+        seq = next_seq();
+        rc = launch_front(*d, *in, geom, out->radii, &hw, seq, (uint32_t)pair_capacity, s);
+        if (rc) return rc;
+    }
     rc = forward_tail(*d, *in, geom, (char *)bin_ws, (char *)img_ws, pair_capacity, max_tile_hint, *out, s, false,
                       segment_capacity(*d) != 0u, true);
     if (rc) return rc;

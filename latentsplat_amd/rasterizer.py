@@ -145,6 +145,9 @@ _SPECULATE = __import__("os").environ.get("LSR_SPECULATIVE", "1") != "0"
 _REACHED_ONLY = __import__("os").environ.get("LSR_REACHED_ONLY", "1") != "0"
 
 
+_EARLY_FRONT = __import__("os").environ.get("LSR_EARLY_FRONT", "1") != "0"     # ABI v10: the front half launched ahead of the allocations
+
+
 def set_reached_only(on: bool) -> None:
     """Whether subsequent forwards bin only the pairs that can reach a pixel (default) or the published algorithm's pairs."""
     global _REACHED_ONLY
@@ -277,11 +280,23 @@ class _RasterizeViews(torch.autograd.Function):
         geom_bytes = lib.lsr_geom_workspace_bytes(C.byref(d))
         if geom_bytes == 0:
             raise LsrError("invalid rasterizer dimensions / argument shapes")
-        geom = torch.empty(geom_bytes, **u8)
-        img = torch.empty(lib.lsr_image_workspace_bytes(C.byref(d)), **u8)
-        radii = torch.empty((V, G), dtype=torch.int32, device=dev)
         npairs, maxtile = C.c_int64(0), C.c_int32(0)
+        # a speculative forward knows its pair capacity up front: the front half (projection, key emission, tile scan) is
+        # launched as soon as its two buffers exist and the device works while the host allocates the other seven (ABI v10
+        # lsr_forward_front; a synchronised call into an idle device: V = 1 0.128 -> 0.120 ms, V = 4 0.201 -> 0.193, the
+        # reference's per-view loop 0.186 -> 0.178 per view).  Not for no-sync calls, which are issued back to back: there the
+        # second C call is 5 us of host time per call that nothing hides (V = 1 streamed 0.083 -> 0.088).
+        cap, hint = (int(1.25 * est[0]) + 4096, _tier_hint(est[1])) if est is not None else (0, 0)
+        # (a capacity the 32-bit offsets of the speculative / no-sync forward cannot address: the exact path)
+        speculate = pair_capacity <= 0 and est is not None and est[0] > 0 and not debug and cap < 2 ** 32
+        front_cap = cap if speculate else 0
         with torch.cuda.device(dev):
+            geom = torch.empty(geom_bytes, **u8)
+            radii = torch.empty((V, G), dtype=torch.int32, device=dev)
+            if _EARLY_FRONT and G > 0 and 0 < front_cap < 2 ** 32:
+                d.forward_flags |= _lib.FWD_FRONT_DONE
+                _lib.check(lib.lsr_forward_front(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii), front_cap, stream), "lsr_forward_front")
+            img = torch.empty(lib.lsr_image_workspace_bytes(C.byref(d)), **u8)
             # everything that does not depend on the pair count is allocated BEFORE prepare(): the GPU
             # idles between prepare's synchronisation and the launches of render(), so that window
             # should hold as little host work as possible
@@ -304,9 +319,7 @@ class _RasterizeViews(torch.autograd.Function):
                            "lsr_forward_nosync")
             else:
                 done = False
-                cap, hint = (int(1.25 * est[0]) + 4096, _tier_hint(est[1])) if est is not None else (0, 0)
-                # (a capacity the 32-bit offsets of the speculative / no-sync forward cannot address: the exact path)
-                if est is not None and est[0] > 0 and not debug and cap < 2 ** 32:
+                if speculate:
                     binws = torch.empty(lib.lsr_binning_workspace_bytes(C.byref(d), cap, hint), **u8)
                     ov = C.c_int32(0)
                     _lib.check(lib.lsr_forward_speculative(C.byref(d), C.byref(inp), _ptr(geom), _ptr(binws), _ptr(img), cap, hint,
@@ -318,6 +331,7 @@ class _RasterizeViews(torch.autograd.Function):
                         layout_pairs = cap          # the workspace layout the backward has to use
                 if not done:
                     SPECULATION_STATS["exact"] += 1
+                    d.forward_flags &= ~_lib.FWD_FRONT_DONE      # (a speculative forward that fell short is run again from the start)
                     try:
                         _lib.check(lib.lsr_forward_prepare(C.byref(d), C.byref(inp), _ptr(geom), _ptr(radii),
                                                            C.byref(npairs), C.byref(maxtile), stream),

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert set(names) == set(_lib.EXPORTS)
-    assert lib.lsr_abi_version() == 9
+    assert lib.lsr_abi_version() == 10
 
 
 def _dims(**kw):
@@ -85,7 +85,7 @@ def test_speculative_sort_tier_hint():
     dict(color_mode=1, sh_degree=5, sh_coeffs=36), dict(color_mode=1, sh_degree=2, sh_coeffs=4),
     dict(vs_means=7), dict(vs_feat=5), dict(cov_elems=7), dict(feat_mode=2),
     dict(feat_mode=1, feat_sh_degree=1, feat_sh_coeffs=3), dict(color_sh_convention=2),
-    dict(forward_flags=8), dict(seg_cap_hint=-1),
+    dict(forward_flags=16), dict(seg_cap_hint=-1),
 ])
 def test_invalid_dims_are_rejected(bad):
     lib = _lib.load()

@@ -397,3 +397,85 @@ def test_speculative_forward_equals_exact_and_recovers_from_overflow(hip_device)
     low_hint = run(vb, tb)
     assert rz.SPECULATION_STATS["reruns"] == reruns + 1
     same(low_hint, exact_big, "too small a tile hint == exact")
+
+
+def test_front_half_launched_early_equals_the_one_call_forward(hip_device):
+    """ABI v10: the autograd op launches the front half (projection, key emission, tile scan) through lsr_forward_front as soon as
+    geom_ws and radii exist and allocates the rest while the device works; the full call follows with LSR_FWD_FRONT_DONE.  The
+    launches and their stream order are those of the one-call form: every output bit for bit, on the exact, the speculative and
+    the no-sync path; a full call whose pending front half does not match is refused (LSR_EINVAL) without launching anything."""
+    import ctypes as C
+    from latentsplat_amd import _lib
+    from latentsplat_amd import rasterizer as rz
+    from latentsplat_amd._lib import Dims, Outputs
+    dev = hip_device
+    G, V, size = 20_000, 2, 96
+    sc = util.make_scene(G, image_size=size, views=V, color_sh_degree=1, feature_channels=4, seed=17)
+    bi = util.boundary_inputs(sc, size, size, bg=(0.1, 0.2, 0.3))
+    views = util.view_table(bi, dev)
+    t = {k: bi[k].to(dev) for k in ("means", "cov6", "opac", "shs", "features")}
+    call = lambda **kw: rz.rasterize_views(views, size, size, 1, t["means"], t["cov6"], t["opac"], shs=t["shs"], features=t["features"], **kw)
+    got = {}
+    saved = rz._EARLY_FRONT
+    try:
+        for early in (True, False):
+            rz._EARLY_FRONT = early
+            rz._ESTIMATES.clear()
+            stats = dict(rz.SPECULATION_STATS)
+            with torch.no_grad():
+                a = call()                          # first call of the shape: exact path (nothing to launch early)
+                b = call()                          # speculative
+                assert rz.SPECULATION_STATS["speculative"] == stats["speculative"] + 1
+                st = rz.last_forward_status()
+                c = call(pair_capacity=int(1.3 * st["num_pairs"]) + 64, max_tile_hint=st["max_tile_pairs"])
+                assert not rz.last_forward_status()["overflow"]
+            got[early] = [[o.clone() for o in x] for x in (a, b, c)]
+    finally:
+        rz._EARLY_FRONT = saved
+    ref = got[False][0]
+    for early in (True, False):
+        for which, outs in zip(("exact", "speculative", "no-sync"), got[early]):
+            for x, y in zip(outs, ref):
+                assert torch.equal(x, y), (early, which)
+    # gradients through the early-front speculative path (the workspaces the backward reads are the one-call form's)
+    grads = {}
+    try:
+        for early in (True, False):
+            rz._EARLY_FRONT = early
+            leaves = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+            out = rz.rasterize_views(views, size, size, 1, leaves["means"], leaves["cov6"], leaves["opac"], shs=leaves["shs"], features=leaves["features"])
+            gen = torch.Generator().manual_seed(5)
+            torch.autograd.backward([out[0], out[1]], [torch.randn(out[0].shape, generator=gen).to(dev), torch.randn(out[1].shape, generator=gen).to(dev)])
+            grads[early] = {k: v.grad.clone() for k, v in leaves.items()}
+    finally:
+        rz._EARLY_FRONT = saved
+    for k in grads[True]:
+        scale = max(1.0, float(grads[False][k].abs().max()))
+        assert float((grads[True][k] - grads[False][k]).abs().max()) <= 2e-5 * scale, k
+
+    # the handshake at the C ABI
+    lib = _lib.load()
+    run = util.HipRun(bi, dev)
+    p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    cap = run.P + 100
+    d = Dims.from_buffer_copy(run.d)
+    d.forward_flags |= _lib.FWD_FRONT_DONE
+    binws = torch.zeros(lib.lsr_binning_workspace_bytes(C.byref(d), cap, 2 ** 31 - 1), dtype=torch.uint8, device=dev)
+    outs = Outputs(p(run.color_out), p(run.feat_out), p(run.mask_out), p(run.depth_out), p(run.radii))
+    nosync = lambda capacity: lib.lsr_forward_nosync(C.byref(d), C.byref(run.inp), p(run.geom), p(binws), p(run.img), capacity, run.maxtile, C.byref(outs), stream)
+    EINVAL = -1
+    assert lib.lsr_error_string(EINVAL) and nosync(cap) == EINVAL, "the flag without a pending front half"
+    want = [x.clone() for x in (run.color_out, run.feat_out, run.mask_out, run.depth_out)]
+    for x in (run.color_out, run.feat_out, run.mask_out, run.depth_out):
+        x.fill_(-7.0)
+    _lib.check(lib.lsr_forward_front(C.byref(d), C.byref(run.inp), p(run.geom), p(run.radii), cap, stream), "front")
+    assert nosync(cap + 1) == EINVAL, "another capacity than the front half's"
+    torch.cuda.synchronize(dev)
+    assert float(run.mask_out.max()) == -7.0, "a refused call must not launch anything"
+    assert nosync(cap) == EINVAL, "the pending front half is consumed by the refused call"
+    _lib.check(lib.lsr_forward_front(C.byref(d), C.byref(run.inp), p(run.geom), p(run.radii), cap, stream), "front")
+    _lib.check(nosync(cap), "no-sync after front")
+    torch.cuda.synchronize(dev)
+    for x, y in zip((run.color_out, run.feat_out, run.mask_out, run.depth_out), want):
+        assert torch.equal(x, y)
