@@ -152,7 +152,8 @@ k_render_fwd(RenderFwdParams p) {
 #pragma unroll
         for (int c4 = 0; c4 < NCHP / 4; ++c4) s_ent[LSR_WAVE][2 + c4] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    const uint32_t num_items = EMU ? p.num_items * (uint32_t)EMU : p.num_items;
+    constexpr uint32_t kEmu = EMU ? (uint32_t)EMU : 1u;     // (a divisor the EMU = 0 instances can compile)
+    const uint32_t num_items = p.num_items * kEmu;
     const int coff = p.has_color ? 3 : 0;
     // RECORD: -1/255 lives in a register pair (the staged record's fourth word of its second quad collects the hit bits)
     float2_t kz2 = float2_t{-kInv255, -kInv255};
@@ -205,7 +206,7 @@ k_render_fwd(RenderFwdParams p) {
         uint32_t trace_iters = 0;   // lock-step iterations of this item
 #endif
         qi = __builtin_amdgcn_readfirstlane(qi);
-        const uint32_t item = p.items[EMU ? qi / (uint32_t)EMU : qi];
+        const uint32_t item = p.items[qi / kEmu];
         const uint32_t vt = item & kItemTileMask, half = item >> kItemHalfShift;
         const int tile = (int)(vt % (uint32_t)p.T), v = (int)(vt / (uint32_t)p.T);
         const int tx0 = (tile % p.gx) * LSR_TILE, ty0 = (tile / p.gx) * LSR_TILE + 8 * (int)half;
@@ -214,8 +215,8 @@ k_render_fwd(RenderFwdParams p) {
         uint32_t hn = p.half_count[2 * (size_t)vt + half];
         const uint32_t *hlist = p.half_list + 2 * (size_t)tstart + (size_t)half * tn;
         if (EMU) {   // this wave's share of the item's batches
-            const uint32_t nbat = (hn + LSR_WAVE - 1) / LSR_WAVE, part = qi % (uint32_t)EMU;
-            const uint32_t b0 = part * nbat / (uint32_t)EMU, b1 = (part + 1u) * nbat / (uint32_t)EMU;
+            const uint32_t nbat = (hn + LSR_WAVE - 1) / LSR_WAVE, part = qi % kEmu;
+            const uint32_t b0 = part * nbat / kEmu, b1 = (part + 1u) * nbat / kEmu;
             hlist += b0 * LSR_WAVE;
             hn = min(hn, b1 * LSR_WAVE) - min(hn, b0 * LSR_WAVE);
         }
