@@ -121,8 +121,9 @@ typedef struct lsr_dims {
                                actually contributed and narrows the render lists' sub-block bits to those (identical
                                images; the backward evaluates ~14 % fewer (entry, sub-block) pairs, the forward pays
                                one LDS atomic per loop iteration).  Ignored by lsr_backward itself.  Coverage: the 4- and
-                               8-channel half-tile instances (and, for the item flags of lsr_layout.geom_item_flags, the
-                               small-batch row / sub-block kernels); forwards of 9-32 payload channels and of scenes beyond
+                               8-channel half-tile instances and the row items of small view batches (2-6 views of 256 x 256);
+                               the sub-block items of single-view-sized calls write only the item flags of
+                               lsr_layout.geom_item_flags; forwards of 9-32 payload channels and of scenes beyond
                                2^24 Gaussians ignore the bit — identical results, the backward then evaluates the
                                footprint-box masks and walks every item back to front.
                                (ABI v9) bit 1, LSR_FWD_CLEARS_GRAD: the forward zeroes the gradient workspace of the
