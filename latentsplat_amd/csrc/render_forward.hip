@@ -78,6 +78,7 @@ struct RenderFwdParams {
     const uint32_t *items;        // work items, costliest first
     uint32_t num_items;           // items of this launch (2 per (view, tile))
     uint32_t quad_items;          // k_render_fwd_small: leading (costliest) items rendered as sub-block items
+    uint32_t all_live;            // LSR_FWD_LIVE=0 (development knob): finished sub-blocks keep their lists (the round-5 behaviour)
     uint32_t *queue;              // work-queue head (zeroed per forward)
     uint32_t *bin_queue;          // per-SIMD-bin queue heads (zeroed per forward), or nullptr: one global queue
     const uint32_t *header;       // geometry-workspace header (pair count: the launch's mean list length)
@@ -287,7 +288,20 @@ k_render_fwd(RenderFwdParams p) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) s_list[b][lane] = null_off;
             const uint32_t e = base + lane;
-            const uint32_t m = e < hn ? (((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) : 0u;   // sub-blocks of this half the entry can reach (never 0 for a list entry)
+            // sub-blocks that still have a pixel to blend (scalar: the lane masks of the finished pixels).  An entry is staged
+            // and listed only for those — a finished sub-block's list would still count into the lock-step length of every
+            // batch behind its stop.  Scenes whose pixels run out of transmittance — opaque 1-10 px splats: this kernel 0.282 ->
+            // 0.222 ms per 16 views, the row items of 4 views 0.214 -> 0.111; encoder-shaped configs[4] 0.451 -> 0.421; the bench
+            // scene's pixels practically never finish: unchanged (profiles/r06_ab_knobs.md section 13)
+            uint32_t live = 0xFFu;
+            if ((done0 | done1) && !p.all_live) {
+                const uint64_t nd = ~(done0 & done1);
+                live = 0u;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) live |= (uint32_t)(((nd >> (8 * g)) & 0xFFull) != 0ull) << g;
+            }
+            const uint32_t m_full = e < hn ? (((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) : 0u;   // sub-blocks of this half the entry can reach (never 0 for a list entry)
+            const uint32_t m = m_full & live;
             if (RECORD) steep |= __ballot(m != 0u && cur.b.y >= kSteepOpacity);
             if (m) {
                 const float4 a = cur.a, b = cur.b;
@@ -413,9 +427,9 @@ k_render_fwd(RenderFwdParams p) {
             if (RECORD) {
                 // the staged entry's sub-block bits <- the sub-blocks it contributed to (a subset of them)
                 uint32_t hits = 0u;
-                if (m) {
-                    hits = ((const uint32_t *)&s_ent[lane][1])[3] & 0xFFu;
-                    if (hits != m) p.half_list_rw[(hlist - p.half_list) + e] = (cur.w & kListIndexMask) | (hits << kListBitsShift);
+                if (m_full) {     // (an entry all of whose sub-blocks had finished was not staged: no hits)
+                    if (m) hits = ((const uint32_t *)&s_ent[lane][1])[3] & 0xFFu;
+                    if (hits != m_full) p.half_list_rw[(hlist - p.half_list) + e] = (cur.w & kListIndexMask) | (hits << kListBitsShift);
                 }
                 if (p.item_cost) {     // the iterations the BACKWARD will spend on this batch: its longest narrowed sub-block list
                     uint32_t longest = 0u;
@@ -618,8 +632,16 @@ __device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const 
 #pragma unroll
         for (int b = 0; b < 4; ++b) s_list[b][lane] = null_off;
         const uint32_t e = base + lane;
-        // the four sub-blocks of THIS row the entry can reach (bits 4 grow .. 4 grow + 3 of its half mask)
-        const uint32_t m = e < hn ? (((((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) >> (4 * grow)) & 0xFu) : 0u;
+        // the four sub-blocks of THIS row the entry can reach (bits 4 grow .. 4 grow + 3 of its half mask) ...
+        const uint32_t m_full = e < hn ? (((((cur.w >> kListBitsShift) | p.ip.all_bits) & 0xFFu) >> (4 * grow)) & 0xFu) : 0u;
+        // ... and of those the ones that still have a pixel to blend (see k_render_fwd)
+        uint32_t live = 0xFu;
+        if (done && !p.all_live) {
+            live = 0u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) live |= (uint32_t)(((~done >> (16 * g)) & 0xFFFFull) != 0ull) << g;
+        }
+        const uint32_t m = m_full & live;
         steep |= __ballot(m != 0u && cur.b.y >= kSteepOpacity);
         if (m) {
             const float4 a = cur.a, b = cur.b;
@@ -713,9 +735,9 @@ __device__ __forceinline__ void render_row_item(const RenderFwdParams &p, const 
         wave_lds_fence();
         if (REC) {
             // this row's nibble of the entry's list word <- the sub-blocks of the row it contributed to (a subset)
-            if (m) {
-                const uint32_t hits = ((const uint32_t *)&s_ent[lane][1])[3] & 0xFu;
-                if (hits != m) atomicAnd((unsigned int *)&p.half_list_rw[(hlist - p.half_list) + e], ~(((m & ~hits) << (4 * grow)) << kListBitsShift));
+            if (m_full) {     // (an entry all of whose sub-blocks had finished was not staged: no hits)
+                const uint32_t hits = m ? ((const uint32_t *)&s_ent[lane][1])[3] & 0xFu : 0u;
+                if (hits != m_full) atomicAnd((unsigned int *)&p.half_list_rw[(hlist - p.half_list) + e], ~(((m_full & ~hits) << (4 * grow)) << kListBitsShift));
             }
             wave_lds_fence();
         }
@@ -1048,6 +1070,7 @@ hipError_t launch_render_forward(const lsr_dims &d, const lsr_inputs &in, const 
 
     p.trace = nullptr;
     p.quad_items = 0;
+    p.all_live = env_int("LSR_FWD_LIVE", 1) == 0 ? 1u : 0u;
 #ifdef LSR_ENABLE_TRACE
     const int64_t max_items = 2 * (int64_t)p.T * d.num_views * 4;     // (x 4: the EMU instances' units)
     const char *trace_path = getenv("LSR_TRACE");
