@@ -479,3 +479,36 @@ def test_front_half_launched_early_equals_the_one_call_forward(hip_device):
     torch.cuda.synchronize(dev)
     for x, y in zip((run.color_out, run.feat_out, run.mask_out, run.depth_out), want):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("rows", [0, 1])
+@pytest.mark.parametrize("record", [0, 1])
+def test_finished_subblocks_leave_the_compaction_without_changing_anything(hip_device, rows, record):
+    """Round 6: once every pixel of a 4x4 sub-block has run out of transmittance the forward kernels stop listing entries for it
+    (its lanes would blend nothing; its list would still set the lock-step length of every batch).  LSR_FWD_LIVE=0 keeps the
+    round-5 behaviour: images, final T, n_contrib and — in a forward a backward follows — the narrowed render lists must be the
+    same bit for bit, for the half-tile kernel and the row items, on a scene whose pixels do finish (and a ragged image edge)."""
+    from latentsplat_amd import _lib
+    sc = util.make_scene(5_000, image_size=72, views=3, color_sh_degree=1, feature_channels=4, sigma_px=(2.0, 14.0), opacity_scale=1.0, seed=29)
+    bi = util.boundary_inputs(sc, 72, 60, bg=(0.3, 0.1, 0.2))
+    runs = {}
+    try:
+        _lib.set_knob("LSR_FWD_ROWS", rows)
+        _lib.set_knob("LSR_FWD_QUAD", 0)
+        for live in (1, 0):
+            _lib.set_knob("LSR_FWD_LIVE", live)
+            runs[live] = util.HipRun(bi, hip_device, forward_flags=_lib.FWD_FOR_BACKWARD if record else 0)
+    finally:
+        _lib.set_knob("LSR_FWD_LIVE", 1)
+        _lib.set_knob("LSR_FWD_ROWS", -1)
+        _lib.set_knob("LSR_FWD_QUAD", -1)
+    a, b = runs[1], runs[0]
+    assert float((a.mask_out > 1.0 - 2e-4).float().mean()) > 0.2, "the scene must saturate a good part of its pixels"
+    for x, y in ((a.color_out, b.color_out), (a.feat_out, b.feat_out), (a.mask_out, b.mask_out), (a.depth_out, b.depth_out)):
+        assert torch.equal(x, y)
+    assert np.array_equal(a.n_contrib(), b.n_contrib()) and np.array_equal(a.final_T(), b.final_T())
+    assert np.array_equal(a.half_count(), b.half_count())
+    assert np.array_equal(a.half_list(), b.half_list()), "the narrowed lists must not depend on the compaction's masks"
+    # (an entry staged for no live sub-block is not looked at any more: the "steep" item flags may only shrink)
+    (fa, va), (fb, vb) = a.item_flags(), b.item_flags()
+    assert va == vb and not (fa & ~fb).any()
