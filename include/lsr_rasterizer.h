@@ -128,7 +128,7 @@ typedef struct lsr_dims {
                                footprint-box masks and walks every item back to front.
                                (ABI v9) bit 1, LSR_FWD_CLEARS_GRAD: the forward zeroes the gradient workspace of the
                                lsr_backward that follows (lsr_outputs.grad_ws, sized by lsr_grad_workspace_bytes) — beside
-                               its per-tile sort and compositing kernels, on a library-owned side stream forked from and
+                               its compositing kernel, on a library-owned side stream (workspaces below ~110 MB: in line behind it) forked from and
                                joined back into `stream` with events inside the call (graph-capturable; 16 views x 300 k:
                                0.05 ms of the forward + backward step) — and lsr_backward, handed dims with the same bit,
                                skips its clear.  Set it for BOTH calls or

@@ -263,10 +263,14 @@ static int forward_tail(const lsr_dims &d, const lsr_inputs &in, char *geom, cha
     // forward + backward step at 16 views x 300 k when it runs alone in front of the compositing backward) costs it 0.011 ms.
     // Measured (profiles/r06_ab_knobs.md section 5): forward + backward 1.0775 -> 1.056 ms; forked in front of the per-tile
     // sort as well, the sort pays what the clear saves (0.068 -> 0.098 ms: 1.089); the compositing waves storing the zeros
-    // themselves, a few KB per batch: 1.058.  LSR_CLEAR_BESIDE=0: the clear runs behind the compositing kernel on `s`.
+    // themselves, a few KB per batch: 1.058.  The fork / join costs 15-20 us of its own: below ~110 MB of workspace the clear
+    // is shorter than that and runs in line behind the compositing kernel (forward + backward, beside vs in line: 2 views x
+    // 300 k 0.290 vs 0.283 ms, 4 views 0.3863 vs 0.3845, configs[3] 0.745 vs 0.741; 6 views 0.552 vs 0.559, configs[4] 2.18 vs
+    // 2.20: section 5).  LSR_CLEAR_BESIDE = 0 / 1: never / always beside.
     const bool clears = (d.forward_flags & LSR_FWD_CLEARS_GRAD) != 0 && d.num_gaussians > 0;
     SideStream side;
-    const bool beside = clears && env_int("LSR_CLEAR_BESIDE", 1) != 0 && side_stream(side);
+    const int beside_knob = env_int("LSR_CLEAR_BESIDE", -1);
+    const bool beside = clears && (beside_knob >= 0 ? beside_knob != 0 : grad_layout(d).fixed >= (size_t)110 * 1000 * 1000) && side_stream(side);
     LSR_STAGE("binning", s, launch_binning(d, geom, bin, num_pairs, max_tile_pairs, out.radii, s, device_counts, seg, speculative));
     bool forked = false;
     if (beside) {

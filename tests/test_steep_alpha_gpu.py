@@ -167,12 +167,13 @@ def test_forward_zeroes_the_gradient_workspace(hip_device, views, G):
             return first, {k: v.grad.clone() for k, v in leaves.items()}
         return first, None
 
-    a, b = run(True)
     try:
+        _lib.set_knob("LSR_CLEAR_BESIDE", 1)      # (forced: by default workspaces below ~110 MB are cleared in line)
+        a, b = run(True)
         _lib.set_knob("LSR_CLEAR_BESIDE", 0)
         c, _ = run(False)
     finally:
-        _lib.set_knob("LSR_CLEAR_BESIDE", 1)
+        _lib.set_knob("LSR_CLEAR_BESIDE", -1)
     for k in a:
         assert torch.isfinite(a[k]).all(), k
         scale = max(1.0, float(a[k].abs().max()))

@@ -20,7 +20,7 @@ import bench  # noqa: E402
 from latentsplat_amd import _lib  # noqa: E402
 from latentsplat_amd.rasterizer import rasterize_views  # noqa: E402
 
-DEFAULTS = {"LSR_REORDER": 1, "LSR_CLEAR_BESIDE": 1, "LSR_FWD_BINQ": -1, "LSR_BWD_BINQ": 0, "LSR_BWD_REV": 2, "LSR_BWD_PARTS": -1, "LSR_BWD_PRIO_PCT": -1, "LSR_FWD_PRIO_PCT": -1, "LSR_FWD_RECORD": 1, "LSR_SEGMENTS": 1, "LSR_PRE_ITEMS": 8, "LSR_FOLD_SCAN": 1, "LSR_HOST_POLL": 1, "LSR_SORT_LPT": 1, "LSR_FUSE_SH": 1, "LSR_FWD_VARIANT": 0, "LSR_BWD_VARIANT": 0, "LSR_FWD_ROWS": -1, "LSR_FWD_ROWREC": 1, "LSR_FWD_QUAD": -1, "LSR_FWD_LIVE": 1}
+DEFAULTS = {"LSR_REORDER": 1, "LSR_CLEAR_BESIDE": -1, "LSR_FWD_BINQ": -1, "LSR_BWD_BINQ": 0, "LSR_BWD_REV": 2, "LSR_BWD_PARTS": -1, "LSR_BWD_PRIO_PCT": -1, "LSR_FWD_PRIO_PCT": -1, "LSR_FWD_RECORD": 1, "LSR_SEGMENTS": 1, "LSR_PRE_ITEMS": 8, "LSR_FOLD_SCAN": 1, "LSR_HOST_POLL": 1, "LSR_SORT_LPT": 1, "LSR_FUSE_SH": 1, "LSR_FWD_VARIANT": 0, "LSR_BWD_VARIANT": 0, "LSR_FWD_ROWS": -1, "LSR_FWD_ROWREC": 1, "LSR_FWD_QUAD": -1, "LSR_FWD_LIVE": 1}
 
 
 def timed(fn, steps, dev):
